@@ -1,0 +1,520 @@
+/* ==========================================================================
+ * oracle/plo_oracle.c -- TEST INFRASTRUCTURE ONLY (see plo_oracle.h header).
+ *
+ * Literal CPU restatement, in plain C, of the per-candidate kernel of
+ * PLinOpt's randomized CSE search over Z_p.  Each function cites the lines of
+ * /root/reference it follows.  Data structures are deliberately naive (sorted
+ * arrays standing in for std::map, linear scans) so that behaviour can be read
+ * against the reference line by line; this file is the checker, never the
+ * product.  "parity unpinned" w.r.t. the genuine binary: see plo_oracle.h.
+ * ========================================================================== */
+#include "plo_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ field */
+/* Givaro::Modular<Integer> semantics: canonical residues in [0,p), integer
+ * order on residues. */
+static uint32_t f_mul(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)(((uint64_t)a * b) % p); }
+static uint32_t f_neg(uint32_t a, uint32_t p) { return a ? p - a : 0; }
+static uint32_t f_inv(uint32_t a, uint32_t p) {
+    int64_t t = 0, nt = 1, r = p, nr = a % p;
+    while (nr) { int64_t q = r / nr, x = t - q * nt; t = nt; nt = x; x = r - q * nr; r = nr; nr = x; }
+    if (t < 0) t += p;
+    return (uint32_t)t;
+}
+static uint32_t f_div(uint32_t a, uint32_t b, uint32_t p) { return f_mul(a, f_inv(b, p), p); }
+static int f_isone(uint32_t e, uint32_t p) { return e == 1u % p; }
+static int f_ismone(uint32_t e, uint32_t p) { return e == p - 1; }
+/* plinopt_library.h:189-197 */
+static int f_absone(uint32_t e, uint32_t p) { return f_isone(e, p) || f_ismone(e, p); }
+/* Fabs, plinopt_library.h:209-213: a = -e; return a<e ? a : e */
+static uint32_t f_abs(uint32_t e, uint32_t p) { uint32_t a = f_neg(e, p); return a < e ? a : e; }
+/* Fsign, plinopt_library.h:220-225 */
+static int f_sign(uint32_t e, uint32_t p) { if (!e) return 0; return f_neg(e, p) < e ? -1 : 1; }
+
+/* -------------------------------------------------------------------- rng */
+static uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+uint32_t plo_oracle_rng_state0(uint64_t seed) { return 1u + (uint32_t)(splitmix64(seed) % 2147483646ull); }
+uint32_t plo_oracle_rng_next(uint32_t *s) { *s = (uint32_t)((950706376ull * (uint64_t)*s) % 2147483647ull); return *s; }
+
+/* --------------------------------------------------------------- containers */
+typedef struct { uint32_t col, val; } ent_t;
+typedef struct { ent_t *e; int n, cap; } row_t;
+typedef struct { row_t *r; int nrows, rcap; int ncols; uint32_t p; } mat_t;
+typedef struct { uint32_t a, b, r; } tri_t;
+typedef struct { tri_t *t; int n, cap; } trivec_t;
+typedef struct { tri_t k; uint32_t cnt; } mapent_t;
+typedef struct { mapent_t *e; int n, cap; } pmap_t;             /* std::map<triple,size_t>, sorted */
+typedef struct { uint32_t idx, col, val; } mult_t;             /* multiples: (var, col, value) */
+typedef struct { mult_t *m; int n, cap; } mults_t;
+typedef struct { char *s; size_t n, cap; int on; } sink_t;
+
+static void *xrealloc(void *q, size_t n) { void *r = realloc(q, n ? n : 1); if (!r) abort(); return r; }
+static void row_push(row_t *r, uint32_t c, uint32_t v) {
+    if (r->n == r->cap) { r->cap = r->cap ? 2 * r->cap : 8; r->e = (ent_t *)xrealloc(r->e, sizeof(ent_t) * r->cap); }
+    r->e[r->n].col = c; r->e[r->n].val = v; r->n++;
+}
+static void row_erase(row_t *r, int k) { memmove(r->e + k, r->e + k + 1, sizeof(ent_t) * (r->n - k - 1)); r->n--; }
+static void mat_init(mat_t *M, int nrows, int ncols, uint32_t p) {
+    M->r = (row_t *)calloc(nrows ? nrows : 1, sizeof(row_t)); M->nrows = nrows; M->rcap = nrows ? nrows : 1; M->ncols = ncols; M->p = p;
+}
+static void mat_free(mat_t *M) { for (int i = 0; i < M->nrows; i++) free(M->r[i].e); free(M->r); M->r = NULL; M->nrows = 0; }
+static void mat_addrow(mat_t *M) {   /* resize(rowdim+1, coldim) */
+    if (M->nrows == M->rcap) { M->rcap *= 2; M->r = (row_t *)xrealloc(M->r, sizeof(row_t) * M->rcap); }
+    memset(&M->r[M->nrows], 0, sizeof(row_t)); M->nrows++;
+}
+/* Transpose, plinopt_library.inl:18-24: T = A^T, rows of T sorted by index. */
+static void mat_transpose(mat_t *T, const mat_t *A) {
+    mat_free(T); mat_init(T, A->ncols, A->nrows, A->p);
+    for (int i = 0; i < A->nrows; i++)
+        for (int k = 0; k < A->r[i].n; k++) row_push(&T->r[A->r[i].e[k].col], (uint32_t)i, A->r[i].e[k].val);
+}
+static void tv_push(trivec_t *v, tri_t t) {
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 16; v->t = (tri_t *)xrealloc(v->t, sizeof(tri_t) * v->cap); }
+    v->t[v->n++] = t;
+}
+static int tri_cmp(const tri_t *x, const tri_t *y) {       /* std::tuple operator< */
+    if (x->a != y->a) return x->a < y->a ? -1 : 1;
+    if (x->b != y->b) return x->b < y->b ? -1 : 1;
+    if (x->r != y->r) return x->r < y->r ? -1 : 1;
+    return 0;
+}
+static int pm_find(const pmap_t *m, const tri_t *k, int *pos) {
+    int lo = 0, hi = m->n;
+    while (lo < hi) { int mid = (lo + hi) / 2; int c = tri_cmp(&m->e[mid].k, k); if (c < 0) lo = mid + 1; else hi = mid; }
+    *pos = lo; return lo < m->n && tri_cmp(&m->e[lo].k, k) == 0;
+}
+static void pm_inc(pmap_t *m, const tri_t *k) {
+    int pos; if (pm_find(m, k, &pos)) { m->e[pos].cnt++; return; }
+    if (m->n == m->cap) { m->cap = m->cap ? 2 * m->cap : 64; m->e = (mapent_t *)xrealloc(m->e, sizeof(mapent_t) * m->cap); }
+    memmove(m->e + pos + 1, m->e + pos, sizeof(mapent_t) * (m->n - pos));
+    m->e[pos].k = *k; m->e[pos].cnt = 1; m->n++;
+}
+static void pm_dec(pmap_t *m, const tri_t *k) {
+    int pos; if (!pm_find(m, k, &pos)) abort();
+    if (--m->e[pos].cnt == 0) { memmove(m->e + pos, m->e + pos + 1, sizeof(mapent_t) * (m->n - pos - 1)); m->n--; }
+}
+static void mults_push(mults_t *v, uint32_t idx, uint32_t col, uint32_t val) {
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 16; v->m = (mult_t *)xrealloc(v->m, sizeof(mult_t) * v->cap); }
+    v->m[v->n].idx = idx; v->m[v->n].col = col; v->m[v->n].val = val; v->n++;
+}
+static void sk_put(sink_t *s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#include <stdarg.h>
+static void sk_put(sink_t *s, const char *fmt, ...) {
+    if (!s->on) return;
+    char buf[96]; va_list ap; va_start(ap, fmt); int k = vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (s->n + (size_t)k + 1 > s->cap) { s->cap = 2 * s->cap + 256; s->s = (char *)xrealloc(s->s, s->cap); }
+    memcpy(s->s + s->n, buf, (size_t)k + 1); s->n += (size_t)k;
+}
+/* printmulorjustdiv, generic version plinopt_library.inl:348-358 */
+static void print_mul(sink_t *s, char c, uint32_t i, uint32_t e, uint32_t *nbmul, uint32_t p) {
+    sk_put(s, "%c%u", c, i);
+    if (!f_absone(e, p)) { ++*nbmul; sk_put(s, "*%u", e); }
+}
+
+/* listpairs, plinopt_optimize.inl:30-41 */
+static void listpairs(trivec_t *v, const row_t *row, uint32_t p) {
+    v->n = 0;
+    for (int a = 0; a < row->n; a++)
+        for (int b = a + 1; b < row->n; b++) {
+            tri_t t = { row->e[a].col, row->e[b].col, f_div(row->e[b].val, row->e[a].val, p) };
+            tv_push(v, t);
+        }
+}
+static int tv_has(const trivec_t *v, const tri_t *k) {
+    for (int i = 0; i < v->n; i++) if (tri_cmp(&v->t[i], k) == 0) return 1;
+    return 0;
+}
+
+typedef struct {
+    mat_t M; mults_t multiples; uint32_t nbadd, nbmul; uint32_t rng; sink_t out; char ouv, tev, rav;
+} cand_t;
+
+/* RemOneCSE with updateAPM=true, plinopt_optimize.inl:60-194 */
+static void rem_one_cse(cand_t *C, const tri_t *cse, trivec_t *AllPairs, pmap_t *PairMap) {
+    mat_t *lM = &C->M; const uint32_t p = lM->p; uint32_t lm = (uint32_t)lM->ncols;
+    /* :70-77 number of +-1 in either column */
+    uint32_t count0 = 0, count1 = 0;
+    for (int i = 0; i < lM->nrows; i++)
+        for (int k = 0; k < lM->r[i].n; k++) {
+            const ent_t *e = &lM->r[i].e[k];
+            if (e->col == cse->a && f_absone(e->val, p)) ++count0;
+            if (e->col == cse->b && f_absone(e->val, p)) ++count1;
+        }
+    tri_t lcse;                                                   /* :79-88 */
+    if (count0 < count1) { lcse.a = cse->b; lcse.b = cse->a; lcse.r = f_inv(cse->r, p); }
+    else { lcse = *cse; }
+    trivec_t newrow = { 0, 0, 0 };
+    for (int i = 0; i < lM->nrows; i++) {                         /* :92-148 */
+        if (!tv_has(&AllPairs[i], cse)) continue;
+        row_t *row = &lM->r[i]; uint32_t coeff = 0;
+        for (int k = 0; k < row->n; k++) if (row->e[k].col == lcse.a) { coeff = row->e[k].val; row_erase(row, k); break; }
+        for (int k = 0; k < row->n; k++) if (row->e[k].col == lcse.b) { row_erase(row, k); row_push(row, lm, coeff); break; }
+        for (int k = 0; k < AllPairs[i].n; k++) pm_dec(PairMap, &AllPairs[i].t[k]);          /* :115-118 */
+        newrow.n = 0;
+        for (int k = 0; k < AllPairs[i].n; k++) {                                              /* :121-130 */
+            const tri_t *t = &AllPairs[i].t[k];
+            if (t->a != lcse.a && t->b != lcse.a && t->a != lcse.b && t->b != lcse.b) tv_push(&newrow, *t);
+        }
+        const ent_t *last = &row->e[row->n - 1];                                               /* :132-137 */
+        for (int k = 0; k < row->n - 1; k++) {
+            tri_t t = { row->e[k].col, last->col, f_div(last->val, row->e[k].val, p) };
+            tv_push(&newrow, t);
+        }
+        for (int k = 0; k < newrow.n; k++) pm_inc(PairMap, &newrow.t[k]);                     /* :140-142 */
+        AllPairs[i].n = 0;
+        for (int k = 0; k < newrow.n; k++) tv_push(&AllPairs[i], newrow.t[k]);                /* :145 */
+    }
+    free(newrow.t);
+    /* :153-169 multiplier reuse */
+    uint32_t asgs = f_abs(lcse.r, p), rindex = lm;
+    if (!f_absone(asgs, p)) {
+        for (int k = 0; k < C->multiples.n; k++)
+            if (C->multiples.m[k].col == lcse.b && C->multiples.m[k].val == asgs) { rindex = C->multiples.m[k].idx; break; }
+        if (rindex == lm) {
+            sk_put(&C->out, "%c%u:=", C->rav, lm);
+            print_mul(&C->out, C->tev, lcse.b, asgs, &C->nbmul, p);
+            sk_put(&C->out, ";\n");
+            mults_push(&C->multiples, lm, lcse.b, asgs);
+        }
+    }
+    /* :175-186 */
+    sk_put(&C->out, "%c%u:=%c%u", C->tev, lm, C->tev, lcse.a);
+    sk_put(&C->out, (f_ismone(asgs, p) || f_sign(lcse.r, p) < 0) ? "-" : "+");
+    if (f_absone(asgs, p)) sk_put(&C->out, "%c%u", C->tev, lcse.b);
+    else sk_put(&C->out, "%c%u", C->rav, rindex);
+    sk_put(&C->out, ";\n");
+    lM->ncols = (int)lm + 1;                                      /* :190-191 */
+}
+
+/* OneSub, plinopt_optimize.inl:209-314 (RANDOM_TIES, no DENSITY_OPTIMIZATION).
+ * ties_out/ties_cap: optional capture of the first tie set (test hook). */
+static int one_sub(cand_t *C, uint32_t *ties_out, int ties_cap, int *nties_out, uint32_t *maxfrq_out) {
+    mat_t *M = &C->M; const uint32_t p = M->p;
+    trivec_t *AllPairs = (trivec_t *)calloc(M->nrows ? M->nrows : 1, sizeof(trivec_t));
+    pmap_t PairMap = { 0, 0, 0 };
+    for (int i = 0; i < M->nrows; i++) listpairs(&AllPairs[i], &M->r[i], p);                  /* :214-217 */
+    for (int i = 0; i < M->nrows; i++) for (int k = 0; k < AllPairs[i].n; k++) pm_inc(&PairMap, &AllPairs[i].t[k]);
+    int ret = 0;
+    if (PairMap.n == 0) { ret = 0; goto done; }                                               /* :233 */
+    {
+        int goodfreq = 0; ret = 1;
+        tri_t *MaxCSE = (tri_t *)malloc(sizeof(tri_t) * (size_t)(PairMap.n + 1)); int mcap = PairMap.n + 1;
+        while (PairMap.n > 0) {                                                               /* :237 */
+            uint32_t maxfrq = 0; int nmax = 0;
+            if (PairMap.n + 1 > mcap) { mcap = 2 * PairMap.n + 1; MaxCSE = (tri_t *)xrealloc(MaxCSE, sizeof(tri_t) * (size_t)mcap); }
+            for (int k = 0; k < PairMap.n; k++) {                                             /* :244-253 */
+                if (PairMap.e[k].cnt == maxfrq) MaxCSE[nmax++] = PairMap.e[k].k;
+                if (PairMap.e[k].cnt > maxfrq) { maxfrq = PairMap.e[k].cnt; nmax = 0; MaxCSE[nmax++] = PairMap.e[k].k; }
+            }
+            if (nties_out) {                       /* test hook: report first tie set and stop */
+                *nties_out = nmax; *maxfrq_out = maxfrq;
+                for (int k = 0; k < nmax && k < ties_cap; k++) { ties_out[3*k] = MaxCSE[k].a; ties_out[3*k+1] = MaxCSE[k].b; ties_out[3*k+2] = MaxCSE[k].r; }
+                ret = 0; break;
+            }
+            if (maxfrq <= 1) { ret = goodfreq; break; }                                       /* :255 */
+            goodfreq = 1;
+            tri_t cse = MaxCSE[0];
+            if (nmax > 1) cse = MaxCSE[plo_oracle_rng_next(&C->rng) % (uint32_t)nmax];       /* :260-265 */
+            ++C->nbadd;                                                                       /* :292 */
+            rem_one_cse(C, &cse, AllPairs, &PairMap);
+        }
+        free(MaxCSE);
+    }
+done:
+    for (int i = 0; i < M->nrows; i++) free(AllPairs[i].t);
+    free(AllPairs); free(PairMap.e);
+    return ret;
+}
+
+/* value histogram in ascending value order (std::map<Element,size_t>) */
+typedef struct { uint32_t val, cnt; } vh_t;
+static int vh_build(vh_t **out, const row_t *row, uint32_t p) {
+    vh_t *h = (vh_t *)malloc(sizeof(vh_t) * (size_t)(row->n + 1)); int n = 0;
+    for (int k = 0; k < row->n; k++) {
+        uint32_t a = f_abs(row->e[k].val, p); int pos = 0;
+        while (pos < n && h[pos].val < a) pos++;
+        if (pos < n && h[pos].val == a) { h[pos].cnt++; continue; }
+        memmove(h + pos + 1, h + pos, sizeof(vh_t) * (size_t)(n - pos)); h[pos].val = a; h[pos].cnt = 1; n++;
+    }
+    *out = h; return n;
+}
+
+/* FactorOutColumns, plinopt_optimize.inl:318-371 (T is the transposed matrix) */
+static void factor_out_columns(cand_t *C, mat_t *T, uint32_t j) {
+    const uint32_t p = T->p;
+    if (T->r[j].n == 0) return;
+    vh_t *h; int nh = vh_build(&h, &T->r[j], p);
+    for (int q = 0; q < nh; q++) {
+        uint32_t element = h[q].val, frequency = h[q].cnt, m = (uint32_t)T->nrows;
+        if (frequency > 1 && !f_absone(element, p)) {
+            uint32_t rindex = m;
+            for (int k = 0; k < C->multiples.n; k++)
+                if (C->multiples.m[k].col == j && C->multiples.m[k].val == element) { rindex = C->multiples.m[k].idx; break; }
+            if (rindex == m) {
+                sk_put(&C->out, "%c%u:=", C->rav, m);
+                print_mul(&C->out, C->tev, j, element, &C->nbmul, p);
+                sk_put(&C->out, ";\n");
+                mults_push(&C->multiples, m, j, element);
+            }
+            sk_put(&C->out, "%c%u:=%c%u;\n", C->tev, m, C->rav, rindex);
+            mat_addrow(T); ++m;
+            for (uint32_t k = 0; k < frequency; k++) {
+                row_t *row = &T->r[j];
+                for (int z = 0; z < row->n; z++)
+                    if (f_abs(row->e[z].val, p) == element) {
+                        row_push(&T->r[m - 1], row->e[z].col, f_sign(row->e[z].val, p) >= 0 ? 1u % p : p - 1);
+                        row_erase(row, z); break;
+                    }
+            }
+        }
+    }
+    free(h);
+}
+
+/* FactorOutRows, plinopt_optimize.inl:375-420 */
+static void factor_out_rows(cand_t *C, mat_t *M, uint32_t i) {
+    const uint32_t p = M->p;
+    if (M->r[i].n == 0) return;
+    vh_t *h; int nh = vh_build(&h, &M->r[i], p);
+    uint32_t m = (uint32_t)M->ncols;
+    for (int q = 0; q < nh; q++) {
+        uint32_t element = h[q].val, frequency = h[q].cnt;
+        if (frequency > 1 && !f_absone(element, p)) {
+            sk_put(&C->out, "%c%u:=", C->tev, m);
+            ++m; M->ncols = (int)m;
+            row_t *row = &M->r[i];
+            row_push(row, m - 1, element);
+            for (int z = 0; z < row->n; z++)
+                if (f_abs(row->e[z].val, p) == element) {
+                    if (f_sign(row->e[z].val, p) < 0) sk_put(&C->out, "-");
+                    sk_put(&C->out, "%c%u", C->tev, row->e[z].col);
+                    row_erase(row, z); break;
+                }
+            for (uint32_t k = 1; k < frequency; k++)
+                for (int z = 0; z < row->n; z++)
+                    if (f_abs(row->e[z].val, p) == element) {
+                        ++C->nbadd;
+                        sk_put(&C->out, "%c%c%u", f_sign(row->e[z].val, p) < 0 ? '-' : '+', C->tev, row->e[z].col);
+                        row_erase(row, z); break;
+                    }
+            sk_put(&C->out, ";\n");
+        }
+    }
+    free(h);
+}
+
+/* Triangle, plinopt_optimize.inl:427-507.  The `found` flag is never reset
+ * inside the do-while, so after the first hit later passes only examine the
+ * first qualifying (iter,next) couple -- restated as written. */
+static int triangle(cand_t *C, mat_t *M, mat_t *T, uint32_t j) {
+    const uint32_t p = T->p;
+    if (T->r[j].n == 0) return 0;
+    int found = 0, over;
+    do {
+        over = 1;
+        for (int it = 0; it < T->r[j].n; it++) {
+            if (f_absone(T->r[j].e[it].val, p)) continue;
+            for (int nx = 0; nx < T->r[j].n; nx++) {
+                if (nx == it || f_absone(T->r[j].e[nx].val, p)) continue;
+                const ent_t iter = T->r[j].e[it], next = T->r[j].e[nx];
+                const uint32_t i = next.col;
+                const uint32_t quot = f_div(next.val, iter.val, p);
+                const row_t *rowi = &M->r[i];
+                for (int th = 0; th < rowi->n; th++) {
+                    if (rowi->e[th].col == j || f_absone(rowi->e[th].val, p)) continue;
+                    uint32_t coeff = f_div(quot, rowi->e[th].val, p);
+                    if (f_absone(coeff, p)) {
+                        uint32_t m = (uint32_t)T->nrows;
+                        found = 1; over = 0;
+                        sk_put(&C->out, "%c%u:=", C->tev, m);                                  /* :458-464 */
+                        uint32_t ais = f_abs(iter.val, p);
+                        if (f_sign(iter.val, p) < 0 || f_ismone(iter.val, p)) sk_put(&C->out, "-");
+                        print_mul(&C->out, C->tev, j, ais, &C->nbmul, p);
+                        sk_put(&C->out, ";\n");
+                        mults_push(&C->multiples, m, j, iter.val);
+                        mat_addrow(T); ++m;                                                    /* :479-481 */
+                        row_push(&T->r[m - 1], iter.col, 1u % p);
+                        row_push(&T->r[m - 1], next.col, quot);
+                        {   /* :484-489 remove iter & next from T[j] */
+                            row_t *cj = &T->r[j]; int w = 0;
+                            for (int z = 0; z < cj->n; z++) {
+                                int kill = (cj->e[z].col == iter.col && cj->e[z].val == iter.val) ||
+                                           (cj->e[z].col == next.col && cj->e[z].val == next.val);
+                                if (!kill) cj->e[w++] = cj->e[z];
+                            }
+                            cj->n = w;
+                        }
+                        mat_transpose(M, T);                                                   /* :491 */
+                        factor_out_rows(C, M, i);                                              /* :495-496 */
+                        mat_transpose(T, M);                                                   /* :498 */
+                        break;
+                    }
+                }
+                if (found) break;
+            }
+            if (found) break;
+        }
+    } while (!over);
+    return found;
+}
+
+/* ProgramGen, plinopt_optimize.inl:513-611 */
+static void program_gen(cand_t *C) {
+    mat_t *M = &C->M; const uint32_t p = M->p;
+    mat_t T; memset(&T, 0, sizeof T); mat_init(&T, 0, 0, p);
+    mat_transpose(&T, M);
+    { int nc = M->ncols; for (int j = 0; j < nc; j++) factor_out_columns(C, &T, (uint32_t)j); }  /* :528-531 */
+    mat_transpose(M, &T);
+    for (int i = 0; i < M->nrows; i++) factor_out_rows(C, M, (uint32_t)i);                       /* :535-537 */
+    mat_transpose(&T, M);
+    for (int j = 0; j < M->ncols; j++) triangle(C, M, &T, (uint32_t)j);                          /* :542-544 */
+    for (int i = 0; i < M->nrows; i++) {                                                         /* :547-604 */
+        const row_t *row = &M->r[i];
+        if (row->n > 0) {
+            sk_put(&C->out, "%c%d:=", C->ouv, i);
+            for (int k = 0; k < row->n; k++) {
+                const ent_t *e = &row->e[k];
+                uint32_t ais = f_abs(e->val, p), rindex = (uint32_t)M->ncols;
+                if (k > 0) ++C->nbadd;                                                           /* :576 */
+                for (int z = 0; z < C->multiples.n; z++)
+                    if (C->multiples.m[z].col == e->col && C->multiples.m[z].val == ais) { rindex = C->multiples.m[z].idx; break; }
+                if (rindex != (uint32_t)M->ncols) {
+                    if (k == 0) { if (ais != e->val) sk_put(&C->out, "-"); }
+                    else sk_put(&C->out, ais == e->val ? "+" : "-");
+                    sk_put(&C->out, "%c%u", C->rav, rindex);
+                } else {
+                    int neg = f_sign(e->val, p) < 0 || f_ismone(e->val, p);
+                    if (k == 0) { if (neg) sk_put(&C->out, "-"); }
+                    else sk_put(&C->out, neg ? "-" : "+");
+                    print_mul(&C->out, C->tev, e->col, ais, &C->nbmul, p);
+                }
+            }
+            sk_put(&C->out, ";\n");
+        } else {
+            sk_put(&C->out, "%c%d:=0;\n", C->ouv, i);
+        }
+    }
+    mat_free(&T);
+}
+
+static void cand_load(cand_t *C, uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col,
+                      const uint32_t *val, uint32_t p, uint64_t seed, const char *letters, int text) {
+    memset(C, 0, sizeof *C);
+    mat_init(&C->M, (int)m, (int)n, p);
+    for (uint32_t i = 0; i < m; i++)
+        for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; k++) row_push(&C->M.r[i], col[k], val[k]);
+    C->rng = plo_oracle_rng_state0(seed);
+    C->ouv = letters[0]; C->tev = letters[1]; C->rav = letters[2];
+    C->out.on = text;
+}
+static void cand_free(cand_t *C) { mat_free(&C->M); free(C->multiples.m); }
+
+/* Optimizer, plinopt_optimize.inl:616-631 */
+static void optimizer(cand_t *C) {
+    while (one_sub(C, NULL, 0, NULL, NULL)) { }
+    program_gen(C);
+}
+
+int plo_oracle_optimizer(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col,
+                         const uint32_t *val, uint32_t p, uint64_t seed, const char letters[4],
+                         uint32_t *adds, uint32_t *muls, char **text) {
+    if (p < 2) return -1;
+    cand_t C; cand_load(&C, m, n, rowptr, col, val, p, seed, letters, text != NULL);
+    if (text) {   /* input2Temps, plinopt_library.inl:319-331: only used columns */
+        unsigned char *used = (unsigned char *)calloc(n ? n : 1, 1);
+        for (uint32_t k = 0; k < rowptr[m]; k++) used[col[k]] = 1;
+        for (uint32_t j = 0; j < n; j++) if (used[j]) sk_put(&C.out, "%c%u:=%c%u;\n", letters[1], j, letters[3], j);
+        free(used);
+    }
+    optimizer(&C);
+    if (adds) *adds = C.nbadd;
+    if (muls) *muls = C.nbmul;
+    if (text) { if (!C.out.s) { C.out.s = (char *)xrealloc(NULL, 1); C.out.s[0] = 0; } *text = C.out.s; }
+    cand_free(&C);
+    return 0;
+}
+
+int plo_oracle_cost_many(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col,
+                         const uint32_t *val, uint32_t p, const uint64_t *seeds, uint64_t seed0,
+                         uint64_t nseeds, uint32_t *adds, uint32_t *muls, int nthreads) {
+    if (p < 2) return -1;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+    for (int64_t k = 0; k < (int64_t)nseeds; k++) {
+        cand_t C; cand_load(&C, m, n, rowptr, col, val, p, seeds ? seeds[k] : seed0 + (uint64_t)k, "otri", 0);
+        optimizer(&C);
+        adds[k] = C.nbadd; muls[k] = C.nbmul;
+        cand_free(&C);
+    }
+    return 0;
+}
+
+static uint64_t cost_key(uint32_t a, uint32_t mu, int mode) {
+    switch (mode) {
+    case 1: return ((uint64_t)a << 32) | mu;                       /* adds, then muls */
+    case 2: return ((uint64_t)(a + mu) << 32);                     /* sum only */
+    default: return ((uint64_t)(a + mu) << 32) | a;                /* sum, then adds */
+    }
+}
+
+int plo_oracle_cse_search(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col,
+                          const uint32_t *val, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode,
+                          uint32_t *best_adds, uint32_t *best_muls, uint64_t *best_seed, int nthreads) {
+    if (p < 2) return -1;
+    if (nthreads < 1) nthreads = 1;
+    uint64_t bkey = ~0ull, bseed = ~0ull; uint32_t ba = ~0u, bm = ~0u;
+#pragma omp parallel num_threads(nthreads)
+    {
+        uint64_t lkey = ~0ull, lseed = ~0ull; uint32_t la = ~0u, lmu = ~0u;
+#pragma omp for schedule(dynamic, 16) nowait
+        for (int64_t k = 0; k < (int64_t)nseeds; k++) {
+            uint64_t s = seed0 + (uint64_t)k;
+            cand_t C; cand_load(&C, m, n, rowptr, col, val, p, s, "otri", 0);
+            optimizer(&C);
+            uint64_t key = cost_key(C.nbadd, C.nbmul, cost_mode);
+            if (key < lkey || (key == lkey && s < lseed)) { lkey = key; lseed = s; la = C.nbadd; lmu = C.nbmul; }
+            cand_free(&C);
+        }
+#pragma omp critical
+        if (lkey < bkey || (lkey == bkey && lseed < bseed)) { bkey = lkey; bseed = lseed; ba = la; bm = lmu; }
+    }
+    *best_adds = ba; *best_muls = bm; *best_seed = bseed;
+    return 0;
+}
+
+int plo_oracle_first_ties(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col,
+                          const uint32_t *val, uint32_t p, uint32_t *tri_abr, int cap, uint32_t *maxfrq) {
+    cand_t C; cand_load(&C, m, n, rowptr, col, val, p, 0, "otri", 0);
+    int nt = 0; *maxfrq = 0;
+    one_sub(&C, tri_abr, cap, &nt, maxfrq);
+    cand_free(&C);
+    return nt;
+}
+
+void plo_oracle_naive_ops(uint32_t m, const uint32_t *rowptr, const uint32_t *val, uint32_t p,
+                          uint32_t *adds, uint32_t *muls) {
+    uint32_t a = 0, mu = 0;
+    for (uint32_t i = 0; i < m; i++) { uint32_t len = rowptr[i + 1] - rowptr[i]; if (len > 1) a += len - 1; }
+    for (uint32_t k = 0; k < rowptr[m]; k++) if (!f_absone(val[k], p)) ++mu;
+    *adds = a; *muls = mu;
+}
+
+void plo_oracle_free(void *q) { free(q); }
+int plo_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,83 @@
+/* ==========================================================================
+ * oracle/plo_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of PLinOpt's per-candidate `Optimizer()` and of
+ * the `CSEOptimiser` restart loop over a prime field Z_p (p < 2^31), used as
+ * the checker for the HIP path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product
+ * (plinopt_amd/, libplinopt_hip.so, bin/) never does.
+ *
+ * PARITY STATUS: "parity unpinned" against the genuine reference binary (it
+ * cannot be built here: LinBox/Givaro absent) and the
+ * reference's tests hold no golden op-count/text for this path.  What IS
+ * pinned (tests/test_oracle_*.py): every emitted SLP evaluates to the input
+ * matrix (the reference's own `slpcheck` criterion, Makefile:85-87,
+ * bin/FDT.sh:58), reported counts equal the op-count of the emitted text under
+ * `lineOperations` rules (plinopt_programs.inl:116-133), the hand-checked
+ * Winograd tie set of SURVEY.md 8c, and best costs <= the stored-SLP bounds.
+ *
+ * Citations are relative to /root/reference/.
+ * ========================================================================== */
+#ifndef PLO_ORACLE_H
+#define PLO_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-candidate random stream (the build's frozen definition; the reference
+ * uses a time-seeded thread_local Givaro::GivRandom, plinopt_optimize.inl:263-265):
+ *   state0 = 1 + splitmix64(seed) mod (2^31-2)
+ *   next() : state = 950706376 * state mod (2^31-1); return state   (GivRandom LCG)
+ *   tie pick = next() mod #ties                                                       */
+uint32_t plo_oracle_rng_state0(uint64_t seed);
+uint32_t plo_oracle_rng_next(uint32_t *state);
+
+/* One candidate: include/plinopt_optimize.inl:616-631 (Optimizer), preceded by
+ * the driver's `input2Temps` preamble (plinopt_library.inl:319-331) when
+ * text != NULL.  Matrix is CSR, columns sorted per row, values in [1,p).
+ * letters = {ouv, tev, rav, inv} e.g. "otri".  *text (if non-NULL) receives a
+ * malloc'd NUL-terminated program; free with plo_oracle_free.
+ * Returns 0, or <0 on error. */
+int plo_oracle_optimizer(uint32_t m, uint32_t n, const uint32_t *rowptr,
+                         const uint32_t *col, const uint32_t *val, uint32_t p,
+                         uint64_t seed, const char letters[4],
+                         uint32_t *adds, uint32_t *muls, char **text);
+
+/* Costs of many seeds (count only).  OpenMP-parallel over seeds when
+ * nthreads > 1.  seeds == NULL means seed0, seed0+1, ... */
+int plo_oracle_cost_many(uint32_t m, uint32_t n, const uint32_t *rowptr,
+                         const uint32_t *col, const uint32_t *val, uint32_t p,
+                         const uint64_t *seeds, uint64_t seed0, uint64_t nseeds,
+                         uint32_t *adds, uint32_t *muls, int nthreads);
+
+/* Restart loop: plinopt_optimize.inl:1193-1247 (CSEOptimiser) with the total
+ * order (cmpOpCount key, seed): cost_mode 0 = sum then adds (default,
+ * plinopt_optimize.h:61-63), 1 = adds then muls (OPTIMIZE_ADDITIONS :54-55),
+ * 2 = sum only (OPTIMIZE_SUMS :57-58). */
+int plo_oracle_cse_search(uint32_t m, uint32_t n, const uint32_t *rowptr,
+                          const uint32_t *col, const uint32_t *val, uint32_t p,
+                          uint64_t seed0, uint64_t nseeds, int cost_mode,
+                          uint32_t *best_adds, uint32_t *best_muls,
+                          uint64_t *best_seed, int nthreads);
+
+/* First-step tie set (for the hand-checked Winograd fixture): writes up to cap
+ * triples (a,b,r) of maximal frequency in map order; returns their number and
+ * the frequency in *maxfrq. */
+int plo_oracle_first_ties(uint32_t m, uint32_t n, const uint32_t *rowptr,
+                          const uint32_t *col, const uint32_t *val, uint32_t p,
+                          uint32_t *tri_abr, int cap, uint32_t *maxfrq);
+
+/* naiveOps: plinopt_library.inl:227-235 */
+void plo_oracle_naive_ops(uint32_t m, const uint32_t *rowptr,
+                          const uint32_t *val, uint32_t p,
+                          uint32_t *adds, uint32_t *muls);
+
+void plo_oracle_free(void *ptr);
+int plo_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

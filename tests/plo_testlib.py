@@ -1,0 +1,348 @@
+"""Independent test-side checkers (pure Python, no product code):
+
+* SMS reader (format: /root/reference/README.md:71-77, data/README.md:10-16),
+* SLP evaluator -> matrix (what /root/reference/src/SLPchecker.cpp:22-105 checks),
+* op counter with `lineOperations` rules (/root/reference/include/plinopt_programs.inl:116-133),
+* ctypes binding of oracle/libplo_oracle.so (the CPU checker).
+
+Nothing here reads /root/reference at run time; data fixtures live in tests/golden/data.
+"""
+import ctypes
+import os
+import re
+import subprocess
+from fractions import Fraction
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(GOLDEN, "data")
+
+
+# ----------------------------------------------------------------------------- SMS
+def read_sms(path):
+    """Returns (m, n, {(i,j): Fraction}) with 0-based indices."""
+    ent = {}
+    m = n = None
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#") or line.startswith("%"):
+                continue
+            tok = line.split()
+            if m is None:
+                m, n = int(tok[0]), int(tok[1])
+                continue
+            i, j = int(tok[0]), int(tok[1])
+            if i == 0 and j == 0:
+                break
+            v = Fraction(tok[2])
+            if v != 0:
+                ent[(i - 1, j - 1)] = v
+    return m, n, ent
+
+
+def to_csr_mod(m, n, ent, p):
+    """CSR over Z_p (rational a/b -> a*b^-1 mod p; entries vanishing mod p dropped)."""
+    rows = [[] for _ in range(m)]
+    for (i, j), v in ent.items():
+        r = (v.numerator % p) * pow(v.denominator % p, -1, p) % p
+        if r:
+            rows[i].append((j, r))
+    rowptr, col, val = [0], [], []
+    for r in rows:
+        r.sort()
+        for j, v in r:
+            col.append(j)
+            val.append(v)
+        rowptr.append(len(col))
+    return rowptr, col, val
+
+
+# ----------------------------------------------------------------------------- SLP
+_TOK = re.compile(r"\s*(:=|[A-Za-z_][A-Za-z_0-9]*|\d+|[-+*/();])")
+
+
+class _Parser:
+    """Recursive-descent evaluation of `lhs:=expr;` into sparse linear forms
+    {input_index or 'c': coeff} over a field given by (add, mul, inv, from_int)."""
+
+    def __init__(self, field):
+        self.F = field
+        self.vars = {}
+
+    def lin_add(self, x, y, sign=1):
+        F = self.F
+        out = dict(x)
+        for k, v in y.items():
+            nv = F.add(out.get(k, F.zero), v if sign > 0 else F.neg(v))
+            if nv == F.zero:
+                out.pop(k, None)
+            else:
+                out[k] = nv
+        return out
+
+    def lin_scale(self, x, c):
+        F = self.F
+        out = {}
+        for k, v in x.items():
+            nv = F.mul(v, c)
+            if nv != F.zero:
+                out[k] = nv
+        return out
+
+    def is_const(self, x):
+        return all(k == "c" for k in x)
+
+    def const(self, x):
+        return x.get("c", self.F.zero)
+
+    def parse_line(self, toks):
+        self.t = toks
+        self.i = 0
+        lhs = self.next()
+        assert self.next() == ":=", toks
+        val = self.expr()
+        assert self.peek() == ";", toks
+        self.vars[lhs] = val
+        return lhs
+
+    def peek(self):
+        return self.t[self.i] if self.i < len(self.t) else None
+
+    def next(self):
+        tok = self.t[self.i]
+        self.i += 1
+        return tok
+
+    def expr(self):
+        sign = 1
+        if self.peek() in "+-":
+            sign = -1 if self.next() == "-" else 1
+        acc = self.term()
+        if sign < 0:
+            acc = self.lin_scale(acc, self.F.neg(self.F.one))
+        while self.peek() in ("+", "-"):
+            op = self.next()
+            acc = self.lin_add(acc, self.term(), 1 if op == "+" else -1)
+        return acc
+
+    def term(self):
+        acc = self.factor()
+        while self.peek() in ("*", "/"):
+            op = self.next()
+            rhs = self.factor()
+            if op == "*":
+                if self.is_const(rhs):
+                    acc = self.lin_scale(acc, self.const(rhs))
+                else:
+                    assert self.is_const(acc), "non-linear product"
+                    acc = self.lin_scale(rhs, self.const(acc))
+            else:
+                assert self.is_const(rhs), "division by non-constant"
+                acc = self.lin_scale(acc, self.F.inv(self.const(rhs)))
+        return acc
+
+    def factor(self):
+        tok = self.next()
+        if tok == "(":
+            v = self.expr()
+            assert self.next() == ")"
+            return v
+        if tok == "-":
+            return self.lin_scale(self.factor(), self.F.neg(self.F.one))
+        if tok.isdigit():
+            c = self.F.from_int(int(tok))
+            return {"c": c} if c != self.F.zero else {}
+        if tok in self.vars:
+            return self.vars[tok]
+        if tok[0] == "i" and tok[1:].isdigit():
+            return {int(tok[1:]): self.F.one}
+        raise KeyError("undefined variable %s" % tok)
+
+
+class FieldQ:
+    zero, one = Fraction(0), Fraction(1)
+    add = staticmethod(lambda a, b: a + b)
+    mul = staticmethod(lambda a, b: a * b)
+    neg = staticmethod(lambda a: -a)
+    inv = staticmethod(lambda a: 1 / a)
+    from_int = staticmethod(lambda n: Fraction(n))
+
+
+class FieldP:
+    def __init__(self, p):
+        self.p = p
+        self.zero, self.one = 0, 1 % p
+
+    def add(self, a, b):
+        return (a + b) % self.p
+
+    def mul(self, a, b):
+        return a * b % self.p
+
+    def neg(self, a):
+        return (-a) % self.p
+
+    def inv(self, a):
+        return pow(a, -1, self.p)
+
+    def from_int(self, n):
+        return n % self.p
+
+
+def tokenize_slp(text):
+    lines = []
+    for raw in text.splitlines():
+        raw = raw.split("#", 1)[0].strip()
+        if not raw or ":=" not in raw:
+            continue
+        toks = _TOK.findall(raw)
+        assert "".join(toks) == re.sub(r"\s+", "", raw), raw
+        lines.append(toks)
+    return lines
+
+
+def eval_slp(text, field, outchar="o"):
+    """Returns {(i,j): coeff} of the matrix computed on outputs `o#` from inputs `i#`."""
+    P = _Parser(field)
+    for toks in tokenize_slp(text):
+        P.parse_line(toks)
+    mat = {}
+    for name, lin in P.vars.items():
+        if name[0] == outchar and name[1:].isdigit():
+            i = int(name[1:])
+            for k, v in lin.items():
+                assert k != "c", "constant term in output"
+                mat[(i, k)] = v
+    return mat
+
+
+def count_ops(text):
+    """(adds, muls) with lineOperations semantics: a sign right after ':=' or '('
+    is a negation, not an addition; every '*' or '/' *operator* is one multiplication
+    (a rational constant a/b is one token, plinopt_programs.inl:646-659)."""
+    adds = muls = 0
+    for toks in tokenize_slp(text):
+        # merge natural '/' natural into one rational token, as programParser does
+        merged = []
+        k = 0
+        while k < len(toks):
+            if (toks[k].isdigit() and k + 2 < len(toks) and toks[k + 1] == "/" and toks[k + 2].isdigit()):
+                merged.append(toks[k] + "/" + toks[k + 2])
+                k += 3
+            else:
+                merged.append(toks[k])
+                k += 1
+        negator = False
+        for w in merged:
+            if w in ("+", "-") and not negator:
+                adds += 1
+            elif w in ("*", "/"):
+                muls += 1
+            negator = w in (":=", "(")
+    return adds, muls
+
+
+# ----------------------------------------------------------------------------- oracle binding
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(ROOT, "oracle", "libplo_oracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        L = ctypes.CDLL(so)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        L.plo_oracle_optimizer.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32,
+                                           ctypes.c_uint64, ctypes.c_char_p, u32p, u32p,
+                                           ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_oracle_cost_many.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32,
+                                           u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, ctypes.c_int]
+        L.plo_oracle_cse_search.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32,
+                                            ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, u32p, u32p, u64p,
+                                            ctypes.c_int]
+        L.plo_oracle_first_ties.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32,
+                                            u32p, ctypes.c_int, u32p]
+        L.plo_oracle_naive_ops.argtypes = [ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p, u32p]
+        L.plo_oracle_naive_ops.restype = None
+        L.plo_oracle_free.argtypes = [ctypes.c_void_p]
+        L.plo_oracle_free.restype = None
+        L.plo_oracle_rng_state0.argtypes = [ctypes.c_uint64]
+        L.plo_oracle_rng_state0.restype = ctypes.c_uint32
+        L.plo_oracle_rng_next.argtypes = [u32p]
+        L.plo_oracle_rng_next.restype = ctypes.c_uint32
+        _oracle = L
+    return _oracle
+
+
+def _arr(xs, ty=ctypes.c_uint32):
+    return (ty * max(len(xs), 1))(*xs)
+
+
+class OracleMatrix:
+    """CSR over Z_p handed to the oracle."""
+
+    def __init__(self, m, n, rowptr, col, val, p):
+        self.m, self.n, self.p = m, n, p
+        self.rowptr, self.col, self.val = list(rowptr), list(col), list(val)
+        self._rp, self._c, self._v = _arr(self.rowptr), _arr(self.col), _arr(self.val)
+
+    @classmethod
+    def from_sms(cls, path, p):
+        m, n, ent = read_sms(path)
+        rp, c, v = to_csr_mod(m, n, ent, p)
+        return cls(m, n, rp, c, v, p)
+
+    def dense(self):
+        d = {}
+        for i in range(self.m):
+            for k in range(self.rowptr[i], self.rowptr[i + 1]):
+                d[(i, self.col[k])] = self.val[k]
+        return d
+
+    def optimizer(self, seed, letters=b"otri", text=True):
+        a, mu = ctypes.c_uint32(), ctypes.c_uint32()
+        tp = ctypes.c_void_p()
+        rc = oracle().plo_oracle_optimizer(self.m, self.n, self._rp, self._c, self._v, self.p, seed, letters,
+                                           ctypes.byref(a), ctypes.byref(mu),
+                                           ctypes.byref(tp) if text else None)
+        assert rc == 0
+        s = None
+        if text:
+            s = ctypes.string_at(tp).decode()
+            oracle().plo_oracle_free(tp)
+        return a.value, mu.value, s
+
+    def cost_many(self, seeds=None, seed0=0, nseeds=0, nthreads=1):
+        if seeds is not None:
+            nseeds = len(seeds)
+            sp = _arr(seeds, ctypes.c_uint64)
+        else:
+            sp = None
+        adds, muls = (ctypes.c_uint32 * max(nseeds, 1))(), (ctypes.c_uint32 * max(nseeds, 1))()
+        rc = oracle().plo_oracle_cost_many(self.m, self.n, self._rp, self._c, self._v, self.p, sp, seed0, nseeds,
+                                           adds, muls, nthreads)
+        assert rc == 0
+        return list(adds[:nseeds]), list(muls[:nseeds])
+
+    def search(self, seed0, nseeds, cost_mode=0, nthreads=1):
+        a, mu, s = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        rc = oracle().plo_oracle_cse_search(self.m, self.n, self._rp, self._c, self._v, self.p, seed0, nseeds,
+                                            cost_mode, ctypes.byref(a), ctypes.byref(mu), ctypes.byref(s), nthreads)
+        assert rc == 0
+        return a.value, mu.value, s.value
+
+    def first_ties(self, cap=4096):
+        buf = (ctypes.c_uint32 * (3 * cap))()
+        mf = ctypes.c_uint32()
+        nt = oracle().plo_oracle_first_ties(self.m, self.n, self._rp, self._c, self._v, self.p, buf, cap,
+                                            ctypes.byref(mf))
+        return [(buf[3 * k], buf[3 * k + 1], buf[3 * k + 2]) for k in range(min(nt, cap))], mf.value
+
+    def naive_ops(self):
+        a, mu = ctypes.c_uint32(), ctypes.c_uint32()
+        oracle().plo_oracle_naive_ops(self.m, self._rp, self._v, self.p, ctypes.byref(a), ctypes.byref(mu))
+        return a.value, mu.value
