@@ -1,0 +1,106 @@
+/* ==========================================================================
+ * plinopt_hip.h -- C-ABI of libplinopt_hip.so, the MI355X (gfx950) drop-in for
+ * PLinOpt's randomized multi-start search for minimum-cost straight-line
+ * programs.  The reference has no FFI: the seam is the body of its OpenMP
+ * restart loops.  Each entry point names the reference code it replaces
+ * (paths relative to the reference tree).  Plain pointers and sizes only.
+ *
+ * Randomness: the reference draws from a time-seeded thread_local
+ * Givaro::GivRandom (include/plinopt_optimize.inl:263-265), so it has no
+ * reproducible "seed".  Here every candidate owns a stream defined by its
+ * 64-bit seed:  state0 = 1 + splitmix64(seed) mod (2^31-2);
+ * next(): state = 950706376*state mod (2^31-1) (the GivRandom LCG);
+ * tie pick = next() mod #ties, ties in std::map order of (col_a,col_b,ratio).
+ * ========================================================================== */
+#ifndef PLINOPT_HIP_H
+#define PLINOPT_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes (0 = ok; negative = error; text via plo_last_error()) */
+#define PLO_OK            0
+#define PLO_E_ARG        -1   /* bad argument (null pointer, p<2, unsorted row ...) */
+#define PLO_E_HIP        -2   /* HIP runtime error / no device / extension missing  */
+#define PLO_E_CAPACITY   -3   /* matrix too large for the LDS-resident kernel        */
+#define PLO_E_UNSUPPORTED -4  /* feature not available on the device path            */
+#define PLO_E_INTERNAL   -5   /* device-side consistency check failed                */
+
+/* Sparse matrix over Z_p in CSR: what FMatrix lM(M,F) holds at
+ * include/plinopt_optimize.inl:1206 (LinBox SparseMatrix<Field,SparseSeq> after
+ * rebind: rows of (column, residue) sorted by column, residues in [1,p)). */
+typedef struct {
+    uint32_t m, n;            /* rows, columns */
+    const uint32_t *rowptr;   /* m+1 */
+    const uint32_t *col;      /* nnz, strictly increasing inside a row */
+    const uint32_t *val;      /* nnz, canonical residues in [1,p) */
+} plo_csr_t;
+
+/* Best candidate: Pair<size_t> nbops of CSEOptimiser (adds, muls) + its seed.
+ * adds = muls = UINT32_MAX is the reference's Pair<size_t>{-1,-1} "+infinity"
+ * (include/plinopt_optimize.inl:883). */
+typedef struct {
+    uint32_t adds, muls;
+    uint64_t seed;
+} plo_best_t;
+
+typedef struct {
+    double   seconds;        /* host wall clock of the call (upload excluded if plan reused) */
+    double   kernel_ms;      /* sum of search-kernel durations, HIP events on the launch stream */
+    uint64_t candidates;     /* candidates evaluated */
+    uint32_t launches;       /* kernel launches */
+    uint32_t lds_bytes;      /* dynamic LDS per workgroup */
+    uint32_t waves_per_wg;   /* candidates in flight per workgroup */
+    uint32_t grid;           /* workgroups per launch */
+    uint64_t algo_bytes;     /* algorithmic bytes per candidate, B_cand = 8*nnz + 12*P0 + 8 */
+} plo_stats_t;
+
+/* cost order of the restart loop, include/plinopt_optimize.h:53-64 */
+#define PLO_COST_SUM_THEN_ADD 0   /* default cmpOpCount            */
+#define PLO_COST_ADD_THEN_MUL 1   /* -DOPTIMIZE_ADDITIONS           */
+#define PLO_COST_SUM          2   /* -DOPTIMIZE_SUMS                */
+
+typedef struct plo_plan plo_plan_t;   /* a matrix prepared and resident in HBM */
+
+/* Library life cycle.  device = HIP ordinal (one process per GPU). */
+int plo_init(int device);
+int plo_shutdown(void);
+const char *plo_last_error(void);
+int plo_device_count(void);
+
+/* Upload one matrix (replaces the per-restart copies `FMatrix lM(M,F), lT(T,F)`
+ * of include/plinopt_optimize.inl:1206-1207: the matrix is converted once). */
+int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **plan);
+int plo_cse_plan_destroy(plo_plan_t *plan);
+
+/* Replaces the body of `#pragma omp parallel for` in CSEOptimiser,
+ * include/plinopt_optimize.inl:1204-1238 (and the same pattern at :1056-1100,
+ * :1137-1177): evaluates candidates seed0 .. seed0+nseeds-1 with the
+ * per-candidate kernel Optimizer() (:616-631: OneSub :209-314, RemOneCSE
+ * :60-194, ProgramGen :513-611, counts only) and returns the minimum under the
+ * total order (cmpOpCount key, seed). Text of the winner is produced by the
+ * host replaying `seed` (plo_cse_replay). */
+int plo_cse_search_plan(plo_plan_t *plan, uint64_t seed0, uint64_t nseeds,
+                        int cost_mode, plo_best_t *out, plo_stats_t *stats);
+int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds,
+                   int cost_mode, plo_best_t *out, plo_stats_t *stats);
+
+/* Same candidates, every (adds, muls) written back: the parity-test entry.
+ * seeds == NULL means seed0, seed0+1, ... */
+int plo_cse_cost_many_plan(plo_plan_t *plan, const uint64_t *seeds, uint64_t seed0,
+                           uint64_t n, uint32_t *adds, uint32_t *muls, plo_stats_t *stats);
+int plo_cse_cost_many(const plo_csr_t *A, uint32_t p, const uint64_t *seeds, uint64_t seed0,
+                      uint64_t n, uint32_t *adds, uint32_t *muls);
+
+/* Pack / unpack the (cost, seed) word used by the grid reduction and by the
+ * single 8-byte MIN all-reduce across ranks (the `#pragma omp critical`
+ * best-so-far of include/plinopt_optimize.inl:1214-1237).  seed_off is the
+ * candidate's offset from seed0 (< 2^32). */
+uint64_t plo_pack_cost(uint32_t adds, uint32_t muls, int cost_mode, uint32_t seed_off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

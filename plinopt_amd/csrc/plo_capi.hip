@@ -1,0 +1,376 @@
+// ===========================================================================
+// plo_capi.hip -- host side of libplinopt_hip.so: the C-ABI declared in
+// include/plinopt_hip.h.  Prepares a matrix once (row image, modular inverses,
+// initial pair table and column bit-masks: the state OneSub builds at
+// reference include/plinopt_optimize.inl:214-225 is identical for every
+// restart, so it is computed once on the host and kept resident in HBM), then
+// launches the per-candidate wave kernel over a seed range.
+// There is NO CPU fallback in this file: without a HIP device every compute
+// entry point fails with PLO_E_HIP.
+// ===========================================================================
+#include "plo_cse_wave.hip"
+#include "../../include/plinopt_hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+int g_cus = 0;
+size_t g_lds_max = 0;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(PLO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+uint32_t inv_mod(uint32_t a, uint32_t p) {
+    int64_t t = 0, nt = 1, r = p, nr = a % p;
+    while (nr) { int64_t q = r / nr, x = t - q * nt; t = nt; nt = x; x = r - q * nr; r = nr; nr = x; }
+    if (t < 0) t += p;
+    return (uint32_t)t;
+}
+uint32_t ceil_log2(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) ++l; return l; }
+uint32_t round_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+} // namespace
+
+struct plo_plan {
+    plo::WavePlan P{};
+    void *d_tmpl = nullptr;
+    uint32_t *d_err = nullptr;
+    unsigned long long *d_best = nullptr;
+    uint32_t waves_per_wg = 0, lds_bytes = 0, blocks_per_cu = 0;
+    uint64_t algo_bytes = 0, pairs0 = 0, distinct0 = 0;
+    uint32_t p = 0;
+    // host copy of the CSR for re-planning with a larger table
+    std::vector<uint32_t> rowptr, col, val;
+    uint32_t m = 0, n = 0;
+    uint32_t cap_scale = 2;
+};
+
+namespace {
+
+int build_plan(plo_plan *pl)
+{
+    const uint32_t m = pl->m, n = pl->n, p = pl->p;
+    const auto &rowptr = pl->rowptr; const auto &col = pl->col; const auto &val = pl->val;
+    const uint32_t nnz = rowptr[m];
+    plo::WavePlan &P = pl->P;
+    P = plo::WavePlan{};
+    uint32_t maxlen = 0; bool unit = true;
+    for (uint32_t i = 0; i < m; ++i) maxlen = std::max(maxlen, rowptr[i + 1] - rowptr[i]);
+    for (uint32_t k = 0; k < nnz; ++k) unit = unit && (val[k] == 1u % p || val[k] == p - 1);
+    if (maxlen > 64) return fail(PLO_E_CAPACITY, "row longer than 64 entries: not handled by the LDS-resident wave kernel");
+    if (m == 0 || m > 31 * 64) return fail(PLO_E_CAPACITY, "row count outside [1,1984] for the wave kernel");
+    const uint32_t mw = (m + 63) / 64;
+    const uint64_t NC = (uint64_t)n + nnz / 2 + 2;
+    if (NC >= 0xFFFFull || NC * NC * (uint64_t)p >= 0xFFFFFFFFull)
+        return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) does not fit 32 bits for this matrix/modulus");
+    if (2ull * nnz >= 65535ull) return fail(PLO_E_CAPACITY, "op-count may exceed 16 bits");
+
+    std::vector<uint32_t> inv(nnz);
+    for (uint32_t k = 0; k < nnz; ++k) inv[k] = inv_mod(val[k], p);
+    // initial pair table (listpairs, plinopt_optimize.inl:30-41; PairMap :220-225)
+    std::map<uint32_t, uint32_t> pm; uint64_t pairs0 = 0;
+    for (uint32_t i = 0; i < m; ++i)
+        for (uint32_t x = rowptr[i]; x < rowptr[i + 1]; ++x)
+            for (uint32_t y = x + 1; y < rowptr[i + 1]; ++y) {
+                uint32_t r = (uint32_t)((uint64_t)val[y] * inv[x] % p);
+                uint32_t key = (uint32_t)(((uint64_t)col[x] * NC + col[y]) * p + r);
+                pm[key]++; ++pairs0;
+            }
+    pl->pairs0 = pairs0; pl->distinct0 = pm.size();
+    pl->algo_bytes = 8ull * nnz + 12ull * pairs0 + 8ull;   // B_cand, SURVEY.md 8(d)
+    uint32_t cap = 64;
+    while (cap < pl->cap_scale * (uint32_t)pm.size() + 16u) cap <<= 1;
+    const uint32_t hbits = ceil_log2(cap);
+
+    P.m = m; P.n = n; P.nnz = nnz; P.p = p; P.NC = (uint32_t)NC; P.cap = cap; P.hbits = hbits;
+    P.lpr_log2 = std::max(2u, ceil_log2(std::max(maxlen, 1u))); P.mw = mw; P.unit = unit ? 1u : 0u;
+    P.multcap = unit ? 0u : (uint32_t)(nnz / 2 + 8); P.maxlen = maxlen;
+    P.mu = p ? (~0ull) / p : 0;
+    uint32_t off = 0;
+    P.off_tab = off;   off += cap * 8u;
+    P.off_val = off;   off += nnz * 4u;
+    P.off_inv = off;   off += unit ? 0u : nnz * 4u;
+    P.off_col = off;   off += nnz * 2u;
+    P.off_len = off;   off += m * 2u;
+    off = round_up(off, 8);
+    P.off_cmask = off;                      // interleaved {cmask[mw], umask[mw]} per column
+    P.off_umask = off + mw * 8u;
+    const uint32_t tmpl_bytes = off + n * 2u * mw * 8u;
+    off += (uint32_t)NC * 2u * mw * 8u;
+    P.tmpl_bytes = tmpl_bytes;
+    P.off_aff = off;   off += (2u * mw + 1u) * 8u;
+    P.off_ties = off;  off += cap * 4u;
+    P.off_mult = off;  off += P.multcap * 8u;
+    P.region_bytes = round_up(off, 16);
+    P.rs_bytes = round_up((m + 1) * 2u, 16);
+
+    // template image
+    std::vector<uint8_t> img(tmpl_bytes + P.rs_bytes, 0);
+    uint64_t *tab = (uint64_t *)(img.data() + P.off_tab);
+    for (uint32_t s = 0; s < cap; ++s) tab[s] = 0xFFFFFFFF00000000ull;   // empty: key all ones, count 0
+    for (const auto &kv : pm) {
+        uint32_t s = (kv.first * 0x9E3779B1u) >> (32u - hbits);
+        while ((uint32_t)(tab[s] >> 32) != 0xFFFFFFFFu) s = (s + 1) & (cap - 1);
+        tab[s] = ((uint64_t)kv.first << 32) | kv.second;
+    }
+    uint32_t *tv = (uint32_t *)(img.data() + P.off_val), *ti = (uint32_t *)(img.data() + P.off_inv);
+    uint16_t *tc = (uint16_t *)(img.data() + P.off_col), *tl = (uint16_t *)(img.data() + P.off_len);
+    uint64_t *tm = (uint64_t *)(img.data() + P.off_cmask);
+    uint16_t *rs = (uint16_t *)(img.data() + tmpl_bytes);
+    for (uint32_t k = 0; k < nnz; ++k) { tv[k] = val[k]; if (!unit) ti[k] = inv[k]; tc[k] = (uint16_t)col[k]; }
+    for (uint32_t i = 0; i < m; ++i) {
+        tl[i] = (uint16_t)(rowptr[i + 1] - rowptr[i]); rs[i] = (uint16_t)rowptr[i];
+        for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            tm[(col[k] * 2u) * mw + (i >> 6)] |= 1ull << (i & 63);
+            if (val[k] == 1u % p || val[k] == p - 1) tm[(col[k] * 2u + 1u) * mw + (i >> 6)] |= 1ull << (i & 63);
+        }
+    }
+    rs[m] = (uint16_t)nnz;
+
+    // waves per workgroup / LDS
+    uint32_t W = 4;
+    while (W > 1 && P.rs_bytes + W * P.region_bytes > g_lds_max) W >>= 1;
+    if (P.rs_bytes + W * P.region_bytes > g_lds_max)
+        return fail(PLO_E_CAPACITY, "candidate state does not fit the 160 KiB LDS of one CU");
+    pl->waves_per_wg = W; pl->lds_bytes = P.rs_bytes + W * P.region_bytes;
+
+    if (pl->d_tmpl) { (void)hipFree(pl->d_tmpl); pl->d_tmpl = nullptr; }
+    HIPCHK(hipMalloc(&pl->d_tmpl, img.size()));
+    HIPCHK(hipMemcpy(pl->d_tmpl, img.data(), img.size(), hipMemcpyHostToDevice));
+    P.tmpl = (const uint64_t *)pl->d_tmpl;
+    if (!pl->d_err) HIPCHK(hipMalloc((void **)&pl->d_err, sizeof(uint32_t)));
+    if (!pl->d_best) HIPCHK(hipMalloc((void **)&pl->d_best, sizeof(unsigned long long)));
+
+    const void *fn = unit ? (const void *)plo::cse_wave_kernel<true> : (const void *)plo::cse_wave_kernel<false>;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    int nb = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)(W * 64), pl->lds_bytes));
+    pl->blocks_per_cu = (uint32_t)std::max(nb, 1);
+    return PLO_OK;
+}
+
+// one launch over [first, first+count) candidates of a job
+int launch(plo_plan *pl, plo::WaveJob J, plo_stats_t *st, float *ms_out)
+{
+    const uint32_t W = pl->waves_per_wg;
+    uint64_t need = (J.ncand + W - 1) / W;
+    uint64_t grid = std::min<uint64_t>((uint64_t)g_cus * pl->blocks_per_cu, need);
+    if (grid == 0) grid = 1;
+    HIPCHK(hipMemsetAsync(pl->d_err, 0, sizeof(uint32_t), g_stream));
+    J.err = pl->d_err;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g_stream));
+    if (pl->P.unit) hipLaunchKernelGGL(plo::cse_wave_kernel<true>, dim3((uint32_t)grid), dim3(W * 64), pl->lds_bytes, g_stream, pl->P, J);
+    else hipLaunchKernelGGL(plo::cse_wave_kernel<false>, dim3((uint32_t)grid), dim3(W * 64), pl->lds_bytes, g_stream, pl->P, J);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, g_stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (ms_out) *ms_out = ms;
+    if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = W; st->algo_bytes = pl->algo_bytes; }
+    return (int)err;   // >0: device error word
+}
+
+int device_error(int err) {
+    switch (err) {
+    case plo::ERR_MULT:  return fail(PLO_E_INTERNAL, "device: multiplier list overflow");
+    case plo::ERR_STEPS: return fail(PLO_E_INTERNAL, "device: more CSE steps than the column bound");
+    case plo::ERR_PGEN:  return fail(PLO_E_UNSUPPORTED, "device: ProgramGen for non +-1 coefficients not available in this build");
+    default:             return fail(PLO_E_INTERNAL, "device: pair table inconsistency");
+    }
+}
+
+// run a job, growing the pair table when the device reports it full
+int run_job(plo_plan *pl, plo::WaveJob J, plo_stats_t *st)
+{
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        int err = launch(pl, J, st, nullptr);
+        if (err < 0) return err;
+        if (err == 0) return PLO_OK;
+        if (err != plo::ERR_TABLE) return device_error(err);
+        pl->cap_scale *= 2;                       // table full: re-plan with twice the slots and retry
+        int rc = build_plan(pl);
+        if (rc != PLO_OK) return rc;
+        if (J.best) HIPCHK(hipMemset(pl->d_best, 0xFF, sizeof(unsigned long long)));
+    }
+    return device_error(plo::ERR_TABLE);
+}
+
+} // namespace
+
+extern "C" {
+
+const char *plo_last_error(void) { return g_err.c_str(); }
+
+int plo_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int plo_init(int device)
+{
+    int n = 0;
+    hipError_t ce = hipGetDeviceCount(&n);
+    if (ce != hipSuccess || n <= 0)
+        return fail(PLO_E_HIP, std::string("no HIP device visible (") + hipGetErrorString(ce) + "): libplinopt_hip has no CPU fallback");
+    if (device < 0 || device >= n) return fail(PLO_E_ARG, "device ordinal out of range");
+    if (g_device == device && g_stream) return PLO_OK;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    g_cus = prop.multiProcessorCount;
+    g_lds_max = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
+    if (g_lds_max > 160u * 1024u) g_lds_max = 160u * 1024u;
+    if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    return PLO_OK;
+}
+
+int plo_shutdown(void)
+{
+    if (g_stream) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    g_device = -1;
+    return PLO_OK;
+}
+
+int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **out)
+{
+    if (!A || !out || !A->rowptr || (A->rowptr[A->m] && (!A->col || !A->val))) return fail(PLO_E_ARG, "null argument");
+    if (p < 3 || p >= 0x80000000u) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
+    if (g_device < 0) { int rc = plo_init(0); if (rc != PLO_OK) return rc; }
+    for (uint32_t i = 0; i < A->m; ++i) {
+        if (A->rowptr[i + 1] < A->rowptr[i]) return fail(PLO_E_ARG, "rowptr not monotone");
+        for (uint32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) {
+            if (A->col[k] >= A->n) return fail(PLO_E_ARG, "column index out of range");
+            if (k > A->rowptr[i] && A->col[k] <= A->col[k - 1]) return fail(PLO_E_ARG, "columns must be strictly increasing inside a row");
+            if (A->val[k] == 0 || A->val[k] >= p) return fail(PLO_E_ARG, "values must be canonical non-zero residues");
+        }
+    }
+    plo_plan *pl = new plo_plan();
+    pl->m = A->m; pl->n = A->n; pl->p = p;
+    pl->rowptr.assign(A->rowptr, A->rowptr + A->m + 1);
+    pl->col.assign(A->col, A->col + A->rowptr[A->m]);
+    pl->val.assign(A->val, A->val + A->rowptr[A->m]);
+    int rc = build_plan(pl);
+    if (rc != PLO_OK) { plo_cse_plan_destroy(pl); return rc; }
+    *out = pl;
+    return PLO_OK;
+}
+
+int plo_cse_plan_destroy(plo_plan_t *pl)
+{
+    if (!pl) return PLO_OK;
+    if (pl->d_tmpl) (void)hipFree(pl->d_tmpl);
+    if (pl->d_err) (void)hipFree(pl->d_err);
+    if (pl->d_best) (void)hipFree(pl->d_best);
+    delete pl;
+    return PLO_OK;
+}
+
+uint64_t plo_pack_cost(uint32_t adds, uint32_t muls, int cost_mode, uint32_t seed_off)
+{
+    uint32_t key;
+    switch (cost_mode) {
+    case PLO_COST_ADD_THEN_MUL: key = (adds << 16) | muls; break;
+    case PLO_COST_SUM:          key = (adds + muls) << 16; break;
+    default:                    key = ((adds + muls) << 16) | adds; break;
+    }
+    return ((uint64_t)key << 32) | seed_off;
+}
+
+int plo_cse_cost_many_plan(plo_plan_t *pl, const uint64_t *seeds, uint64_t seed0, uint64_t n,
+                           uint32_t *adds, uint32_t *muls, plo_stats_t *st)
+{
+    if (!pl || !adds || !muls) return fail(PLO_E_ARG, "null argument");
+    if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    auto t0 = std::chrono::steady_clock::now();
+    if (n == 0) return PLO_OK;
+    uint32_t *d_adds = nullptr, *d_muls = nullptr; uint64_t *d_seeds = nullptr;
+    HIPCHK(hipMalloc((void **)&d_adds, n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&d_muls, n * sizeof(uint32_t)));
+    if (seeds) { HIPCHK(hipMalloc((void **)&d_seeds, n * sizeof(uint64_t))); HIPCHK(hipMemcpy(d_seeds, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice)); }
+    plo::WaveJob J{}; J.seed0 = seed0; J.seeds = d_seeds; J.ncand = n; J.adds = d_adds; J.muls = d_muls; J.best = nullptr; J.cost_mode = 0;
+    int rc = run_job(pl, J, st);
+    if (rc == PLO_OK) {
+        hipError_t e1 = hipMemcpy(adds, d_adds, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipError_t e2 = hipMemcpy(muls, d_muls, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(PLO_E_HIP, "copy back failed");
+    }
+    (void)hipFree(d_adds); (void)hipFree(d_muls); if (d_seeds) (void)hipFree(d_seeds);
+    st->candidates = n;
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int plo_cse_cost_many(const plo_csr_t *A, uint32_t p, const uint64_t *seeds, uint64_t seed0, uint64_t n,
+                      uint32_t *adds, uint32_t *muls)
+{
+    plo_plan_t *pl = nullptr;
+    int rc = plo_cse_plan_create(A, p, &pl);
+    if (rc != PLO_OK) return rc;
+    rc = plo_cse_cost_many_plan(pl, seeds, seed0, n, adds, muls, nullptr);
+    plo_cse_plan_destroy(pl);
+    return rc;
+}
+
+int plo_cse_search_plan(plo_plan_t *pl, uint64_t seed0, uint64_t nseeds, int cost_mode,
+                        plo_best_t *out, plo_stats_t *st)
+{
+    if (!pl || !out) return fail(PLO_E_ARG, "null argument");
+    if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
+    if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    auto t0 = std::chrono::steady_clock::now();
+    out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull;
+    uint64_t bkey = ~0ull, bseed = ~0ull;
+    const uint64_t CH = 0xFFFFFFFFull;                        // seed offsets inside a launch are 32-bit
+    for (uint64_t done = 0; done < nseeds;) {
+        const uint64_t cnt = std::min<uint64_t>(CH, nseeds - done);
+        HIPCHK(hipMemsetAsync(pl->d_best, 0xFF, sizeof(unsigned long long), g_stream));
+        plo::WaveJob J{}; J.seed0 = seed0 + done; J.seeds = nullptr; J.ncand = cnt; J.best = pl->d_best; J.cost_mode = (uint32_t)cost_mode;
+        int rc = run_job(pl, J, st);
+        if (rc != PLO_OK) return rc;
+        unsigned long long w = 0;
+        HIPCHK(hipMemcpy(&w, pl->d_best, sizeof w, hipMemcpyDeviceToHost));
+        const uint64_t key = w >> 32, sd = seed0 + done + (w & 0xFFFFFFFFull);
+        if (key < bkey || (key == bkey && sd < bseed)) { bkey = key; bseed = sd; }
+        done += cnt;
+    }
+    if (nseeds) {
+        uint32_t a = 0, mu = 0;
+        plo_stats_t s2{};
+        int rc = plo_cse_cost_many_plan(pl, &bseed, 0, 1, &a, &mu, &s2);     // (adds, muls) of the winner
+        if (rc != PLO_OK) return rc;
+        out->adds = a; out->muls = mu; out->seed = bseed;
+        if ((plo_pack_cost(a, mu, cost_mode, 0) >> 32) != bkey) return fail(PLO_E_INTERNAL, "winner cost does not match the reduced key");
+    }
+    st->candidates = nseeds;
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PLO_OK;
+}
+
+int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode,
+                   plo_best_t *out, plo_stats_t *stats)
+{
+    plo_plan_t *pl = nullptr;
+    int rc = plo_cse_plan_create(A, p, &pl);
+    if (rc != PLO_OK) return rc;
+    rc = plo_cse_search_plan(pl, seed0, nseeds, cost_mode, out, stats);
+    plo_cse_plan_destroy(pl);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,369 @@
+// ===========================================================================
+// plo_cse_wave.hip -- gfx950 kernel: one wavefront (64 lanes) evaluates one
+// candidate of PLinOpt's randomized greedy pairwise-CSE search, counts only.
+//
+// Restates, per candidate, Optimizer() = { while(OneSub) ; ProgramGen }
+// (reference include/plinopt_optimize.inl:616-631) over Z_p, p < 2^31:
+//   OneSub      :209-314  pair table, max-frequency scan, random tie pick
+//   RemOneCSE   :60-194   orientation by +-1 counts, row rewrite, table patch,
+//                         multiplier reuse (`multiples`)
+//   ProgramGen  :513-611  FactorOutColumns :318-371, FactorOutRows :375-420,
+//                         Triangle :427-507, output rows :547-604
+// The restart loop CSEOptimiser :1204-1238 is the grid: every wave walks its
+// share of the seed range and keeps a packed (cost,seed) minimum; one 64-bit
+// atomicMin per workgroup replaces the `#pragma omp critical` block :1214-1237.
+//
+// Data layout (per wave, all in LDS; the matrix image is fetched from an
+// L2-resident template at the start of every candidate):
+//   tab[cap]      u64  open-addressing pair table: key<<32 | count, key =
+//                      (col_a*NC + col_b)*p + ratio, so integer order of keys ==
+//                      std::map order of the reference's (size_t,size_t,Element)
+//   masks[NC*2mw] u64  per column c: cmask (bit i: row i holds column c) then umask
+//                      (bit i: that entry is +-1); mw = ceil(m/64) words each
+//   val/inv[nnz]  u32  row entries (value, its modular inverse), rows packed at
+//   col[nnz]      u16  fixed offsets rs[i]; rows only shrink (2 entries -> 1)
+//   len[m]        u16
+//   ties[cap]     u32  keys of maximal frequency (scratch), mult[] multiplier list
+// No MFMA: there is no dense contraction here; the work is LDS integer traffic.
+// ===========================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plo {
+
+struct WavePlan {
+    uint32_t m, n, nnz, p, NC, cap, hbits, lpr_log2, mw, unit, multcap, maxlen;
+    uint32_t off_tab, off_cmask, off_umask, off_val, off_inv, off_col, off_len;   // template part
+    uint32_t tmpl_bytes;                                                          // multiple of 8
+    uint32_t off_aff, off_ties, off_mult, region_bytes;                           // scratch part
+    uint32_t rs_bytes;                                                            // shared rs[] image, multiple of 8
+    uint64_t mu;                                                                  // floor(2^64/p)
+    const uint64_t *tmpl;   // tmpl_bytes of template followed by rs_bytes of rs[m+1] (u16)
+};
+
+struct WaveJob {
+    uint64_t seed0;            // candidate c has seed seed0 + c (seeds==nullptr) or seeds[c]
+    const uint64_t *seeds;
+    uint64_t ncand;
+    uint32_t *adds, *muls;     // per-candidate outputs (may be null)
+    unsigned long long *best;  // packed (cost,seed offset) minimum (may be null)
+    uint32_t cost_mode;
+    uint32_t *err;             // device error word
+};
+
+enum { ERR_TABLE = 1, ERR_MULT = 2, ERR_STEPS = 3, ERR_PGEN = 4 };
+
+#define PLO_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t w = (uint32_t)__shfl_xor((int)v, o); v = v > w ? v : w; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+        uint64_t w = ((uint64_t)hi << 32) | lo; v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t srclane) { return (uint32_t)__shfl((int)v, (int)srclane); }
+
+template <bool UNIT>
+__device__ __forceinline__ uint32_t fmul(uint32_t a, uint32_t b, uint32_t p, uint64_t mu) {
+    if (UNIT) return a == b ? 1u : p - 1u;   // operands are +-1 only
+    uint64_t x = (uint64_t)a * b;
+    uint64_t q = __umul64hi(x, mu);
+    uint64_t r = x - q * p;
+    while (r >= p) r -= p;
+    return (uint32_t)r;
+}
+__device__ __forceinline__ uint32_t fabsp(uint32_t e, uint32_t p) { uint32_t a = e ? p - e : 0u; return a < e ? a : e; }
+__device__ __forceinline__ bool absone(uint32_t e, uint32_t p) { return e == 1u || e == p - 1u; }
+
+// GivRandom LCG on the Mersenne prime 2^31-1
+__device__ __forceinline__ uint32_t rng_next(uint32_t &s) {
+    uint64_t x = 950706376ull * (uint64_t)s;
+    x = (x & 0x7FFFFFFFull) + (x >> 31);
+    x = (x & 0x7FFFFFFFull) + (x >> 31);
+    if (x >= 0x7FFFFFFFull) x -= 0x7FFFFFFFull;
+    s = (uint32_t)x; return s;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint32_t tab_hash(uint32_t key, uint32_t hbits) { return (key * 0x9E3779B1u) >> (32u - hbits); }
+
+// count[key] -= 1 ; the key must be live
+__device__ __forceinline__ bool tab_dec(uint64_t *tab, uint32_t key, uint32_t cap, uint32_t hbits) {
+    volatile uint64_t *vt = tab;
+    uint32_t s = tab_hash(key, hbits);
+    for (uint32_t pr = 0; pr < cap; ++pr) {
+        uint64_t v = vt[s];
+        if ((uint32_t)(v >> 32) == key) { atomicAdd((unsigned long long *)&tab[s], ~0ull); return true; }
+        s = (s + 1u) & (cap - 1u);
+    }
+    return false;
+}
+// count[key] += 1 ; claims an empty or dead (count 0) slot for a new key.
+// Only called when no decrement is in flight (see the two sweeps below), so a
+// key can never end up in two slots.
+__device__ __forceinline__ bool tab_inc(uint64_t *tab, uint32_t key, uint32_t cap, uint32_t hbits) {
+    volatile uint64_t *vt = tab;
+    uint32_t s = tab_hash(key, hbits);
+    for (uint32_t pr = 0; pr < 2u * cap + 64u; ++pr) {
+        uint64_t v = vt[s];
+        if ((uint32_t)(v >> 32) == key) { atomicAdd((unsigned long long *)&tab[s], 1ull); return true; }
+        if ((uint32_t)v == 0u) {
+            uint64_t nv = ((uint64_t)key << 32) | 1ull;
+            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)nv);
+            if (old == v) return true;
+            continue;                      // slot changed under us: look at it again
+        }
+        s = (s + 1u) & (cap - 1u);
+    }
+    return false;
+}
+
+// One candidate.  Returns packed (adds<<32 | muls); sets *errw on failure.
+template <bool UNIT>
+__device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_t *rs, uint64_t seed,
+                                  uint32_t lane, uint32_t *errw)
+{
+    uint64_t *tab   = (uint64_t *)(reg + P.off_tab);
+    uint64_t *cmask = (uint64_t *)(reg + P.off_cmask);
+    uint64_t *umask = (uint64_t *)(reg + P.off_umask);
+    uint32_t *val   = (uint32_t *)(reg + P.off_val);
+    uint32_t *inv   = (uint32_t *)(reg + P.off_inv);
+    uint16_t *col   = (uint16_t *)(reg + P.off_col);
+    uint16_t *len   = (uint16_t *)(reg + P.off_len);
+    uint64_t *affw  = (uint64_t *)(reg + P.off_aff);      // [mw] affected rows, [mw] affected & coeff +-1, [1] scratch
+    uint32_t *ties  = (uint32_t *)(reg + P.off_ties);
+    uint32_t *multv = (uint32_t *)(reg + P.off_mult);     // multcap values, then multcap u32 columns
+    uint32_t *multc = multv + P.multcap;
+
+    const uint32_t p = P.p, NC = P.NC, cap = P.cap, hbits = P.hbits, mw = P.mw, ms = 2u * P.mw;   // masks interleaved: {cmask[mw],umask[mw]} per column
+    const uint64_t mu = P.mu;
+    const uint32_t LPR = 1u << P.lpr_log2, G = 64u >> P.lpr_log2;
+    const uint32_t g = lane >> P.lpr_log2, t = lane & (LPR - 1u), gbase = g << P.lpr_log2;
+    const uint64_t gmask = (LPR == 64u) ? ~0ull : (((1ull << LPR) - 1ull) << gbase);
+
+    uint32_t rng = 1u + (uint32_t)(splitmix64(seed) % 2147483646ull);
+    uint32_t ncols = P.n, nbadd = 0, nbmul = 0, nmult = 0;
+
+    for (;;) {
+        if (ncols >= NC) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_STEPS); break; }
+        // ---- OneSub :244-253  maximal frequency over the pair table
+        uint32_t lmax = 0;
+        for (uint32_t s = lane; s < cap; s += 64u) { uint32_t c = (uint32_t)tab[s]; lmax = c > lmax ? c : lmax; }
+        const uint32_t maxfrq = uni32(wave_max(lmax));
+        if (maxfrq <= 1u) break;                                            // :255
+        // ---- ties in map order; random pick :260-265
+        uint32_t T = 0;
+        for (uint32_t s0 = 0; s0 < cap; s0 += 64u) {
+            uint64_t v = tab[s0 + lane];
+            bool is = (uint32_t)v == maxfrq;
+            uint64_t bm = __ballot(is);
+            if (is) ties[T + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)(v >> 32);
+            T += (uint32_t)__popcll(bm);
+        }
+        T = uni32(T);
+        PLO_WAVE_SYNC();
+        uint32_t key;
+        if (T == 1u) {
+            key = ties[0];
+        } else {
+            const uint32_t k = uni32(rng_next(rng) % T);
+            if (T <= 64u) {
+                uint32_t mine = lane < T ? ties[lane] : 0xFFFFFFFFu, rank = 0;
+                for (uint32_t j = 0; j < T; ++j) rank += (bcast(mine, j) < mine) ? 1u : 0u;
+                uint64_t w = __ballot(lane < T && rank == k);
+                key = bcast(mine, (uint32_t)__builtin_ctzll(w));
+            } else {
+                uint32_t lo = 0u, hi = 0xFFFFFFFEu;                       // k-th smallest by bisection on the key value
+                while (lo < hi) {
+                    uint32_t mid = lo + ((hi - lo) >> 1), c = 0;
+                    for (uint32_t s0 = 0; s0 < T; s0 += 64u) {
+                        bool le = (s0 + lane < T) && ties[s0 + lane] <= mid;
+                        c += (uint32_t)__popcll(__ballot(le));
+                    }
+                    if (c >= k + 1u) hi = mid; else lo = mid + 1u;
+                }
+                key = lo;
+            }
+        }
+        key = uni32(key);
+        ++nbadd;                                                            // :292
+        // ---- RemOneCSE :60-194
+        const uint32_t r = key % p, ab = key / p, a = ab / NC, b = ab % NC;
+        uint32_t c0 = 0, c1 = 0;
+        for (uint32_t w = 0; w < mw; ++w) { c0 += (uint32_t)__popcll(umask[a * ms + w]); c1 += (uint32_t)__popcll(umask[b * ms + w]); }
+        const bool swap = uni32(c0) < uni32(c1);                                          // :79-88
+        const uint32_t l0 = swap ? b : a, l1 = swap ? a : b, lm = ncols;
+        if (lane < 2u * mw + 1u) affw[lane] = 0ull;
+        PLO_WAVE_SYNC();
+        bool bad = false;
+        // sweep 1: rows holding the triple (a,b,r); retire their old pairs (:115-118)
+        for (uint32_t w = 0; w < mw; ++w) {
+            uint64_t msk = uni64(cmask[a * ms + w] & cmask[b * ms + w]);
+            while (msk) {
+                int myrow = -1;
+                for (uint32_t gg = 0; gg < G && msk; ++gg) { int i = __builtin_ctzll(msk); msk &= msk - 1ull; if (g == gg) myrow = (int)(w * 64u) + i; }
+                const bool act = myrow >= 0;
+                const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
+                const bool have = t < ln;
+                const uint32_t c = have ? col[base + t] : 0xFFFFu, v = have ? val[base + t] : 0u;
+                const uint32_t iv = UNIT ? v : (have ? inv[base + t] : 0u);
+                const uint64_t ma = __ballot(have && c == a) & gmask, mb = __ballot(have && c == b) & gmask;
+                const uint32_t la = ma ? (uint32_t)__builtin_ctzll(ma) : lane, lb = mb ? (uint32_t)__builtin_ctzll(mb) : lane;
+                const uint32_t va = bcast(v, la), ia = bcast(iv, la), vb = bcast(v, lb), ib = bcast(iv, lb);
+                const bool aff = act && ma && mb && vb == fmul<UNIT>(r, va, p, mu);
+                if (aff && have) {
+                    if (lane != la && lane != lb) {
+                        uint32_t k1 = c < a ? (c * NC + a) * p + fmul<UNIT>(va, iv, p, mu) : (a * NC + c) * p + fmul<UNIT>(v, ia, p, mu);
+                        uint32_t k2 = c < b ? (c * NC + b) * p + fmul<UNIT>(vb, iv, p, mu) : (b * NC + c) * p + fmul<UNIT>(v, ib, p, mu);
+                        bad |= !tab_dec(tab, k1, cap, hbits);
+                        bad |= !tab_dec(tab, k2, cap, hbits);
+                    } else if (lane == la) {
+                        bad |= !tab_dec(tab, key, cap, hbits);
+                        atomicOr((unsigned long long *)&affw[(uint32_t)myrow >> 6], 1ull << ((uint32_t)myrow & 63u));
+                        if (!UNIT) affw[2u * mw] = fmul<UNIT>(va, ib, p, mu);   // 1/r, same in every affected row
+                    }
+                }
+            }
+        }
+        PLO_WAVE_SYNC();
+        // sweep 2: rewrite the rows, add the pairs with the new column (:96-110, :132-142)
+        for (uint32_t w = 0; w < mw; ++w) {
+            uint64_t msk = uni64(affw[w]);
+            while (msk) {
+                int myrow = -1;
+                for (uint32_t gg = 0; gg < G && msk; ++gg) { int i = __builtin_ctzll(msk); msk &= msk - 1ull; if (g == gg) myrow = (int)(w * 64u) + i; }
+                const bool act = myrow >= 0;
+                const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
+                const bool have = t < ln;
+                const uint32_t c = have ? col[base + t] : 0xFFFFu, v = have ? val[base + t] : 0u;
+                const uint32_t iv = UNIT ? v : (have ? inv[base + t] : 0u);
+                const uint64_t m0 = __ballot(have && c == l0) & gmask, m1 = __ballot(have && c == l1) & gmask;
+                const uint32_t q0 = m0 ? (uint32_t)__builtin_ctzll(m0) : lane, q1 = m1 ? (uint32_t)__builtin_ctzll(m1) : lane;
+                const uint32_t coeff = bcast(v, q0), icoeff = bcast(iv, q0);
+                if (have) {
+                    if (lane != q0 && lane != q1) {
+                        bad |= !tab_inc(tab, (c * NC + lm) * p + fmul<UNIT>(coeff, iv, p, mu), cap, hbits);
+                        const uint32_t np = base + t - (lane > q0 ? 1u : 0u) - (lane > q1 ? 1u : 0u);
+                        col[np] = (uint16_t)c; val[np] = v; if (!UNIT) inv[np] = iv;
+                    } else if (lane == q0) {
+                        const uint32_t np = base + ln - 2u;
+                        col[np] = (uint16_t)lm; val[np] = coeff; if (!UNIT) inv[np] = icoeff;
+                        len[myrow] = (uint16_t)(ln - 1u);
+                        if (UNIT || absone(coeff, p)) atomicOr((unsigned long long *)&affw[mw + ((uint32_t)myrow >> 6)], 1ull << ((uint32_t)myrow & 63u));
+                    }
+                }
+            }
+        }
+        PLO_WAVE_SYNC();
+        if (lane < mw) {
+            const uint64_t af = affw[lane], uaf = affw[mw + lane];
+            cmask[l0 * ms + lane] &= ~af; cmask[l1 * ms + lane] &= ~af;
+            umask[l0 * ms + lane] &= ~af; umask[l1 * ms + lane] &= ~af;
+            cmask[lm * ms + lane] = af;   umask[lm * ms + lane] = uaf;
+        }
+        if (__ballot(bad)) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_TABLE); break; }
+        // ---- multiplier reuse :153-169 (counts only)
+        if (!UNIT) {
+            const uint32_t rho = swap ? (uint32_t)affw[2u * mw] : r;
+            const uint32_t asgs = fabsp(rho, p);
+            if (!absone(asgs, p)) {
+                bool hit = false;
+                for (uint32_t s0 = 0; s0 < nmult; s0 += 64u)
+                    hit |= (s0 + lane < nmult) && multc[s0 + lane] == l1 && multv[s0 + lane] == asgs;
+                if (!__ballot(hit)) {
+                    if (nmult >= P.multcap) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_MULT); break; }
+                    if (lane == 0) { multv[nmult] = asgs; multc[nmult] = l1; }
+                    ++nmult; ++nbmul;
+                }
+            }
+        }
+        ncols = lm + 1u;                                                    // :190-191
+        PLO_WAVE_SYNC();
+    }
+
+    // ---- ProgramGen :513-611
+    if (UNIT) {
+        // all coefficients are +-1: the three factoring passes are no-ops and
+        // every row costs len-1 additions (:576), no multiplication
+        uint32_t acc = 0;
+        for (uint32_t i = lane; i < P.m; i += 64u) { uint32_t ln = len[i]; acc += ln > 1u ? ln - 1u : 0u; }
+        nbadd += wave_sum(acc);
+    } else {
+        if (lane == 0) atomicMax(errw, (uint32_t)ERR_PGEN);   // general ProgramGen lives in plo_cse_pgen (see host dispatch)
+    }
+    return ((uint64_t)nbadd << 32) | nbmul;
+}
+
+__device__ __forceinline__ uint32_t cost_key32(uint32_t a, uint32_t mu_, uint32_t mode) {
+    switch (mode) {
+    case 1: return (a << 16) | mu_;              // adds, then muls
+    case 2: return (a + mu_) << 16;              // sum only
+    default: return ((a + mu_) << 16) | a;       // sum, then adds
+    }
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(256) void cse_wave_kernel(WavePlan P, WaveJob J)
+{
+    extern __shared__ uint64_t lds64[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // shared: rs[m+1] (row offsets never change); per wave: one candidate region
+    const uint32_t rs_words = P.rs_bytes >> 3, tw = P.tmpl_bytes >> 3;
+    for (uint32_t i = threadIdx.x; i < rs_words; i += blockDim.x) lds64[i] = P.tmpl[tw + i];
+    __syncthreads();
+    const uint16_t *rs = (const uint16_t *)lds64;
+    uint8_t *reg = (uint8_t *)lds64 + P.rs_bytes + (size_t)wave * P.region_bytes;
+    uint64_t best = ~0ull;
+    const uint64_t stride = (uint64_t)gridDim.x * nwaves;
+    for (uint64_t c = (uint64_t)blockIdx.x * nwaves + wave; c < J.ncand; c += stride) {
+        for (uint32_t i = lane; i < tw; i += 64u) ((uint64_t *)reg)[i] = P.tmpl[i];     // matrix image -> LDS
+        PLO_WAVE_SYNC();
+        const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
+        const uint64_t res = run_candidate<UNIT>(P, reg, rs, seed, lane, J.err);
+        const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
+        if (lane == 0) {
+            if (J.adds) J.adds[c] = a;
+            if (J.muls) J.muls[c] = mu_;
+        }
+        const uint64_t packed = ((uint64_t)cost_key32(a, mu_, J.cost_mode) << 32) | (uint32_t)c;
+        best = packed < best ? packed : best;
+        PLO_WAVE_SYNC();
+    }
+    if (J.best) {
+        // grid min-reduce: wave value is uniform; waves -> LDS -> one atomicMin per workgroup
+        __syncthreads();
+        if (lane == 0) lds64[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = lds64[0];
+            for (uint32_t w = 1; w < nwaves; ++w) b = lds64[w] < b ? lds64[w] : b;
+            if (b != ~0ull) atomicMin(J.best, (unsigned long long)b);
+        }
+    }
+}
+
+template __global__ void cse_wave_kernel<true>(WavePlan, WaveJob);
+template __global__ void cse_wave_kernel<false>(WavePlan, WaveJob);
+
+} // namespace plo

@@ -1,0 +1,70 @@
+"""Host-side mirror of the reference's restart-loop interface for the CSE path.
+
+`CSEOptimiser(nbops, sout, F, M, T, global, randomloops, verbose)`
+(reference include/plinopt_optimize.inl:1193-1247) runs `randomloops`
+independent candidates and keeps the best (adds, muls) under `cmpOpCount`
+(include/plinopt_optimize.h:53-64).  Here the loop body runs on the GPU through
+libplinopt_hip.so; this module only marshals arguments.
+"""
+import ctypes
+
+from . import capi
+
+
+class CSEPlan:
+    """A matrix over Z_p prepared once and resident in HBM (plo_cse_plan_create)."""
+
+    def __init__(self, m, n, rowptr, col, val, p, device=None):
+        L = capi.lib()
+        if device is not None:
+            capi.check(L.plo_init(int(device)))
+        self.m, self.n, self.p = m, n, p
+        self.nnz = len(col)
+        csr, self._keep = capi.make_csr(m, n, rowptr, col, val)
+        h = ctypes.c_void_p()
+        capi.check(L.plo_cse_plan_create(ctypes.byref(csr), p, ctypes.byref(h)))
+        self._h = h
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().plo_cse_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cost_many(self, seeds=None, seed0=0, n=0):
+        """(adds[], muls[]) of candidates `seeds` (or seed0..seed0+n-1): Optimizer() per seed."""
+        L = capi.lib()
+        if seeds is not None:
+            n = len(seeds)
+            sp = (ctypes.c_uint64 * max(n, 1))(*seeds)
+        else:
+            sp = None
+        adds = (ctypes.c_uint32 * max(n, 1))()
+        muls = (ctypes.c_uint32 * max(n, 1))()
+        st = capi.Stats()
+        capi.check(L.plo_cse_cost_many_plan(self._h, sp, seed0, n, adds, muls, ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return list(adds[:n]), list(muls[:n])
+
+    def search(self, seed0, nseeds, cost_mode=capi.COST_SUM_THEN_ADD):
+        """Best (adds, muls, seed) over seeds seed0..seed0+nseeds-1, ties to the smallest seed."""
+        L = capi.lib()
+        b, st = capi.Best(), capi.Stats()
+        capi.check(L.plo_cse_search_plan(self._h, seed0, nseeds, cost_mode, ctypes.byref(b), ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return b.adds, b.muls, b.seed
+
+
+def cmp_op_count_key(adds, muls, cost_mode=capi.COST_SUM_THEN_ADD):
+    """Sort key equivalent to cmpOpCount (include/plinopt_optimize.h:53-64)."""
+    if cost_mode == capi.COST_ADD_THEN_MUL:
+        return (adds, muls)
+    if cost_mode == capi.COST_SUM:
+        return (adds + muls,)
+    return (adds + muls, adds)

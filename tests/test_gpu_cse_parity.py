@@ -1,0 +1,67 @@
+"""Parity of the HIP wave kernel (through the C-ABI) with the CPU oracle:
+bit-exact (adds, muls) per seed, identical argmin under (cmpOpCount, seed)."""
+import os
+
+import pytest
+
+from plo_testlib import DATA, OracleMatrix
+
+pytestmark = pytest.mark.gpu
+
+P = 131071
+
+UNIT_FILES = [
+    "2x2x2_7_Winograd_L.sms", "2x2x2_7_Winograd_P.sms", "2x2x2_7_Strassen_R.sms", "cyclic.sms",
+    "3x3x3_23_58_L.sms", "3x3x3_23_58_P.sms", "3x3x3_23_Grey-221_P.sms",
+    "4x4x4_49_156_L.sms", "4x4x4_49_156_R.sms", "4x4x4_49_156_P.sms",
+    "3x4x7_63_rational_L.sms", "3x3x6_40_L.sms", "6x3x3_40_DPS-accurate_R.sms", "4x4T_8+26_RXTX_P.sms",
+    "4o4o4_F32_Standard_L.sms", "3x4x7_63_rational-ALT_L.sms",
+]
+
+
+def _plan(M):
+    from plinopt_amd import CSEPlan
+    return CSEPlan(M.m, M.n, M.rowptr, M.col, M.val, M.p)
+
+
+@pytest.mark.parametrize("name", UNIT_FILES)
+def test_cost_many_matches_oracle(hip, name):
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    nseeds = 3000 if len(M.col) < 100 else 1200
+    plan = _plan(M)
+    ga, gm = plan.cost_many(seed0=0, n=nseeds)
+    oa, om = M.cost_many(seed0=0, nseeds=nseeds, nthreads=8)
+    assert ga == oa
+    assert gm == om
+    # explicit, scattered 64-bit seeds
+    seeds = [(1 << 40) + 7919 * k * k for k in range(257)] + [2 ** 64 - 1, 2 ** 63, 0]
+    ga, gm = plan.cost_many(seeds=seeds)
+    oa, om = M.cost_many(seeds=seeds)
+    assert (ga, gm) == (oa, om)
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "4x4x4_49_156_L.sms", "3x3x3_23_58_P.sms"])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_search_argmin_matches_oracle(hip, name, mode):
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    plan = _plan(M)
+    n = 5000
+    got = plan.search(12345, n, cost_mode=mode)
+    exp = M.search(12345, n, cost_mode=mode, nthreads=8)
+    assert got == exp
+
+
+def test_other_modulus(hip):
+    for p in (7, 65537):
+        M = OracleMatrix.from_sms(os.path.join(DATA, "3x3x3_23_58_L.sms"), p)
+        plan = _plan(M)
+        assert plan.cost_many(seed0=5, n=500) == tuple(M.cost_many(seed0=5, nseeds=500, nthreads=8))
+
+
+def test_capacity_error_is_loud(hip):
+    """A modulus whose pair key needs more than 32 bits is refused, never silently rerouted."""
+    from plinopt_amd import capi
+    M = OracleMatrix.from_sms(os.path.join(DATA, "3x3x3_23_58_L.sms"), 2147483629)
+    with pytest.raises(capi.PloError) as e:
+        _plan(M)
+    assert e.value.code == capi.PLO_E_CAPACITY
