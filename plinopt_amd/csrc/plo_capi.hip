@@ -70,20 +70,24 @@ int build_plan(plo_plan *pl)
     if (maxlen > 64) return fail(PLO_E_CAPACITY, "row longer than 64 entries: not handled by the LDS-resident wave kernel");
     if (m == 0 || m > 31 * 64) return fail(PLO_E_CAPACITY, "row count outside [1,1984] for the wave kernel");
     const uint32_t mw = (m + 63) / 64;
-    const uint64_t NC = (uint64_t)n + nnz / 2 + 2;
-    if (NC >= 0xFFFFull || NC * NC * (uint64_t)p >= 0xFFFFFFFFull)
-        return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) does not fit 32 bits for this matrix/modulus");
+    // every CSE step lowers sum(len-1) by its frequency >= 2, so there are at most naive_adds/2 steps
+    uint32_t naive = 0;
+    for (uint32_t i = 0; i < m; ++i) { uint32_t l = rowptr[i + 1] - rowptr[i]; if (l > 1) naive += l - 1; }
+    const uint64_t NC = (uint64_t)n + naive / 2 + 2;
+    const uint32_t rb = ceil_log2(p), bb = ceil_log2((uint32_t)NC);     // residues < 2^rb, columns < 2^bb
+    if (NC >= 0xFFFFull || 2u * bb + rb > 44u)
+        return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) does not fit 44 bits for this matrix/modulus");
     if (2ull * nnz >= 65535ull) return fail(PLO_E_CAPACITY, "op-count may exceed 16 bits");
 
     std::vector<uint32_t> inv(nnz);
     for (uint32_t k = 0; k < nnz; ++k) inv[k] = inv_mod(val[k], p);
     // initial pair table (listpairs, plinopt_optimize.inl:30-41; PairMap :220-225)
-    std::map<uint32_t, uint32_t> pm; uint64_t pairs0 = 0;
+    std::map<uint64_t, uint32_t> pm; uint64_t pairs0 = 0;
     for (uint32_t i = 0; i < m; ++i)
         for (uint32_t x = rowptr[i]; x < rowptr[i + 1]; ++x)
             for (uint32_t y = x + 1; y < rowptr[i + 1]; ++y) {
                 uint32_t r = (uint32_t)((uint64_t)val[y] * inv[x] % p);
-                uint32_t key = (uint32_t)(((uint64_t)col[x] * NC + col[y]) * p + r);
+                uint64_t key = ((uint64_t)col[x] << (bb + rb)) | ((uint64_t)col[y] << rb) | r;
                 pm[key]++; ++pairs0;
             }
     pl->pairs0 = pairs0; pl->distinct0 = pm.size();
@@ -94,7 +98,8 @@ int build_plan(plo_plan *pl)
 
     P.m = m; P.n = n; P.nnz = nnz; P.p = p; P.NC = (uint32_t)NC; P.cap = cap; P.hbits = hbits;
     P.lpr_log2 = std::max(2u, ceil_log2(std::max(maxlen, 1u))); P.mw = mw; P.unit = unit ? 1u : 0u;
-    P.multcap = unit ? 0u : (uint32_t)(nnz / 2 + 8); P.maxlen = maxlen;
+    P.multcap = unit ? 0u : (uint32_t)(naive / 2 + 8); P.maxlen = maxlen; P.rb = rb; P.bb = bb;
+    if (cap > 65536u) return fail(PLO_E_CAPACITY, "pair table larger than 65536 slots");
     P.mu = p ? (~0ull) / p : 0;
     uint32_t off = 0;
     P.off_tab = off;   off += cap * 8u;
@@ -109,7 +114,8 @@ int build_plan(plo_plan *pl)
     off += (uint32_t)NC * 2u * mw * 8u;
     P.tmpl_bytes = tmpl_bytes;
     P.off_aff = off;   off += (2u * mw + 1u) * 8u;
-    P.off_ties = off;  off += cap * 4u;
+    P.off_ties = off;  off += cap * 2u;
+    off = round_up(off, 8);
     P.off_mult = off;  off += P.multcap * 8u;
     P.region_bytes = round_up(off, 16);
     P.rs_bytes = round_up((m + 1) * 2u, 16);
@@ -117,11 +123,12 @@ int build_plan(plo_plan *pl)
     // template image
     std::vector<uint8_t> img(tmpl_bytes + P.rs_bytes, 0);
     uint64_t *tab = (uint64_t *)(img.data() + P.off_tab);
-    for (uint32_t s = 0; s < cap; ++s) tab[s] = 0xFFFFFFFF00000000ull;   // empty: key all ones, count 0
+    for (uint32_t s = 0; s < cap; ++s) tab[s] = PLO_EMPTY;               // empty: key all ones, count 0
     for (const auto &kv : pm) {
-        uint32_t s = (kv.first * 0x9E3779B1u) >> (32u - hbits);
-        while ((uint32_t)(tab[s] >> 32) != 0xFFFFFFFFu) s = (s + 1) & (cap - 1);
-        tab[s] = ((uint64_t)kv.first << 32) | kv.second;
+        uint32_t x = (uint32_t)kv.first ^ ((uint32_t)(kv.first >> 32) * 0x85EBCA6Bu);
+        uint32_t s = (x * 0x9E3779B1u) >> (32u - hbits);                   // == plo::tab_hash
+        while (tab[s] != PLO_EMPTY) s = (s + 1) & (cap - 1);
+        tab[s] = (kv.first << PLO_VB) | kv.second;
     }
     uint32_t *tv = (uint32_t *)(img.data() + P.off_val), *ti = (uint32_t *)(img.data() + P.off_inv);
     uint16_t *tc = (uint16_t *)(img.data() + P.off_col), *tl = (uint16_t *)(img.data() + P.off_len);
@@ -248,7 +255,7 @@ int plo_shutdown(void)
 int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **out)
 {
     if (!A || !out || !A->rowptr || (A->rowptr[A->m] && (!A->col || !A->val))) return fail(PLO_E_ARG, "null argument");
-    if (p < 3 || p >= 0x80000000u) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
+    if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
     if (g_device < 0) { int rc = plo_init(0); if (rc != PLO_OK) return rc; }
     for (uint32_t i = 0; i < A->m; ++i) {
         if (A->rowptr[i + 1] < A->rowptr[i]) return fail(PLO_E_ARG, "rowptr not monotone");
@@ -351,11 +358,15 @@ int plo_cse_search_plan(plo_plan_t *pl, uint64_t seed0, uint64_t nseeds, int cos
     }
     if (nseeds) {
         uint32_t a = 0, mu = 0;
-        plo_stats_t s2{};
-        int rc = plo_cse_cost_many_plan(pl, &bseed, 0, 1, &a, &mu, &s2);     // (adds, muls) of the winner
-        if (rc != PLO_OK) return rc;
+        if (cost_mode == PLO_COST_SUM_THEN_ADD) { a = (uint32_t)(bkey & 0xFFFFu); mu = (uint32_t)(bkey >> 16) - a; }
+        else if (cost_mode == PLO_COST_ADD_THEN_MUL) { a = (uint32_t)(bkey >> 16); mu = (uint32_t)(bkey & 0xFFFFu); }
+        else {
+            plo_stats_t s2{};                                                // sum-only key: ask the device for the split
+            int rc = plo_cse_cost_many_plan(pl, &bseed, 0, 1, &a, &mu, &s2);
+            if (rc != PLO_OK) return rc;
+            if ((plo_pack_cost(a, mu, cost_mode, 0) >> 32) != bkey) return fail(PLO_E_INTERNAL, "winner cost does not match the reduced key");
+        }
         out->adds = a; out->muls = mu; out->seed = bseed;
-        if ((plo_pack_cost(a, mu, cost_mode, 0) >> 32) != bkey) return fail(PLO_E_INTERNAL, "winner cost does not match the reduced key");
     }
     st->candidates = nseeds;
     st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -15,15 +15,15 @@
 //
 // Data layout (per wave, all in LDS; the matrix image is fetched from an
 // L2-resident template at the start of every candidate):
-//   tab[cap]      u64  open-addressing pair table: key<<32 | count, key =
-//                      (col_a*NC + col_b)*p + ratio, so integer order of keys ==
-//                      std::map order of the reference's (size_t,size_t,Element)
+//   tab[cap]      u64  open-addressing pair table: key<<20 | count, key =
+//                      col_a<<(bb+rb) | col_b<<rb | ratio (44 bits), so integer order of
+//                      keys == std::map order of the reference's (size_t,size_t,Element)
 //   masks[NC*2mw] u64  per column c: cmask (bit i: row i holds column c) then umask
 //                      (bit i: that entry is +-1); mw = ceil(m/64) words each
 //   val/inv[nnz]  u32  row entries (value, its modular inverse), rows packed at
 //   col[nnz]      u16  fixed offsets rs[i]; rows only shrink (2 entries -> 1)
 //   len[m]        u16
-//   ties[cap]     u32  keys of maximal frequency (scratch), mult[] multiplier list
+//   ties[cap]     u16  slots of maximal frequency (scratch), mult[] multiplier list
 // No MFMA: there is no dense contraction here; the work is LDS integer traffic.
 // ===========================================================================
 #include <hip/hip_runtime.h>
@@ -33,6 +33,7 @@ namespace plo {
 
 struct WavePlan {
     uint32_t m, n, nnz, p, NC, cap, hbits, lpr_log2, mw, unit, multcap, maxlen;
+    uint32_t rb, bb;        // bits of a ratio (p-1) and of a column index (NC-1): 2*bb+rb <= 44
     uint32_t off_tab, off_cmask, off_umask, off_val, off_inv, off_col, off_len;   // template part
     uint32_t tmpl_bytes;                                                          // multiple of 8
     uint32_t off_aff, off_ties, off_mult, region_bytes;                           // scratch part
@@ -78,6 +79,9 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
     return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v);
 }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t srclane) { return (uint32_t)__shfl((int)v, (int)srclane); }
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t srclane) {
+    return ((uint64_t)bcast((uint32_t)(v >> 32), srclane) << 32) | bcast((uint32_t)v, srclane);
+}
 
 template <bool UNIT>
 __device__ __forceinline__ uint32_t fmul(uint32_t a, uint32_t b, uint32_t p, uint64_t mu) {
@@ -106,15 +110,21 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-__device__ __forceinline__ uint32_t tab_hash(uint32_t key, uint32_t hbits) { return (key * 0x9E3779B1u) >> (32u - hbits); }
+#define PLO_VB 20u                                  // value bits of a table slot
+#define PLO_VMASK 0xFFFFFull
+#define PLO_EMPTY 0xFFFFFFFFFFF00000ull             // key all ones, value 0
+__device__ __forceinline__ uint32_t tab_hash(uint64_t key, uint32_t hbits) {
+    uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
+    return (x * 0x9E3779B1u) >> (32u - hbits);
+}
 
 // count[key] -= 1 ; the key must be live
-__device__ __forceinline__ bool tab_dec(uint64_t *tab, uint32_t key, uint32_t cap, uint32_t hbits) {
+__device__ __forceinline__ bool tab_dec(uint64_t *tab, uint64_t key, uint32_t cap, uint32_t hbits) {
     volatile uint64_t *vt = tab;
     uint32_t s = tab_hash(key, hbits);
     for (uint32_t pr = 0; pr < cap; ++pr) {
         uint64_t v = vt[s];
-        if ((uint32_t)(v >> 32) == key) { atomicAdd((unsigned long long *)&tab[s], ~0ull); return true; }
+        if ((v >> PLO_VB) == key) { atomicAdd((unsigned long long *)&tab[s], ~0ull); return true; }
         s = (s + 1u) & (cap - 1u);
     }
     return false;
@@ -122,14 +132,14 @@ __device__ __forceinline__ bool tab_dec(uint64_t *tab, uint32_t key, uint32_t ca
 // count[key] += 1 ; claims an empty or dead (count 0) slot for a new key.
 // Only called when no decrement is in flight (see the two sweeps below), so a
 // key can never end up in two slots.
-__device__ __forceinline__ bool tab_inc(uint64_t *tab, uint32_t key, uint32_t cap, uint32_t hbits) {
+__device__ __forceinline__ bool tab_inc(uint64_t *tab, uint64_t key, uint32_t cap, uint32_t hbits) {
     volatile uint64_t *vt = tab;
     uint32_t s = tab_hash(key, hbits);
     for (uint32_t pr = 0; pr < 2u * cap + 64u; ++pr) {
         uint64_t v = vt[s];
-        if ((uint32_t)(v >> 32) == key) { atomicAdd((unsigned long long *)&tab[s], 1ull); return true; }
-        if ((uint32_t)v == 0u) {
-            uint64_t nv = ((uint64_t)key << 32) | 1ull;
+        if ((v >> PLO_VB) == key) { atomicAdd((unsigned long long *)&tab[s], 1ull); return true; }
+        if ((v & PLO_VMASK) == 0ull) {
+            uint64_t nv = (key << PLO_VB) | 1ull;
             uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)nv);
             if (old == v) return true;
             continue;                      // slot changed under us: look at it again
@@ -137,6 +147,232 @@ __device__ __forceinline__ bool tab_inc(uint64_t *tab, uint32_t key, uint32_t ca
         s = (s + 1u) & (cap - 1u);
     }
     return false;
+}
+
+// generic add on the table: slot = key<<32 | value; used by ProgramGen for the
+// (column, |coefficient|) multiset: low 16 bits = occurrences, bit 16 = "a
+// multiplier r := t_col * |coefficient| already exists" (`multiples`).
+__device__ __forceinline__ bool tab_add(uint64_t *tab, uint64_t key, uint32_t incv, uint32_t cap, uint32_t hbits) {
+    volatile uint64_t *vt = tab;
+    uint32_t s = tab_hash(key, hbits);
+    for (uint32_t pr = 0; pr < 2u * cap + 64u; ++pr) {
+        uint64_t v = vt[s];
+        if (v == PLO_EMPTY) {
+            uint64_t nv = (key << PLO_VB) | incv;
+            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)nv);
+            if (old == v) return true;
+            continue;
+        }
+        if ((v >> PLO_VB) == key) { atomicAdd((unsigned long long *)&tab[s], (unsigned long long)incv); return true; }
+        s = (s + 1u) & (cap - 1u);
+    }
+    return false;
+}
+__device__ __forceinline__ uint32_t tab_find(const uint64_t *tab, uint64_t key, uint32_t cap, uint32_t hbits) {
+    uint32_t s = tab_hash(key, hbits);
+    for (uint32_t pr = 0; pr < cap; ++pr) {
+        uint64_t v = tab[s];
+        if (v == PLO_EMPTY) return 0u;
+        if ((v >> PLO_VB) == key) return (uint32_t)(v & PLO_VMASK);
+        s = (s + 1u) & (cap - 1u);
+    }
+    return 0u;
+}
+
+#define PLO_FRESH 0xFFFFu       // column id of a variable created inside ProgramGen (never looked up by index)
+#define PLO_MFLAG 0x10000u      // "in multiples" flag in the table value
+
+// ProgramGen for general coefficients, counts only (reference
+// include/plinopt_optimize.inl:513-611).  Counting semantics, derived from the
+// reference code (DESIGN.md "ProgramGen, count-only"):
+//  A FactorOutColumns :318-371  every (column j, |v|=e) with e not +-1 occurring >1 times in
+//    column j costs one multiplication unless (j,e) is already in `multiples`; the entries become +-1
+//    entries of a fresh column.
+//  B FactorOutRows :375-420  every |v|=e not +-1 occurring f>1 times in a row costs f-1 additions and
+//    collapses into one entry (fresh column, e).
+//  C Triangle :427-507  scan order and the never-reset `found` flag restated literally.
+//  D output rows :547-604  len-1 additions per row; one multiplication per entry whose |v| is not +-1
+//    and whose (column,|v|) is not in `multiples`.
+// Numbering of fresh columns never influences a count, so they all carry the id PLO_FRESH.
+__device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const uint16_t *rs, uint32_t lane,
+                                        uint32_t ncols0, uint32_t nmult, uint32_t nbadd, uint32_t nbmul, uint32_t *errw)
+{
+    uint64_t *tab   = (uint64_t *)(reg + P.off_tab);
+    uint64_t *cmask = (uint64_t *)(reg + P.off_cmask);
+    uint64_t *umask = (uint64_t *)(reg + P.off_umask);
+    uint32_t *val   = (uint32_t *)(reg + P.off_val);
+    uint32_t *inv   = (uint32_t *)(reg + P.off_inv);
+    uint16_t *col   = (uint16_t *)(reg + P.off_col);
+    uint16_t *len   = (uint16_t *)(reg + P.off_len);
+    uint32_t *multv = (uint32_t *)(reg + P.off_mult);
+    uint32_t *multc = multv + P.multcap;
+    const uint32_t p = P.p, cap = P.cap, hbits = P.hbits, m = P.m, ms = 2u * P.mw, rb = P.rb;
+    const uint64_t mu = P.mu;
+    const uint32_t LPR = 1u << P.lpr_log2, G = 64u >> P.lpr_log2;
+    const uint32_t g = lane >> P.lpr_log2, t = lane & (LPR - 1u), gbase = g << P.lpr_log2;
+    const uint64_t gmask = (LPR == 64u) ? ~0ull : (((1ull << LPR) - 1ull) << gbase);
+    bool bad = false;
+
+    if (P.mw != 1u) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_PGEN); return 0; }
+
+    // multiset of (column, |v|) + the multiples set
+    for (uint32_t s = lane; s < cap; s += 64u) tab[s] = PLO_EMPTY;
+    PLO_WAVE_SYNC();
+    for (uint32_t s0 = 0; s0 < nmult; s0 += 64u)
+        if (s0 + lane < nmult) bad |= !tab_add(tab, ((uint64_t)multc[s0 + lane] << rb) | multv[s0 + lane], PLO_MFLAG, cap, hbits);
+    PLO_WAVE_SYNC();
+    // A1: occurrences of (j, e)
+    for (uint32_t r0 = 0; r0 < m; r0 += G) {
+        const uint32_t row = r0 + g; const bool act = row < m;
+        const uint32_t base = act ? rs[row] : 0u, ln = act ? len[row] : 0u;
+        if (t < ln) {
+            const uint32_t e = fabsp(val[base + t], p);
+            if (!absone(e, p)) bad |= !tab_add(tab, ((uint64_t)col[base + t] << rb) | e, 1u, cap, hbits);
+        }
+    }
+    PLO_WAVE_SYNC();
+    // A2: one multiplication per repeated (j,e) not yet in multiples; it joins multiples
+    {
+        uint32_t cnt = 0;
+        for (uint32_t s = lane; s < cap; s += 64u) {
+            uint64_t v = tab[s];
+            if (v != PLO_EMPTY && ((uint32_t)v & 0xFFFFu) >= 2u && !((uint32_t)v & PLO_MFLAG)) { ++cnt; tab[s] = v | PLO_MFLAG; }
+        }
+        nbmul += wave_sum(cnt);
+    }
+    PLO_WAVE_SYNC();
+    // A3: repeated entries move to a fresh column with value +-1
+    for (uint32_t r0 = 0; r0 < m; r0 += G) {
+        const uint32_t row = r0 + g; const bool act = row < m;
+        const uint32_t base = act ? rs[row] : 0u, ln = act ? len[row] : 0u;
+        if (t < ln) {
+            const uint32_t v = val[base + t], e = fabsp(v, p), c = col[base + t];
+            if (!absone(e, p) && (tab_find(tab, ((uint64_t)c << rb) | e, cap, hbits) & 0xFFFFu) >= 2u) {
+                const uint32_t u = (v == e) ? 1u : p - 1u;                 // Fsign >= 0 ? one : mOne
+                col[base + t] = (uint16_t)PLO_FRESH; val[base + t] = u; inv[base + t] = u;
+                atomicAnd((unsigned long long *)&cmask[c * ms], ~(1ull << row));
+            }
+        }
+    }
+    PLO_WAVE_SYNC();
+    // B: FactorOutRows on every row
+    {
+        uint32_t addacc = 0;
+        for (uint32_t r0 = 0; r0 < m; r0 += G) {
+            const uint32_t row = r0 + g; const bool act = row < m;
+            const uint32_t base = act ? rs[row] : 0u, ln = act ? len[row] : 0u;
+            const bool have = t < ln;
+            const uint32_t v = have ? val[base + t] : 0u, iv = have ? inv[base + t] : 0u, c = have ? col[base + t] : PLO_FRESH;
+            uint32_t e = have ? fabsp(v, p) : 0u;
+            if (absone(e, p)) e = 0u;
+            uint32_t freq = 0, first = LPR;
+            for (uint32_t u = 0; u < LPR; ++u) {
+                const uint32_t eu = bcast(e, gbase + u);
+                if (e != 0u && eu == e) { ++freq; if (first == LPR) first = u; }
+            }
+            const bool grouped = e != 0u && freq > 1u;
+            const bool leader = grouped && first == t;
+            if (leader) addacc += freq - 1u;
+            const bool keep = have && (!grouped || leader);
+            const uint64_t km = __ballot(keep) & gmask;
+            if (grouped && !leader && c != PLO_FRESH) atomicAnd((unsigned long long *)&cmask[c * ms], ~(1ull << row));
+            if (leader && c != PLO_FRESH) atomicAnd((unsigned long long *)&cmask[c * ms], ~(1ull << row));
+            if (keep) {
+                const uint32_t np = base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                if (leader) { col[np] = (uint16_t)PLO_FRESH; val[np] = e; inv[np] = (v == e) ? iv : p - iv; }
+                else { col[np] = (uint16_t)c; val[np] = v; inv[np] = iv; }
+            }
+            if (act && t == 0u) len[row] = (uint16_t)__popcll(km);
+        }
+        nbadd += wave_sum(addacc);
+    }
+    PLO_WAVE_SYNC();
+    // C: Triangle, column by column (rows on lanes; mw == 1)
+    for (uint32_t j = 0; j < ncols0; ++j) {
+        bool found = false;
+        for (;;) {
+            const uint64_t NU = uni64(cmask[j * ms] & ~umask[j * ms]);      // rows holding a non +-1 entry in column j
+            if (__popcll(NU) < 2) break;
+            const bool mine = (NU >> lane) & 1ull;
+            uint32_t vj = 0, ivj = 0;
+            if (mine) {
+                const uint32_t base = rs[lane], ln = len[lane];
+                for (uint32_t z = 0; z < ln; ++z) if (col[base + z] == j) { vj = val[base + z]; ivj = inv[base + z]; break; }
+            }
+            int it = -1, nx = -1;
+            uint64_t scan = NU;
+            if (found) {                                                      // only the first couple is looked at again
+                const uint32_t i0 = (uint32_t)__builtin_ctzll(NU);
+                scan = 1ull << i0;
+            }
+            while (scan) {
+                const uint32_t i0 = (uint32_t)__builtin_ctzll(scan); scan &= scan - 1ull;
+                const uint32_t v1 = bcast(vj, i0), iv1 = bcast(ivj, i0);
+                (void)v1;
+                uint64_t cand = NU & ~(1ull << i0);
+                if (found) cand = 1ull << __builtin_ctzll(cand);
+                bool hit = false;
+                if ((cand >> lane) & 1ull) {
+                    const uint32_t quot = fmul<false>(vj, iv1, p, mu), nq = p - quot;
+                    const uint32_t base = rs[lane], ln = len[lane];
+                    for (uint32_t z = 0; z < ln; ++z) {
+                        const uint32_t tv = val[base + z];
+                        if (col[base + z] != j && !absone(tv, p) && (tv == quot || tv == nq)) { hit = true; break; }
+                    }
+                }
+                const uint64_t hm = __ballot(hit);
+                if (hm) { it = (int)i0; nx = (int)__builtin_ctzll(hm); break; }
+            }
+            if (it < 0) break;
+            // apply :453-498
+            found = true;
+            const uint32_t v1 = bcast(vj, (uint32_t)it), iv1 = bcast(ivj, (uint32_t)it);
+            ++nbmul;                                                          // t_m := t_j * |a|
+            if (lane == 0) bad |= !tab_add(tab, ((uint64_t)j << rb) | v1, PLO_MFLAG, cap, hbits);   // multiples gets the SIGNED value (:464)
+            if (lane == (uint32_t)it) {
+                const uint32_t base = rs[lane], ln = len[lane];
+                for (uint32_t z = 0; z < ln; ++z) if (col[base + z] == j) { col[base + z] = (uint16_t)PLO_FRESH; val[base + z] = 1u; inv[base + z] = 1u; break; }
+            }
+            uint32_t addone = 0;
+            if (lane == (uint32_t)nx) {
+                const uint32_t quot = fmul<false>(vj, iv1, p, mu), iquot = fmul<false>(ivj, v1, p, mu);
+                const uint32_t eq = fabsp(quot, p), ieq = (quot == eq) ? iquot : p - iquot;
+                const uint32_t base = rs[lane], ln = len[lane];
+                uint32_t w = 0, f = 1;                                        // FactorOutRows on this row (:495-496)
+                for (uint32_t z = 0; z < ln; ++z) {
+                    const uint32_t cz = col[base + z], tv = val[base + z], ti = inv[base + z];
+                    if (cz == j) continue;                                    // moved to the new column with value quot
+                    if (fabsp(tv, p) == eq) { ++f; if (cz != PLO_FRESH) atomicAnd((unsigned long long *)&cmask[cz * ms], ~(1ull << lane)); continue; }
+                    col[base + w] = (uint16_t)cz; val[base + w] = tv; inv[base + w] = ti; ++w;
+                }
+                col[base + w] = (uint16_t)PLO_FRESH; val[base + w] = eq; inv[base + w] = ieq; ++w;
+                len[lane] = (uint16_t)w;
+                addone = f - 1u;
+            }
+            nbadd += bcast(addone, (uint32_t)nx);
+            if (lane == 0) cmask[j * ms] &= ~((1ull << it) | (1ull << nx));
+            PLO_WAVE_SYNC();
+        }
+    }
+    // D: output rows
+    {
+        uint32_t addacc = 0, mulacc = 0;
+        for (uint32_t r0 = 0; r0 < m; r0 += G) {
+            const uint32_t row = r0 + g; const bool act = row < m;
+            const uint32_t base = act ? rs[row] : 0u, ln = act ? len[row] : 0u;
+            if (act && t == 0u && ln > 1u) addacc += ln - 1u;
+            if (t < ln) {
+                const uint32_t e = fabsp(val[base + t], p), c = col[base + t];
+                if (!absone(e, p)) {
+                    const bool reuse = c != PLO_FRESH && (tab_find(tab, ((uint64_t)c << rb) | e, cap, hbits) & PLO_MFLAG);
+                    if (!reuse) ++mulacc;
+                }
+            }
+        }
+        nbadd += wave_sum(addacc); nbmul += wave_sum(mulacc);
+    }
+    if (__ballot(bad)) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_TABLE); }
+    return ((uint64_t)nbadd << 32) | nbmul;
 }
 
 // One candidate.  Returns packed (adds<<32 | muls); sets *errw on failure.
@@ -152,11 +388,13 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
     uint16_t *col   = (uint16_t *)(reg + P.off_col);
     uint16_t *len   = (uint16_t *)(reg + P.off_len);
     uint64_t *affw  = (uint64_t *)(reg + P.off_aff);      // [mw] affected rows, [mw] affected & coeff +-1, [1] scratch
-    uint32_t *ties  = (uint32_t *)(reg + P.off_ties);
+    uint16_t *ties  = (uint16_t *)(reg + P.off_ties);
     uint32_t *multv = (uint32_t *)(reg + P.off_mult);     // multcap values, then multcap u32 columns
     uint32_t *multc = multv + P.multcap;
 
-    const uint32_t p = P.p, NC = P.NC, cap = P.cap, hbits = P.hbits, mw = P.mw, ms = 2u * P.mw;   // masks interleaved: {cmask[mw],umask[mw]} per column
+    const uint32_t p = P.p, NC = P.NC, cap = P.cap, hbits = P.hbits, mw = P.mw, ms = 2u * P.mw;
+    const uint32_t rb = P.rb, bb = P.bb, abs_ = P.rb + P.bb;
+#define PLO_KEY(a_, b_, r_) (((uint64_t)(a_) << abs_) | ((uint64_t)(b_) << rb) | (uint64_t)(r_))   // masks interleaved: {cmask[mw],umask[mw]} per column
     const uint64_t mu = P.mu;
     const uint32_t LPR = 1u << P.lpr_log2, G = 64u >> P.lpr_log2;
     const uint32_t g = lane >> P.lpr_log2, t = lane & (LPR - 1u), gbase = g << P.lpr_log2;
@@ -169,47 +407,48 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         if (ncols >= NC) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_STEPS); break; }
         // ---- OneSub :244-253  maximal frequency over the pair table
         uint32_t lmax = 0;
-        for (uint32_t s = lane; s < cap; s += 64u) { uint32_t c = (uint32_t)tab[s]; lmax = c > lmax ? c : lmax; }
+        for (uint32_t s = lane; s < cap; s += 64u) { uint32_t c = (uint32_t)(tab[s] & PLO_VMASK); lmax = c > lmax ? c : lmax; }
         const uint32_t maxfrq = uni32(wave_max(lmax));
         if (maxfrq <= 1u) break;                                            // :255
         // ---- ties in map order; random pick :260-265
         uint32_t T = 0;
         for (uint32_t s0 = 0; s0 < cap; s0 += 64u) {
             uint64_t v = tab[s0 + lane];
-            bool is = (uint32_t)v == maxfrq;
+            bool is = (uint32_t)(v & PLO_VMASK) == maxfrq;
             uint64_t bm = __ballot(is);
-            if (is) ties[T + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)(v >> 32);
+            if (is) ties[T + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)(s0 + lane);
             T += (uint32_t)__popcll(bm);
         }
         T = uni32(T);
         PLO_WAVE_SYNC();
-        uint32_t key;
+        uint64_t key;
         if (T == 1u) {
-            key = ties[0];
+            key = tab[ties[0]] >> PLO_VB;
         } else {
             const uint32_t k = uni32(rng_next(rng) % T);
             if (T <= 64u) {
-                uint32_t mine = lane < T ? ties[lane] : 0xFFFFFFFFu, rank = 0;
-                for (uint32_t j = 0; j < T; ++j) rank += (bcast(mine, j) < mine) ? 1u : 0u;
+                const uint64_t mine = lane < T ? (tab[ties[lane]] >> PLO_VB) : ~0ull;
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < T; ++j) rank += (bcast64(mine, j) < mine) ? 1u : 0u;
                 uint64_t w = __ballot(lane < T && rank == k);
-                key = bcast(mine, (uint32_t)__builtin_ctzll(w));
+                key = bcast64(mine, (uint32_t)__builtin_ctzll(w));
             } else {
-                uint32_t lo = 0u, hi = 0xFFFFFFFEu;                       // k-th smallest by bisection on the key value
+                uint64_t lo = 0ull, hi = (1ull << 44) - 1ull;             // k-th smallest by bisection on the key value
                 while (lo < hi) {
-                    uint32_t mid = lo + ((hi - lo) >> 1), c = 0;
+                    uint64_t mid = lo + ((hi - lo) >> 1); uint32_t c = 0;
                     for (uint32_t s0 = 0; s0 < T; s0 += 64u) {
-                        bool le = (s0 + lane < T) && ties[s0 + lane] <= mid;
+                        bool le = (s0 + lane < T) && (tab[ties[s0 + lane]] >> PLO_VB) <= mid;
                         c += (uint32_t)__popcll(__ballot(le));
                     }
-                    if (c >= k + 1u) hi = mid; else lo = mid + 1u;
+                    if (c >= k + 1u) hi = mid; else lo = mid + 1ull;
                 }
                 key = lo;
             }
         }
-        key = uni32(key);
+        key = uni64(key);
         ++nbadd;                                                            // :292
         // ---- RemOneCSE :60-194
-        const uint32_t r = key % p, ab = key / p, a = ab / NC, b = ab % NC;
+        const uint32_t r = (uint32_t)(key & ((1ull << rb) - 1ull)), b = (uint32_t)(key >> rb) & ((1u << bb) - 1u), a = (uint32_t)(key >> abs_);
         uint32_t c0 = 0, c1 = 0;
         for (uint32_t w = 0; w < mw; ++w) { c0 += (uint32_t)__popcll(umask[a * ms + w]); c1 += (uint32_t)__popcll(umask[b * ms + w]); }
         const bool swap = uni32(c0) < uni32(c1);                                          // :79-88
@@ -234,8 +473,8 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
                 const bool aff = act && ma && mb && vb == fmul<UNIT>(r, va, p, mu);
                 if (aff && have) {
                     if (lane != la && lane != lb) {
-                        uint32_t k1 = c < a ? (c * NC + a) * p + fmul<UNIT>(va, iv, p, mu) : (a * NC + c) * p + fmul<UNIT>(v, ia, p, mu);
-                        uint32_t k2 = c < b ? (c * NC + b) * p + fmul<UNIT>(vb, iv, p, mu) : (b * NC + c) * p + fmul<UNIT>(v, ib, p, mu);
+                        uint64_t k1 = c < a ? PLO_KEY(c, a, fmul<UNIT>(va, iv, p, mu)) : PLO_KEY(a, c, fmul<UNIT>(v, ia, p, mu));
+                        uint64_t k2 = c < b ? PLO_KEY(c, b, fmul<UNIT>(vb, iv, p, mu)) : PLO_KEY(b, c, fmul<UNIT>(v, ib, p, mu));
                         bad |= !tab_dec(tab, k1, cap, hbits);
                         bad |= !tab_dec(tab, k2, cap, hbits);
                     } else if (lane == la) {
@@ -263,7 +502,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
                 const uint32_t coeff = bcast(v, q0), icoeff = bcast(iv, q0);
                 if (have) {
                     if (lane != q0 && lane != q1) {
-                        bad |= !tab_inc(tab, (c * NC + lm) * p + fmul<UNIT>(coeff, iv, p, mu), cap, hbits);
+                        bad |= !tab_inc(tab, PLO_KEY(c, lm, fmul<UNIT>(coeff, iv, p, mu)), cap, hbits);
                         const uint32_t np = base + t - (lane > q0 ? 1u : 0u) - (lane > q1 ? 1u : 0u);
                         col[np] = (uint16_t)c; val[np] = v; if (!UNIT) inv[np] = iv;
                     } else if (lane == q0) {
@@ -310,7 +549,8 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         for (uint32_t i = lane; i < P.m; i += 64u) { uint32_t ln = len[i]; acc += ln > 1u ? ln - 1u : 0u; }
         nbadd += wave_sum(acc);
     } else {
-        if (lane == 0) atomicMax(errw, (uint32_t)ERR_PGEN);   // general ProgramGen lives in plo_cse_pgen (see host dispatch)
+        PLO_WAVE_SYNC();
+        return program_gen_general(P, reg, rs, lane, ncols, nmult, nbadd, nbmul, errw);
     }
     return ((uint64_t)nbadd << 32) | nbmul;
 }

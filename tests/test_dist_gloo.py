@@ -1,0 +1,64 @@
+"""N>1 path on CPU: two gloo ranks shard the seed range, each reduces its shard to a packed
+(cost, seed) word and ONE MIN all-reduce yields the same winner as the unsharded search.
+The per-shard search is done by the CPU oracle here (stand-in for the device; test-only)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch, torch.distributed as dist
+from plinopt_amd.dist import shard_range, allreduce_best
+from plo_testlib import DATA, OracleMatrix
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), 131071)
+seed0, n = 777, 3001
+for mode in (0, 1, 2):
+    s, cnt = shard_range(seed0, n, rank, world)
+    local = M.search(s, cnt, cost_mode=mode) if cnt else None
+    seed, word = allreduce_best(local, seed0, mode)
+    exp = M.search(seed0, n, cost_mode=mode)
+    assert seed == exp[2], (mode, seed, exp)
+# a rank with an empty shard must not disturb the reduction
+s, cnt = shard_range(5, 1, rank, world)
+local = M.search(s, cnt) if cnt else None
+seed, word = allreduce_best(local, 5, 0)
+assert seed == 5
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_seed_shard_min_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
+
+
+def test_shard_range_partitions_exactly():
+    from plinopt_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            got = [shard_range(100, n, r, world) for r in range(world)]
+            assert sum(c for _, c in got) == n
+            pos = 100
+            for s, c in got:
+                assert s == pos
+                pos += c
+
+
+def test_pack_key_order():
+    from plinopt_amd.dist import pack_key
+    assert pack_key(10, 2, 5) < pack_key(11, 1, 0) < pack_key(9, 4, 0)
+    assert pack_key(10, 2, 5) < pack_key(10, 2, 6)
+    assert pack_key(3, 100, 0, 1) < pack_key(4, 0, 0, 1)
+    assert pack_key(0, 0, 0) >= 0 and pack_key(32767, 0, 2 ** 32 - 1) < 2 ** 63

@@ -52,16 +52,16 @@ def test_search_argmin_matches_oracle(hip, name, mode):
 
 
 def test_other_modulus(hip):
-    for p in (7, 65537):
+    for p in (7, 65537, 2147483629):
         M = OracleMatrix.from_sms(os.path.join(DATA, "3x3x3_23_58_L.sms"), p)
         plan = _plan(M)
         assert plan.cost_many(seed0=5, n=500) == tuple(M.cost_many(seed0=5, nseeds=500, nthreads=8))
 
 
 def test_capacity_error_is_loud(hip):
-    """A modulus whose pair key needs more than 32 bits is refused, never silently rerouted."""
+    """A modulus whose pair key needs more than 44 bits is refused, never silently rerouted."""
     from plinopt_amd import capi
-    M = OracleMatrix.from_sms(os.path.join(DATA, "3x3x3_23_58_L.sms"), 2147483629)
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_P.sms"), 2147483629)
     with pytest.raises(capi.PloError) as e:
         _plan(M)
     assert e.value.code == capi.PLO_E_CAPACITY

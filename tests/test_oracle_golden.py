@@ -1,0 +1,99 @@
+"""Pins of the CPU oracle (oracle/plo_oracle.c) against the reference's own fixtures.
+
+The reference pins no op-count or program text (its tests assert semantic
+correctness only: Makefile:85-87, bin/FDT.sh:58), so the oracle is pinned by
+  (1) every emitted SLP evaluates to the input matrix (the `slpcheck` criterion),
+  (2) reported (adds, muls) == op-count of the emitted text (`lineOperations`),
+  (3) the hand-checked first tie set of Winograd L,
+  (4) best cost <= the stored-SLP bounds of data/*.slp, which themselves verify.
+"""
+import glob
+import json
+import os
+
+import pytest
+
+import synth
+from plo_testlib import (DATA, GOLDEN, FieldP, FieldQ, OracleMatrix, count_ops, eval_slp, read_sms)
+
+P = 131071
+ALL = sorted(os.path.basename(f) for f in glob.glob(os.path.join(DATA, "*.sms")) if "-X_" not in f)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_emitted_slp_computes_the_matrix(name):
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    D = M.dense()
+    F = FieldP(P)
+    for seed in (0, 1, 99):
+        a, mu, txt = M.optimizer(seed)
+        assert eval_slp(txt, F) == D
+        assert count_ops(txt) == (a, mu)
+        assert M.cost_many(seeds=[seed]) == ([a], [mu])       # count-only path == text path
+
+
+def test_winograd_first_tie_set_hand_checked():
+    # 6 distinct triples; two of frequency 3, in map order (0,2,-1),(2,3,1)
+    M = OracleMatrix.from_sms(os.path.join(DATA, "2x2x2_7_Winograd_L.sms"), P)
+    ties, maxfrq = M.first_ties()
+    assert maxfrq == 3
+    assert ties == [(0, 2, P - 1), (2, 3, 1)]
+
+
+def test_other_tie_sets_from_survey_table():
+    # SURVEY.md 8a size table: max frequency (number of ties)
+    for name, frq, nties in [("cyclic.sms", 4, 8), ("4x4x4_49_156_L.sms", 12, 12), ("4x4x4_49_156_P.sms", 12, 2)]:
+        M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+        ties, maxfrq = M.first_ties()
+        assert (maxfrq, len(ties)) == (frq, nties), name
+        assert ties == sorted(ties)
+
+
+@pytest.mark.parametrize("name,bound", [
+    ("2x2x2_7_Winograd_L", 4), ("2x2x2_7_Winograd_R", 4), ("2x2x2_7_Winograd_P", 7),
+])
+def test_reaches_known_optimum_on_winograd(name, bound):
+    M = OracleMatrix.from_sms(os.path.join(DATA, name + ".sms"), P)
+    a, mu, seed = M.search(0, 200)
+    assert (a, mu) == (bound, 0)
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L", "3x3x3_23_58_L", "4x4x4_49_156_L", "4x4x4_49_156_P"])
+def test_stored_slp_is_a_valid_bound(name):
+    """data/<name>.slp computes data/<name>.sms (data/Makefile:37-38 `%.chk`); its op-count is an
+    achievable bound that the greedy search approaches (quality sanity, not parity)."""
+    m, n, ent = read_sms(os.path.join(DATA, name + ".sms"))
+    txt = open(os.path.join(DATA, name + ".slp")).read()
+    assert eval_slp(txt, FieldQ) == ent
+    stored_adds, stored_muls = count_ops(txt)
+    M = OracleMatrix.from_sms(os.path.join(DATA, name + ".sms"), P)
+    a, mu, _ = M.search(0, 300, nthreads=4)
+    na, nm = M.naive_ops()
+    assert a + mu < na + nm
+    assert a + mu <= stored_adds + stored_muls + max(4, (stored_adds + stored_muls) // 8)
+
+
+def test_triangle_and_factoring_paths_emit_valid_programs():
+    F = FieldP(P)
+    tri = 0
+    for s in range(600):
+        m, n, rows = synth.small_valued(s, P)
+        rp, c, v = synth.to_csr(rows, P)
+        M = OracleMatrix(m, n, rp, c, v, P)
+        a, mu, txt = M.optimizer(s)
+        assert eval_slp(txt, F) == M.dense(), (s, rows)
+        assert count_ops(txt) == (a, mu)
+    m, n, rows = 2, 2, [{0: 2}, {0: 6, 1: 3}]
+    rp, c, v = synth.to_csr(rows, P)
+    a, mu, txt = OracleMatrix(m, n, rp, c, v, P).optimizer(0)
+    assert (a, mu) == (1, 2)            # one triangle: 2 multiplications instead of 3
+
+
+def test_golden_costs_fixture():
+    """Frozen (adds, muls) vectors of the oracle itself (tests/golden/oracle_costs.json, made by
+    tests/golden/make_oracle_costs.py): guards the checker against silent drift."""
+    G = json.load(open(os.path.join(GOLDEN, "oracle_costs.json")))
+    for name, rec in G["matrices"].items():
+        M = OracleMatrix.from_sms(os.path.join(DATA, name), G["p"])
+        a, mu = M.cost_many(seed0=rec["seed0"], nseeds=len(rec["adds"]))
+        assert a == rec["adds"] and mu == rec["muls"], name
