@@ -1,0 +1,194 @@
+// ===========================================================================
+// bin/optimizer -- front-end keeping the reference CLI contract of
+// src/optimizer.cpp:150-228: flags -D -K -G -A -F -E -N -P -M -q # -v # -O #,
+// SLP on stdout only (:87), `#`-prefixed statistics on stderr (:89-98).
+// New flags (the reference has none): --gpu N (0 = host only), --seed S.
+//
+// With -q p the restart loop of CSEOptimiser (include/plinopt_optimize.inl:
+// 1204-1238) runs on the GPU through the C-ABI of libplinopt_hip.so
+// (plo_cse_search); the winning seed is then replayed on the host to produce
+// the program text.  Over the rationals (no -q) the loop runs on the host, as
+// in the reference.  A failing GPU call is fatal: there is no silent fallback.
+// ===========================================================================
+#include "plo_host.hpp"
+#include "../../../include/plinopt_hip.h"
+
+#include <chrono>
+#include <dlfcn.h>
+#include <libgen.h>
+#include <unistd.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace plo;
+using Ops = std::pair<size_t, size_t>;
+
+namespace {
+
+struct HipLib {
+    void *h = nullptr;
+    decltype(&plo_init) init = nullptr;
+    decltype(&plo_last_error) last_error = nullptr;
+    decltype(&plo_cse_search) cse_search = nullptr;
+    decltype(&plo_shutdown) shutdown = nullptr;
+    bool load(const char *argv0) {
+        std::vector<std::string> cand;
+        if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
+        char buf[4096]; ssize_t k = readlink("/proc/self/exe", buf, sizeof buf - 1);
+        if (k > 0) { buf[k] = 0; std::string d = dirname(buf); cand.push_back(d + "/../plinopt_amd/libplinopt_hip.so"); cand.push_back(d + "/libplinopt_hip.so"); }
+        cand.emplace_back("libplinopt_hip.so");
+        for (auto &c : cand) { h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        (void)argv0;
+        if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
+        init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
+        cse_search = (decltype(cse_search))dlsym(h, "plo_cse_search"); shutdown = (decltype(shutdown))dlsym(h, "plo_shutdown");
+        return init && last_error && cse_search && shutdown;
+    }
+};
+
+template <class F> std::string replay_text(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed, Ops &ops) {
+    std::ostringstream os;
+    input2temps(os, lM, 'i', 't');                          // plinopt_optimize.inl:1211
+    Replay<F> R(f, lM, seed, os, 'o', 't', 'r');
+    ops = R.optimizer();                                    // :1212
+    return os.str();
+}
+
+// host restart loop (rationals, or --gpu 0): candidates seed0..seed0+loops-1, total order (cmpOpCount, seed)
+template <class F> bool host_search(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, Ops &best, uint64_t &bseed) {
+    bool have = false;
+#pragma omp parallel for schedule(dynamic)
+    for (long long k = 0; k < (long long)loops; ++k) {
+        std::ostringstream sink; Ops ops;
+        Replay<F> R(f, lM, seed0 + (uint64_t)k, sink, 'o', 't', 'r');
+        ops = R.optimizer();
+#pragma omp critical
+        {
+            uint64_t s = seed0 + (uint64_t)k;
+            if (!have || cmp_op_count(ops, best) || (!cmp_op_count(best, ops) && s < bseed)) { best = ops; bseed = s; have = true; }
+        }
+    }
+    return have;
+}
+
+template <class F>
+int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool tryDirect, bool tryKernel, bool tryLU,
+        bool tryAB, bool mostCSE, bool allkernels, int verbose, uint32_t q, const char *argv0)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    std::clog << std::string(40, '#') << std::endl;
+    const Ops opsinit = naive_ops(QField(), MQ);            // src/optimizer.cpp:77: computed over Q
+    auto lM = rebind(MQ, f);
+    Ops nbops = opsinit; std::string text;
+
+    if (tryAB) std::clog << "# -A (alternative factorization) is not part of this build (SURVEY.md 8f)" << std::endl;
+    if (tryDirect) {
+        Ops dops; uint64_t seed = 0; bool have = false;
+        bool on_gpu = false;
+        if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+            on_gpu = true;
+            HipLib L;
+            if (!L.load(argv0)) return 2;
+            if (L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m" << std::endl; return 2; }
+            std::vector<uint32_t> rp(1, 0), cc, vv;
+            for (auto &r : lM.rows) { for (auto &e : r) { cc.push_back((uint32_t)e.first); vv.push_back((uint32_t)e.second); } rp.push_back((uint32_t)cc.size()); }
+            plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
+            plo_best_t b{}; plo_stats_t st{};
+            int rc = L.cse_search(&A, q, seed0, loops, PLO_COST_SUM_THEN_ADD, &b, &st);
+            if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: GPU search failed (" << rc << "): " << L.last_error() << "\033[0m" << std::endl; return 2; }
+            dops = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
+            if (verbose > 0)
+                std::clog << "# GPU: " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms, "
+                          << (st.kernel_ms > 0 ? st.candidates / (st.kernel_ms * 1e-3) : 0.0) << " candidates/s" << std::endl;
+            L.shutdown();
+        }
+        if (!on_gpu) have = host_search(f, lM, seed0, loops, dops, seed);
+        if (have) {
+            Ops rops; std::string t = replay_text(f, lM, seed, rops);
+            if (rops != dops) { std::cerr << "# \033[1;31mERROR: replay of seed " << seed << " gives " << rops.first << '|' << rops.second
+                                          << ", search said " << dops.first << '|' << dops.second << "\033[0m" << std::endl; return 3; }
+            if (verbose > 0) std::clog << "# Found D: " << dops.first << '|' << dops.second << " instead of "
+                                       << nbops.first << '|' << nbops.second << "\t[seed " << seed << ']' << std::endl;
+            if (cmp_op_count(dops, nbops)) { nbops = dops; text = t; }                 // :1241-1245
+        }
+    }
+    if (tryKernel && verbose > 1) std::clog << "# -K (kernel method) is not part of this build (SURVEY.md 8f)" << std::endl;
+    if (tryLU && verbose > 1) std::clog << "# -G (LU method) is not part of this build (SURVEY.md 8f)" << std::endl;
+    if (allkernels) std::clog << "# -N (exhaustive nullspace permutations) is not part of this build" << std::endl;
+    if (mostCSE) std::clog << "# -E (exhaustive CSE tree) is not part of this build (SURVEY.md 8f)" << std::endl;
+
+    if (cmp_op_count(opsinit, nbops) || opsinit == nbops) {                           // :1473-1485
+        std::ostringstream os;
+        input2temps(os, lM, 'i', 't');
+        Replay<F> R(f, lM, 0, os, 'o', 't', 'r');
+        nbops = R.direct(); text = os.str();
+    }
+    std::cout << text << std::flush;                                                  // src/optimizer.cpp:87
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (nbops.first != 0 || nbops.second != 0) {
+        std::clog << std::string(40, '#') << std::endl;
+        std::clog << "# \033[1;32m" << nbops.first << "\tadditions\tinstead of " << opsinit.first << "\033[0m \t" << secs << "s" << std::endl;
+        std::clog << "# \033[1;32m" << nbops.second << "\tmultiplications\tinstead of " << opsinit.second << "\033[0m" << std::endl;
+        std::clog << std::string(40, '#') << std::endl;
+    }
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    bool printMaple = false, printPretty = false, mostCSE = false, tryKernel = false, tryLU = false, tryAB = false,
+         tryDirect = false, allkernels = false;
+    int verbose = 1, gpu = 1; size_t loops = 100; uint64_t q = 0, seed0 = 0; std::string filename; bool replay_only = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a(argv[i]);
+        if (a == "-h") {
+            std::clog << "Usage: " << argv[0] << " [-h|-M|-P|-K|-D|-G|-E|-N|-A|-q #|-O #|--gpu #|--seed #] [stdin|matrixfile.sms]\n"
+                      << "  -D/-K/-G: direct/kernel/LU methods (default is all; this build runs -D)\n"
+                      << "  -q #: search modulo (default is Rationals, on the host)\n"
+                      << "  -O #: randomized search with that many loops (default " << loops << " loops)\n"
+                      << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only\n"
+                      << "  --seed #: first candidate seed (default 0)\n";
+            exit(-1);
+        } else if (a == "-M") printMaple = true;
+        else if (a == "-P") printPretty = true;
+        else if (a == "-G") tryLU = true;
+        else if (a == "-A") tryAB = true;
+        else if (a == "-D") tryDirect = true;
+        else if (a == "-K") tryKernel = true;
+        else if (a == "-F") { }
+        else if (a == "-E") mostCSE = true;
+        else if (a == "-N") allkernels = true;
+        else if (a == "-q" && i + 1 < argc) q = strtoull(argv[++i], nullptr, 10);
+        else if (a == "-v" && i + 1 < argc) verbose = atoi(argv[++i]);
+        else if (a == "-O" && i + 1 < argc) loops = strtoull(argv[++i], nullptr, 10);
+        else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
+        else if (a == "--replay") replay_only = true;    // print the program of candidate --seed, no search
+        else filename = a;
+    }
+    if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
+    (void)printMaple; (void)printPretty;
+    try {
+        QMat MQ;
+        if (filename.empty()) MQ = read_sms(std::cin);
+        else { std::ifstream in(filename); if (!in) return -1; MQ = read_sms(in); }
+        if (replay_only) {
+            Ops ops;
+            if (q) { ZpField f((uint32_t)q); std::cout << replay_text(f, rebind(MQ, f), seed0, ops); }
+            else { QField f; std::cout << replay_text(f, rebind(MQ, f), seed0, ops); }
+            std::clog << "# " << ops.first << "\tadditions\n# " << ops.second << "\tmultiplications" << std::endl;
+            return 0;
+        }
+        if (q != 0) {
+            if (q < 3 || q >= (1ull << 31)) { std::cerr << "# ERROR: modulus must be an odd prime below 2^31 in this build" << std::endl; return -1; }
+            return run(ZpField((uint32_t)q), MQ, loops, seed0, gpu, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, verbose, (uint32_t)q, argv[0]);
+        }
+        return run(QField(), MQ, loops, seed0, 0, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, verbose, 0, argv[0]);
+    } catch (const std::exception &e) {
+        std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m" << std::endl;
+        return -1;
+    }
+}

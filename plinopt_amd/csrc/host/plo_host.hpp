@@ -1,0 +1,556 @@
+// ===========================================================================
+// plo_host.hpp -- dependency-free C++17 host substrate of the drop-in:
+// what the reference gets from Givaro/LinBox for this path, and no more.
+//   * fields Z_p (canonical residues, integer order) and Q (exact small rationals)
+//   * sparse row matrix, SMS reader/writer (reference README.md:71-77)
+//   * SLP parser/evaluator -> matrix (what src/SLPchecker.cpp:22-105 verifies)
+//   * `replay`: text-emitting Optimizer() for ONE seed -- the host replays the
+//     seed the GPU search returned (include/plinopt_optimize.inl:616-631) and
+//     also serves the rational (Q) path of bin/optimizer, which the reference
+//     runs on the CPU and BASELINE config[0] keeps there ("plumbing, no GPU").
+// This is product code; it never includes or links anything under oracle/.
+// ===========================================================================
+#ifndef PLO_HOST_HPP
+#define PLO_HOST_HPP
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <numeric>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+namespace plo {
+
+// ------------------------------------------------------------------ rationals
+struct Rat {
+    int64_t n = 0, d = 1;
+    Rat() = default;
+    Rat(int64_t nn, int64_t dd = 1) { set((__int128)nn, (__int128)dd); }
+    void set(__int128 nn, __int128 dd) {
+        if (dd == 0) throw std::domain_error("rational with zero denominator");
+        if (dd < 0) { nn = -nn; dd = -dd; }
+        __int128 a = nn < 0 ? -nn : nn, b = dd;
+        while (b) { __int128 t = a % b; a = b; b = t; }
+        if (a > 1) { nn /= a; dd /= a; }
+        if (nn > INT64_MAX || nn < -INT64_MAX || dd > INT64_MAX) throw std::overflow_error("rational overflow (64-bit)");
+        n = (int64_t)nn; d = (int64_t)dd;
+    }
+    static Rat make(__int128 nn, __int128 dd) { Rat r; r.set(nn, dd); return r; }
+    bool operator==(const Rat &o) const { return n == o.n && d == o.d; }
+    bool operator!=(const Rat &o) const { return !(*this == o); }
+    bool operator<(const Rat &o) const { return (__int128)n * o.d < (__int128)o.n * d; }
+};
+inline std::ostream &operator<<(std::ostream &os, const Rat &r) { os << r.n; if (r.d != 1) os << '/' << r.d; return os; }
+
+inline Rat parse_rat(const std::string &s) {
+    auto sl = s.find('/');
+    if (sl == std::string::npos) return Rat(std::stoll(s));
+    return Rat(std::stoll(s.substr(0, sl)), std::stoll(s.substr(sl + 1)));
+}
+
+// --------------------------------------------------------------------- fields
+// Z_p with Givaro::Modular<Integer> conventions:
+// canonical residues in [0,p), operator< is integer order, isMOne(e) <=> e==p-1,
+// Fabs/Fsign as include/plinopt_library.h:209-225.
+struct ZpField {
+    using Elt = uint32_t;
+    uint32_t p;
+    explicit ZpField(uint32_t pp) : p(pp) {}
+    Elt zero() const { return 0; }
+    Elt one() const { return 1u % p; }
+    Elt mone() const { return p - 1; }
+    Elt mul(Elt a, Elt b) const { return (Elt)((uint64_t)a * b % p); }
+    Elt add(Elt a, Elt b) const { return (Elt)(((uint64_t)a + b) % p); }
+    Elt neg(Elt a) const { return a ? p - a : 0; }
+    Elt inv(Elt a) const {
+        int64_t t = 0, nt = 1, r = p, nr = a % p;
+        while (nr) { int64_t q = r / nr, x = t - q * nt; t = nt; nt = x; x = r - q * nr; r = nr; nr = x; }
+        if (r != 1) throw std::domain_error("element not invertible mod p");
+        if (t < 0) t += p;
+        return (Elt)t;
+    }
+    Elt div(Elt a, Elt b) const { return mul(a, inv(b)); }
+    bool isZero(Elt a) const { return a == 0; }
+    bool isOne(Elt a) const { return a == one(); }
+    bool isMOne(Elt a) const { return a == mone(); }
+    bool less(Elt a, Elt b) const { return a < b; }
+    Elt abs(Elt e) const { Elt a = neg(e); return a < e ? a : e; }
+    int sign(Elt e) const { if (!e) return 0; return neg(e) < e ? -1 : 1; }
+    Elt fromRat(const Rat &r) const {
+        int64_t nn = r.n % (int64_t)p; if (nn < 0) nn += p;
+        Elt dd = (Elt)(r.d % (int64_t)p);
+        if (dd == 0) throw std::domain_error("denominator vanishes mod p");
+        return div((Elt)nn, dd);
+    }
+    Elt fromInt(int64_t v) const { int64_t x = v % (int64_t)p; if (x < 0) x += p; return (Elt)x; }
+    void write(std::ostream &os, Elt e) const { os << e; }
+    // printmulorjustdiv, generic: include/plinopt_library.inl:348-358
+    void print_mul(std::ostream &os, char c, size_t i, Elt e, size_t &nbmul) const {
+        os << c << i;
+        if (!(isOne(e) || isMOne(e))) { ++nbmul; os << '*' << e; }
+    }
+    std::string name() const { return "Z/" + std::to_string(p) + "Z"; }
+};
+
+struct QField {
+    using Elt = Rat;
+    Elt zero() const { return Rat(0); }
+    Elt one() const { return Rat(1); }
+    Elt mone() const { return Rat(-1); }
+    Elt mul(const Elt &a, const Elt &b) const { return Rat::make((__int128)a.n * b.n, (__int128)a.d * b.d); }
+    Elt add(const Elt &a, const Elt &b) const { return Rat::make((__int128)a.n * b.d + (__int128)b.n * a.d, (__int128)a.d * b.d); }
+    Elt neg(const Elt &a) const { return Rat::make(-(__int128)a.n, a.d); }
+    Elt inv(const Elt &a) const { return Rat::make(a.d, a.n); }
+    Elt div(const Elt &a, const Elt &b) const { return Rat::make((__int128)a.n * b.d, (__int128)a.d * b.n); }
+    bool isZero(const Elt &a) const { return a.n == 0; }
+    bool isOne(const Elt &a) const { return a.n == 1 && a.d == 1; }
+    bool isMOne(const Elt &a) const { return a.n == -1 && a.d == 1; }
+    bool less(const Elt &a, const Elt &b) const { return a < b; }
+    Elt abs(const Elt &e) const { return e.n < 0 ? neg(e) : e; }
+    int sign(const Elt &e) const { return e.n > 0 ? 1 : (e.n < 0 ? -1 : 0); }
+    Elt fromRat(const Rat &r) const { return r; }
+    Elt fromInt(int64_t v) const { return Rat(v); }
+    void write(std::ostream &os, const Elt &e) const { os << e; }
+    // printmulorjustdiv, rational specialisation: include/plinopt_library.inl:360-374
+    void print_mul(std::ostream &os, char c, size_t i, const Elt &r, size_t &nbmul) const {
+        os << c << i;
+        if (!isOne(r)) { ++nbmul; if (r.n == 1) os << '/' << r.d; else os << '*' << r; }
+    }
+    std::string name() const { return "Q"; }
+};
+
+template <class F> inline bool absOne(const F &f, const typename F::Elt &e) { return f.isOne(e) || f.isMOne(e); }
+
+// --------------------------------------------------------------------- matrix
+template <class E> struct SparseMat {
+    using Row = std::vector<std::pair<size_t, E>>;
+    std::vector<Row> rows;
+    size_t ncols = 0;
+    SparseMat() = default;
+    SparseMat(size_t m, size_t n) : rows(m), ncols(n) {}
+    size_t rowdim() const { return rows.size(); }
+    size_t coldim() const { return ncols; }
+    size_t nnz() const { size_t s = 0; for (auto &r : rows) s += r.size(); return s; }
+};
+using QMat = SparseMat<Rat>;
+
+template <class E> SparseMat<E> transpose(const SparseMat<E> &A) {   // plinopt_library.inl:18-24
+    SparseMat<E> T(A.coldim(), A.rowdim());
+    for (size_t i = 0; i < A.rowdim(); ++i) for (auto &e : A.rows[i]) T.rows[e.first].emplace_back(i, e.second);
+    return T;
+}
+// rebind<Field>::other(M,F): rational -> field image, entries that vanish are dropped (Appendix B)
+template <class F> SparseMat<typename F::Elt> rebind(const QMat &M, const F &f) {
+    SparseMat<typename F::Elt> R(M.rowdim(), M.coldim());
+    for (size_t i = 0; i < M.rowdim(); ++i)
+        for (auto &e : M.rows[i]) { auto v = f.fromRat(e.second); if (!f.isZero(v)) R.rows[i].emplace_back(e.first, v); }
+    return R;
+}
+// naiveOps, plinopt_library.inl:227-235
+template <class F, class E> std::pair<size_t, size_t> naive_ops(const F &f, const SparseMat<E> &M) {
+    size_t a = 0, mu = 0;
+    for (auto &r : M.rows) { if (r.size() > 1) a += r.size() - 1; for (auto &e : r) if (!absOne(f, e.second)) ++mu; }
+    return {a, mu};
+}
+
+// SMS: header `m n R|M`, 1-based triples, `0 0 0` terminator, `#`/`%` comments, ints or a/b
+inline QMat read_sms(std::istream &in) {
+    std::string line; bool header = false; QMat M;
+    std::vector<std::tuple<size_t, size_t, Rat>> ent;
+    size_t m = 0, n = 0;
+    while (std::getline(in, line)) {
+        size_t b = line.find_first_not_of(" \t\r");
+        if (b == std::string::npos || line[b] == '#' || line[b] == '%') continue;
+        std::istringstream ls(line);
+        if (!header) { std::string ty; if (!(ls >> m >> n)) throw std::runtime_error("SMS: bad header"); ls >> ty; header = true; continue; }
+        long long i, j; std::string v;
+        if (!(ls >> i >> j >> v)) throw std::runtime_error("SMS: bad triple: " + line);
+        if (i == 0 && j == 0) break;
+        if (i < 1 || j < 1 || (size_t)i > m || (size_t)j > n) throw std::runtime_error("SMS: index out of range: " + line);
+        Rat r = parse_rat(v);
+        if (r.n != 0) ent.emplace_back((size_t)i - 1, (size_t)j - 1, r);
+    }
+    if (!header) throw std::runtime_error("SMS: empty input");
+    M = QMat(m, n);
+    for (auto &t : ent) {
+        auto &row = M.rows[std::get<0>(t)];
+        auto it = std::lower_bound(row.begin(), row.end(), std::get<1>(t), [](const std::pair<size_t, Rat> &e, size_t c) { return e.first < c; });
+        if (it != row.end() && it->first == std::get<1>(t)) it->second = std::get<2>(t); else row.insert(it, {std::get<1>(t), std::get<2>(t)});
+    }
+    return M;
+}
+template <class F, class E> void write_sms(std::ostream &os, const F &f, const SparseMat<E> &M, char ty = 'R') {
+    os << M.rowdim() << ' ' << M.coldim() << ' ' << ty << '\n';
+    for (size_t i = 0; i < M.rowdim(); ++i) for (auto &e : M.rows[i]) { os << i + 1 << ' ' << e.first + 1 << ' '; f.write(os, e.second); os << '\n'; }
+    os << "0 0 0\n";
+}
+
+// ------------------------------------------------------------------------ SLP
+// Straight-line programs `lhs:=expr;` over + - * / ( ), naturals and a/b
+// constants (reference README.md:83-92).  evaluate(): matrix of the outputs
+// `o#` in terms of the inputs `i#` (matrixBuilder, plinopt_programs.inl:1458-1608).
+template <class F> class SlpEval {
+    using E = typename F::Elt;
+    using Lin = std::vector<std::pair<long, E>>;       // sorted by index; index -1 = constant term
+    const F &f;
+    std::map<std::string, Lin> vars;
+    std::vector<std::string> tk; size_t pos = 0;
+
+    Lin axpy(const Lin &x, const Lin &y, bool minus) const {
+        Lin o; o.reserve(x.size() + y.size());
+        size_t a = 0, b = 0;
+        while (a < x.size() || b < y.size()) {
+            if (b == y.size() || (a < x.size() && x[a].first < y[b].first)) o.push_back(x[a++]);
+            else if (a == x.size() || y[b].first < x[a].first) { o.emplace_back(y[b].first, minus ? f.neg(y[b].second) : y[b].second); ++b; }
+            else { E v = f.add(x[a].second, minus ? f.neg(y[b].second) : y[b].second); if (!f.isZero(v)) o.emplace_back(x[a].first, v); ++a; ++b; }
+        }
+        return o;
+    }
+    Lin scale(const Lin &x, const E &c) const { Lin o; for (auto &e : x) { E v = f.mul(e.second, c); if (!f.isZero(v)) o.emplace_back(e.first, v); } return o; }
+    static bool isconst(const Lin &x) { return x.empty() || (x.size() == 1 && x[0].first == -1); }
+    E constof(const Lin &x) const { return x.empty() ? f.zero() : x[0].second; }
+    const std::string &peek() const { static const std::string none; return pos < tk.size() ? tk[pos] : none; }
+    Lin expr() {
+        bool neg = false;
+        if (peek() == "+" || peek() == "-") { neg = tk[pos++] == "-"; }
+        Lin acc = term(); if (neg) acc = scale(acc, f.mone());
+        while (peek() == "+" || peek() == "-") { bool mi = tk[pos++] == "-"; acc = axpy(acc, term(), mi); }
+        return acc;
+    }
+    Lin term() {
+        Lin acc = factor();
+        while (peek() == "*" || peek() == "/") {
+            bool dv = tk[pos++] == "/"; Lin r = factor();
+            if (dv) { if (!isconst(r)) throw std::runtime_error("SLP: division by a non-constant"); acc = scale(acc, f.inv(constof(r))); }
+            else if (isconst(r)) acc = scale(acc, constof(r));
+            else if (isconst(acc)) acc = scale(r, constof(acc));
+            else throw std::runtime_error("SLP: non-linear product");
+        }
+        return acc;
+    }
+    Lin factor() {
+        if (pos >= tk.size()) throw std::runtime_error("SLP: unexpected end of line");
+        std::string t = tk[pos++];
+        if (t == "(") { Lin v = expr(); if (peek() != ")") throw std::runtime_error("SLP: missing )"); ++pos; return v; }
+        if (t == "-") return scale(factor(), f.mone());
+        if (isdigit((unsigned char)t[0])) { E c = f.fromInt(std::stoll(t)); Lin v; if (!f.isZero(c)) v.emplace_back(-1, c); return v; }
+        auto it = vars.find(t);
+        if (it != vars.end()) return it->second;
+        if (t[0] == 'i' && t.size() > 1 && isdigit((unsigned char)t[1])) { Lin v; v.emplace_back(std::stol(t.substr(1)), f.one()); return v; }
+        throw std::runtime_error("SLP: undefined variable " + t);
+    }
+public:
+    explicit SlpEval(const F &ff) : f(ff) {}
+    static std::vector<std::string> tokenize(const std::string &line) {
+        std::vector<std::string> out; size_t i = 0;
+        while (i < line.size()) {
+            char c = line[i];
+            if (isspace((unsigned char)c)) { ++i; continue; }
+            if (c == ':' && i + 1 < line.size() && line[i + 1] == '=') { out.emplace_back(":="); i += 2; continue; }
+            if (isalpha((unsigned char)c) || c == '_') { size_t j = i; while (j < line.size() && (isalnum((unsigned char)line[j]) || line[j] == '_')) ++j; out.push_back(line.substr(i, j - i)); i = j; continue; }
+            if (isdigit((unsigned char)c)) { size_t j = i; while (j < line.size() && isdigit((unsigned char)line[j])) ++j; out.push_back(line.substr(i, j - i)); i = j; continue; }
+            out.emplace_back(1, c); ++i;
+        }
+        return out;
+    }
+    // returns (adds, muls) with lineOperations semantics (plinopt_programs.inl:116-133)
+    std::pair<size_t, size_t> run(std::istream &in) {
+        std::string line; size_t adds = 0, muls = 0;
+        while (std::getline(in, line)) {
+            auto h = line.find('#'); if (h != std::string::npos) line.resize(h);
+            if (line.find(":=") == std::string::npos) continue;
+            tk = tokenize(line); pos = 0;
+            if (tk.size() < 3 || tk[1] != ":=") throw std::runtime_error("SLP: bad line: " + line);
+            // op count: a sign right after := or ( is a negation; a/b with both natural is one constant
+            bool negator = false;
+            for (size_t k = 0; k < tk.size(); ++k) {
+                const std::string &w = tk[k];
+                bool ratl = w == "/" && k > 0 && k + 1 < tk.size() && isdigit((unsigned char)tk[k - 1][0]) && isdigit((unsigned char)tk[k + 1][0]);
+                if ((w == "+" || w == "-") && !negator) ++adds;
+                else if ((w == "*" || w == "/") && !ratl) ++muls;
+                negator = (w == ":=" || w == "(");
+            }
+            std::string lhs = tk[0]; pos = 2;
+            Lin v = expr();
+            if (pos < tk.size() && peek() != ";") throw std::runtime_error("SLP: trailing tokens in: " + line);   // a missing final ; is tolerated, as by programParser
+            vars[lhs] = std::move(v);
+        }
+        return {adds, muls};
+    }
+    // outputs `o#` as a matrix (rows = outputs, cols = inputs); dimensions cover what is used
+    SparseMat<E> matrix(char outchar = 'o', size_t minrows = 0, size_t mincols = 0) const {
+        size_t m = minrows, n = mincols;
+        for (auto &kv : vars) if (kv.first[0] == outchar && kv.first.size() > 1 && isdigit((unsigned char)kv.first[1])) {
+            m = std::max(m, (size_t)std::stoul(kv.first.substr(1)) + 1);
+            for (auto &e : kv.second) { if (e.first < 0) throw std::runtime_error("SLP: constant term in output " + kv.first); n = std::max(n, (size_t)e.first + 1); }
+        }
+        SparseMat<E> A(m, n);
+        for (auto &kv : vars) if (kv.first[0] == outchar && kv.first.size() > 1 && isdigit((unsigned char)kv.first[1])) {
+            auto &row = A.rows[std::stoul(kv.first.substr(1))];
+            for (auto &e : kv.second) row.emplace_back((size_t)e.first, e.second);
+        }
+        return A;
+    }
+};
+
+template <class F, class E> bool same_matrix(const F &f, const SparseMat<E> &A, const SparseMat<E> &B) {
+    size_t m = std::max(A.rowdim(), B.rowdim());
+    static const typename SparseMat<E>::Row empty;
+    for (size_t i = 0; i < m; ++i) {
+        const auto &a = i < A.rowdim() ? A.rows[i] : empty; const auto &b = i < B.rowdim() ? B.rows[i] : empty;
+        if (a.size() != b.size()) return false;
+        for (size_t k = 0; k < a.size(); ++k) if (a[k].first != b[k].first || !(a[k].second == b[k].second)) return false;
+    }
+    (void)f; return true;
+}
+
+// ---------------------------------------------------------------------- replay
+// Per-candidate random stream (include/plinopt_hip.h): GivRandom LCG seeded per candidate.
+struct CandRng {
+    uint32_t s;
+    explicit CandRng(uint64_t seed) {
+        uint64_t x = seed + 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
+        s = 1u + (uint32_t)(x % 2147483646ull);
+    }
+    uint32_t next() { s = (uint32_t)((950706376ull * (uint64_t)s) % 2147483647ull); return s; }
+};
+
+// Text-emitting restatement of Optimizer() for one seed.  Structured around the
+// same containers the reference uses (ordered map of pair triples) because the
+// order of that map IS the tie-break order.
+template <class F> class Replay {
+    using E = typename F::Elt;
+    using Mat = SparseMat<E>;
+    struct Tri { size_t a, b; E r; };
+    struct TriLess {
+        const F *f;
+        bool operator()(const Tri &x, const Tri &y) const {
+            if (x.a != y.a) return x.a < y.a;
+            if (x.b != y.b) return x.b < y.b;
+            return f->less(x.r, y.r);
+        }
+    };
+    struct Mult { size_t idx, col; E val; };
+    const F &f; Mat M; CandRng rng; std::ostream &out;
+    char ouv, tev, rav;
+    std::vector<Mult> multiples;
+    size_t nbadd = 0, nbmul = 0;
+
+    bool eq(const Tri &x, const Tri &y) const { return x.a == y.a && x.b == y.b && x.r == y.r; }
+    std::vector<Tri> listpairs(const typename Mat::Row &row) const {      // :30-41
+        std::vector<Tri> v;
+        for (size_t x = 0; x < row.size(); ++x) for (size_t y = x + 1; y < row.size(); ++y)
+            v.push_back(Tri{row[x].first, row[y].first, f.div(row[y].second, row[x].second)});
+        return v;
+    }
+    bool find_mult(size_t col, const E &v, size_t &idx) const {
+        for (auto &mm : multiples) if (mm.col == col && mm.val == v) { idx = mm.idx; return true; }
+        return false;
+    }
+    void rem_one_cse(const Tri &cse, std::vector<std::vector<Tri>> &AP, std::map<Tri, size_t, TriLess> &PM) {   // :60-194
+        size_t lm = M.ncols, c0 = 0, c1 = 0;
+        for (auto &row : M.rows) for (auto &e : row) {
+            if (e.first == cse.a && absOne(f, e.second)) ++c0;
+            if (e.first == cse.b && absOne(f, e.second)) ++c1;
+        }
+        Tri l = cse;
+        if (c0 < c1) l = Tri{cse.b, cse.a, f.inv(cse.r)};
+        for (size_t i = 0; i < M.rowdim(); ++i) {
+            auto &ap = AP[i];
+            if (std::find_if(ap.begin(), ap.end(), [&](const Tri &t) { return eq(t, cse); }) == ap.end()) continue;
+            auto &row = M.rows[i]; E coeff = f.zero();
+            for (auto it = row.begin(); it != row.end(); ++it) if (it->first == l.a) { coeff = it->second; row.erase(it); break; }
+            for (auto it = row.begin(); it != row.end(); ++it) if (it->first == l.b) { row.erase(it); row.emplace_back(lm, coeff); break; }
+            for (auto &t : ap) { auto it = PM.find(t); if (--it->second == 0) PM.erase(it); }
+            std::vector<Tri> nr;
+            for (auto &t : ap) if (t.a != l.a && t.b != l.a && t.a != l.b && t.b != l.b) nr.push_back(t);
+            for (size_t k = 0; k + 1 < row.size(); ++k) nr.push_back(Tri{row[k].first, row.back().first, f.div(row.back().second, row[k].second)});
+            for (auto &t : nr) PM[t]++;
+            ap.swap(nr);
+        }
+        E asgs = f.abs(l.r); size_t rindex = lm;
+        if (!absOne(f, asgs)) {
+            if (!find_mult(l.b, asgs, rindex)) {
+                out << rav << lm << ":="; f.print_mul(out, tev, l.b, asgs, nbmul); out << ";\n";
+                multiples.push_back(Mult{lm, l.b, asgs});
+            }
+        }
+        out << tev << lm << ":=" << tev << l.a << ((f.isMOne(asgs) || f.sign(l.r) < 0) ? '-' : '+');
+        if (absOne(f, asgs)) out << tev << l.b; else out << rav << rindex;
+        out << ";\n";
+        M.ncols = lm + 1;
+    }
+    bool one_sub() {                                                                                    // :209-314
+        std::vector<std::vector<Tri>> AP;
+        for (auto &row : M.rows) AP.push_back(listpairs(row));
+        std::map<Tri, size_t, TriLess> PM(TriLess{&f});
+        for (auto &ap : AP) for (auto &t : ap) PM[t]++;
+        if (PM.empty()) return false;
+        bool good = false;
+        while (!PM.empty()) {
+            size_t maxfrq = 0; std::vector<Tri> mx;
+            for (auto &kv : PM) {
+                if (kv.second == maxfrq) mx.push_back(kv.first);
+                if (kv.second > maxfrq) { maxfrq = kv.second; mx.assign(1, kv.first); }
+            }
+            if (maxfrq <= 1) return good;
+            good = true;
+            Tri cse = mx[0];
+            if (mx.size() > 1) cse = mx[rng.next() % mx.size()];
+            ++nbadd;
+            rem_one_cse(cse, AP, PM);
+        }
+        return true;
+    }
+    std::map<E, size_t, std::function<bool(const E &, const E &)>> histo(const typename Mat::Row &row) const {
+        std::map<E, size_t, std::function<bool(const E &, const E &)>> h([this](const E &x, const E &y) { return f.less(x, y); });
+        for (auto &e : row) h[f.abs(e.second)]++;
+        return h;
+    }
+    void factor_out_columns(Mat &T, size_t j) {                                                          // :318-371
+        if (T.rows[j].empty()) return;
+        auto h = histo(T.rows[j]);
+        for (auto &kv : h) {
+            size_t m = T.rowdim();
+            if (kv.second > 1 && !absOne(f, kv.first)) {
+                size_t rindex = m;
+                if (!find_mult(j, kv.first, rindex)) {
+                    out << rav << m << ":="; f.print_mul(out, tev, j, kv.first, nbmul); out << ";\n";
+                    multiples.push_back(Mult{m, j, kv.first});
+                }
+                out << tev << m << ":=" << rav << rindex << ";\n";
+                T.rows.emplace_back(); ++m;
+                for (size_t k = 0; k < kv.second; ++k) {
+                    auto &row = T.rows[j];
+                    for (auto it = row.begin(); it != row.end(); ++it) if (f.abs(it->second) == kv.first) {
+                        T.rows[m - 1].emplace_back(it->first, f.sign(it->second) >= 0 ? f.one() : f.mone());
+                        row.erase(it); break;
+                    }
+                }
+            }
+        }
+    }
+    void factor_out_rows(Mat &A, size_t i) {                                                             // :375-420
+        if (A.rows[i].empty()) return;
+        auto h = histo(A.rows[i]);
+        size_t m = A.ncols;
+        for (auto &kv : h) {
+            if (kv.second > 1 && !absOne(f, kv.first)) {
+                out << tev << m << ":="; ++m; A.ncols = m;
+                auto &row = A.rows[i];
+                row.emplace_back(m - 1, kv.first);
+                for (auto it = row.begin(); it != row.end(); ++it) if (f.abs(it->second) == kv.first) {
+                    if (f.sign(it->second) < 0) out << '-';
+                    out << tev << it->first; row.erase(it); break;
+                }
+                for (size_t k = 1; k < kv.second; ++k)
+                    for (auto it = row.begin(); it != row.end(); ++it) if (f.abs(it->second) == kv.first) {
+                        ++nbadd; out << (f.sign(it->second) < 0 ? '-' : '+') << tev << it->first; row.erase(it); break;
+                    }
+                out << ";\n";
+            }
+        }
+    }
+    static void set_transpose(Mat &dst, const Mat &src) { dst = transpose(src); }
+    bool triangle(Mat &A, Mat &T, size_t j) {                                                            // :427-507
+        if (T.rows[j].empty()) return false;
+        bool found = false, over;
+        do {
+            over = true;
+            for (size_t it = 0; it < T.rows[j].size(); ++it) {
+                if (absOne(f, T.rows[j][it].second)) continue;
+                for (size_t nx = 0; nx < T.rows[j].size(); ++nx) {
+                    if (nx == it || absOne(f, T.rows[j][nx].second)) continue;
+                    const auto iter = T.rows[j][it], next = T.rows[j][nx];
+                    const size_t i = next.first;
+                    const E quot = f.div(next.second, iter.second);
+                    for (size_t th = 0; th < A.rows[i].size(); ++th) {
+                        const auto &third = A.rows[i][th];
+                        if (third.first == j || absOne(f, third.second)) continue;
+                        if (!absOne(f, f.div(quot, third.second))) continue;
+                        size_t m = T.rowdim(); found = true; over = false;
+                        out << tev << m << ":=";
+                        E ais = f.abs(iter.second);
+                        if (f.sign(iter.second) < 0 || f.isMOne(iter.second)) out << '-';
+                        f.print_mul(out, tev, j, ais, nbmul); out << ";\n";
+                        multiples.push_back(Mult{m, j, iter.second});
+                        T.rows.emplace_back();
+                        T.rows[m].emplace_back(iter.first, f.one());
+                        T.rows[m].emplace_back(next.first, quot);
+                        auto &cj = T.rows[j];
+                        cj.erase(std::remove_if(cj.begin(), cj.end(), [&](const std::pair<size_t, E> &q) {
+                                     return (q.first == iter.first && q.second == iter.second) || (q.first == next.first && q.second == next.second); }), cj.end());
+                        set_transpose(A, T);
+                        factor_out_rows(A, i);
+                        set_transpose(T, A);
+                        break;
+                    }
+                    if (found) break;
+                }
+                if (found) break;
+            }
+        } while (!over);
+        return found;
+    }
+    void program_gen() {                                                                                 // :513-611
+        Mat T = transpose(M);
+        { size_t nc = M.ncols; for (size_t j = 0; j < nc; ++j) factor_out_columns(T, j); }
+        set_transpose(M, T);
+        for (size_t i = 0; i < M.rowdim(); ++i) factor_out_rows(M, i);
+        set_transpose(T, M);
+        for (size_t j = 0; j < M.ncols; ++j) triangle(M, T, j);
+        for (size_t i = 0; i < M.rowdim(); ++i) {
+            const auto &row = M.rows[i];
+            if (row.empty()) { out << ouv << i << ":=0;\n"; continue; }
+            out << ouv << i << ":=";
+            for (size_t k = 0; k < row.size(); ++k) {
+                const auto &e = row[k]; E ais = f.abs(e.second); size_t rindex = 0;
+                if (k > 0) ++nbadd;
+                if (find_mult(e.first, ais, rindex)) {
+                    if (k == 0) { if (!(ais == e.second)) out << '-'; } else out << (ais == e.second ? '+' : '-');
+                    out << rav << rindex;
+                } else {
+                    bool ng = f.sign(e.second) < 0 || f.isMOne(e.second);
+                    if (k == 0) { if (ng) out << '-'; } else out << (ng ? '-' : '+');
+                    f.print_mul(out, tev, e.first, ais, nbmul);
+                }
+            }
+            out << ";\n";
+        }
+    }
+public:
+    Replay(const F &ff, const Mat &A, uint64_t seed, std::ostream &os, char o = 'o', char t = 't', char r = 'r')
+        : f(ff), M(A), rng(seed), out(os), ouv(o), tev(t), rav(r) {}
+    // Optimizer(), include/plinopt_optimize.inl:616-631
+    std::pair<size_t, size_t> optimizer() { while (one_sub()) {} program_gen(); return {nbadd, nbmul}; }
+    // the fallback of OptMethods :1473-1485: ProgramGen on the untouched matrix
+    std::pair<size_t, size_t> direct() { program_gen(); return {nbadd, nbmul}; }
+};
+
+// input2Temps with usage check, plinopt_library.inl:319-331
+template <class E> void input2temps(std::ostream &os, const SparseMat<E> &M, char inv, char tev) {
+    std::vector<char> used(M.coldim(), 0);
+    for (auto &r : M.rows) for (auto &e : r) used[e.first] = 1;
+    for (size_t j = 0; j < M.coldim(); ++j) if (used[j]) os << tev << j << ":=" << inv << j << ";\n";
+}
+
+// cmpOpCount, include/plinopt_optimize.h:53-64 (mode 0 default, 1 OPTIMIZE_ADDITIONS, 2 OPTIMIZE_SUMS)
+inline bool cmp_op_count(std::pair<size_t, size_t> a, std::pair<size_t, size_t> b, int mode = 0) {
+    if (mode == 1) return a.first < b.first || (a.first == b.first && a.second < b.second);
+    if (mode == 2) return a.first + a.second < b.first + b.second;
+    size_t as = a.first + a.second, bs = b.first + b.second;
+    return as < bs || (as == bs && a.first < b.first);
+}
+
+} // namespace plo
+#endif

@@ -102,7 +102,7 @@ class _Parser:
         lhs = self.next()
         assert self.next() == ":=", toks
         val = self.expr()
-        assert self.peek() == ";", toks
+        assert self.peek() in (";", None), toks
         self.vars[lhs] = val
         return lhs
 

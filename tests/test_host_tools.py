@@ -1,0 +1,110 @@
+"""Host tools (C++): bin/optimizer keeps the reference CLI contract (stdout = SLP only,
+'#' lines on stderr), bin/SLPchecker verifies programs; the host replay of a seed is
+text-identical to the CPU oracle's program for the same seed."""
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+from plo_testlib import DATA, ROOT, OracleMatrix
+
+OPT = os.path.join(ROOT, "bin", "optimizer")
+CHK = os.path.join(ROOT, "bin", "SLPchecker")
+P = 131071
+ALL = sorted(os.path.basename(f) for f in glob.glob(os.path.join(DATA, "*.sms")) if "-X_" not in f)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+
+
+def run(cmd, stdin=None):
+    r = subprocess.run(cmd, input=stdin, capture_output=True, text=True, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("name", ["cyclic.sms", "2x2x2_7_Winograd_L.sms", "4x4x4_49_156_L.sms", "2x2x2_7_DPS-accurate_L.sms",
+                                  "4x4x4_48_rational_P.sms", "3o3o6_Toom4_P.sms", "2o2o4_5_Toom3_P.sms"])
+def test_config1_plumbing_over_Q(name):
+    """BASELINE configs[0]: bin/optimizer data/cyclic.sms, single CPU pass; then the
+    reference's own check `optimizer | SLPchecker -M` (bin/FDT.sh:58)."""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, path, "-O", "10"])
+    assert rc == 0, err
+    assert all(re.match(r"^[a-z]\d+:=", ln) for ln in out.strip().splitlines())         # stdout is SLP only
+    assert all(ln.startswith("#") for ln in err.strip().splitlines())                    # stderr is '#' lines
+    m = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
+    assert m and int(m.group(1)) <= int(m.group(2))
+    rc, _, err2 = run([CHK, "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+    # the count printed by the checker (lineOperations) equals the count printed by the optimizer
+    assert int(re.search(r"# \S*?(\d+)\tadditions", err2).group(1)) == int(m.group(1))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_host_replay_text_equals_oracle_text(name):
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    for seed in (0, 3, 12345678901234):
+        a, mu, txt = M.optimizer(seed)
+        rc, out, err = run([OPT, "-q", str(P), "--replay", "--seed", str(seed), path])
+        assert rc == 0, err
+        assert out == txt
+        assert "# %d\tadditions" % a in err and "# %d\tmultiplications" % mu in err
+
+
+def test_mod_p_host_search_matches_oracle_and_verifies():
+    path = os.path.join(DATA, "4x4x4_49_156_L.sms")
+    M = OracleMatrix.from_sms(path, P)
+    rc, out, err = run([OPT, "-q", str(P), "-D", "-O", "300", "--gpu", "0", "--seed", "42", path])
+    assert rc == 0, err
+    a, mu, seed = M.search(42, 300)
+    assert "# Found D: %d|%d" % (a, mu) in err and "[seed %d]" % seed in err
+    assert out == M.optimizer(seed)[2]
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2
+
+
+def test_checker_rejects_a_wrong_program():
+    path = os.path.join(DATA, "2x2x2_7_Winograd_L.sms")
+    good = open(os.path.join(DATA, "2x2x2_7_Winograd_L.slp")).read()
+    assert run([CHK, "-M", path], stdin=good)[0] == 0
+    bad = good.replace("o1:=i3+o0;", "o1:=i3-o0;")
+    rc, _, err = run([CHK, "-M", path], stdin=bad)
+    assert rc == 1 and "ERROR" in err
+
+
+def test_regenerates_32x32x32_matrix_from_its_slp():
+    """data/32x32x32_15096_L.sms is absent upstream (.MISSING_LARGE_BLOBS); the reference rule
+    (Makefile:79-80) rebuilds it from the stored SLP.  Sizes: SURVEY.md 8a."""
+    rc, out, err = run([CHK, os.path.join(DATA, "32x32x32_15096_L.slp")])
+    assert rc == 0
+    lines = out.splitlines()
+    assert lines[0].split()[:2] == ["15096", "1024"]
+    assert len(lines) - 2 == 1257376
+    assert "34750\tadditions" in err
+    vals = {}
+    for ln in lines[1:-1]:
+        v = ln.split()[2]
+        vals[v] = vals.get(v, 0) + 1
+    assert vals["1/17"] + vals["-1/17"] == 1052576
+
+
+def test_stored_slps_verify_against_their_matrices():
+    """GDT-style sanity on the data pairs (data/Makefile:37-38)."""
+    n = 0
+    for slp in sorted(glob.glob(os.path.join(DATA, "*.slp"))):
+        sms = slp[:-4] + ".sms"
+        if "32x32x32" in slp or "-X_" in slp or not os.path.exists(sms):
+            continue
+        rc, _, err = run([CHK, "-M", sms, slp])
+        if rc != 0:      # algorithms over F_32 / F_243 (characteristic 2 / 3) only verify modulo their characteristic
+            q = "2" if ("F32" in slp or "S32" in slp) else "3" if ("F243" in slp or "S243" in slp) else None
+            assert q, (slp, err)
+            rc, _, err = run([CHK, "-q", q, "-M", sms, slp])
+        assert rc == 0 and "SUCCESS" in err, (slp, err)
+        n += 1
+    assert n >= 50
