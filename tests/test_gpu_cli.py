@@ -1,0 +1,52 @@
+"""End to end through the reference CLI contract on the GPU: BASELINE configs[1]
+`bin/optimizer -q 131071 -D -O 1000000 data/2x2x2_7_Winograd_L.sms`, then the reference's own
+verification pipeline (`| SLPchecker -q -M`, bin/FDT.sh:58-60)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from plo_testlib import DATA, ROOT, OracleMatrix
+
+pytestmark = pytest.mark.gpu
+OPT = os.path.join(ROOT, "bin", "optimizer")
+CHK = os.path.join(ROOT, "bin", "SLPchecker")
+P = 131071
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+
+
+def run(cmd, stdin=None):
+    r = subprocess.run(cmd, input=stdin, capture_output=True, text=True, timeout=600)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("name,loops,bound", [
+    ("2x2x2_7_Winograd_L.sms", 1000000, 4),          # configs[1]: 10^6 restarts, known optimum 4 adds
+    ("4x4x4_49_156_L.sms", 300000, None),
+    ("2x2x2_7_DPS-accurate_L.sms", 50000, None),     # rational coefficients: multiplications counted
+])
+def test_optimizer_cli_on_gpu(name, loops, bound):
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "-q", str(P), "-D", "-O", str(loops), path])
+    assert rc == 0, err
+    m = re.search(r"# Found D: (\d+)\|(\d+) instead of (\d+)\|(\d+)\t\[seed (\d+)\]", err)
+    assert m, err
+    a, mu, seed = int(m.group(1)), int(m.group(2)), int(m.group(5))
+    if bound is not None:
+        assert (a, mu) == (bound, 0)
+    M = OracleMatrix.from_sms(path, P)
+    oa, om, otxt = M.optimizer(seed)
+    assert (oa, om) == (a, mu)
+    assert out == otxt                                  # identical emitted SLP for the winning seed
+    sample = min(loops, 20000)                          # the winner is at least as good as any sampled seed
+    sa, sm, sseed = M.search(0, sample, nthreads=8)
+    assert (a + mu, a) <= (sa + sm, sa)
+    if (a, mu) == (sa, sm):
+        assert seed <= sseed
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
