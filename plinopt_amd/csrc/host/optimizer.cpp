@@ -11,9 +11,11 @@
 // in the reference.  A failing GPU call is fatal: there is no silent fallback.
 // ===========================================================================
 #include "plo_host.hpp"
+#include "plo_fast.hpp"
 #include "../../../include/plinopt_hip.h"
 
 #include <chrono>
+#include <memory>
 #include <dlfcn.h>
 #include <libgen.h>
 #include <unistd.h>
@@ -47,9 +49,27 @@ struct HipLib {
     }
 };
 
+int g_engine = 0;   // 0 auto (scalable engine over Z_p), 1 literal std::map replay, 2 scalable engine
+
 template <class F> std::string replay_text(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed, Ops &ops) {
     std::ostringstream os;
     input2temps(os, lM, 'i', 't');                          // plinopt_optimize.inl:1211
+    if constexpr (std::is_same<F, ZpField>::value) {
+        if (g_engine != 1) {
+            auto t0 = std::chrono::steady_clock::now();
+            SharedIndex S(f, lM);
+            auto t1 = std::chrono::steady_clock::now();
+            FastCand C(S, seed, &os, 'o', 't', 'r');
+            ops = C.optimizer();
+            auto t2 = std::chrono::steady_clock::now();
+            if (g_engine == 2) std::clog << "# engine: index " << std::chrono::duration<double>(t1 - t0).count() << " s, candidate " << std::chrono::duration<double>(t2 - t1).count()
+                << " s; decs " << C.st.decs << ", fresh pairs " << C.st.fresh_inst << " (" << C.st.fresh_distinct << " distinct), level rebuilds " << C.st.rebuilds
+                << " (scanned " << C.st.rebuild_scan << "), select scanned " << C.st.select_scan << ", candidate rows " << C.st.cand_rows << ", affected rows " << C.st.aff_rows
+                << ", top frequency " << C.st.max_level0 << ", nnz at ProgramGen " << C.st.live_nnz_end << ", columns " << C.st.cols_end << std::endl;
+            if (g_engine == 2) std::clog << "# engine: scalable, " << C.steps() << " CSE steps, " << S.keys.size() << " initial triples, " << S.pairs0 << " pair instances" << std::endl;
+            return os.str();
+        }
+    }
     Replay<F> R(f, lM, seed, os, 'o', 't', 'r');
     ops = R.optimizer();                                    // :1212
     return os.str();
@@ -58,11 +78,13 @@ template <class F> std::string replay_text(const F &f, const SparseMat<typename 
 // host restart loop (rationals, or --gpu 0): candidates seed0..seed0+loops-1, total order (cmpOpCount, seed)
 template <class F> bool host_search(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, Ops &best, uint64_t &bseed) {
     bool have = false;
+    std::unique_ptr<SharedIndex> S;
+    if constexpr (std::is_same<F, ZpField>::value) if (g_engine != 1) S.reset(new SharedIndex(f, lM));
 #pragma omp parallel for schedule(dynamic)
     for (long long k = 0; k < (long long)loops; ++k) {
         std::ostringstream sink; Ops ops;
-        Replay<F> R(f, lM, seed0 + (uint64_t)k, sink, 'o', 't', 'r');
-        ops = R.optimizer();
+        if (S) { FastCand C(*S, seed0 + (uint64_t)k); ops = C.optimizer(); }
+        else { Replay<F> R(f, lM, seed0 + (uint64_t)k, sink, 'o', 't', 'r'); ops = R.optimizer(); }
 #pragma omp critical
         {
             uint64_t s = seed0 + (uint64_t)k;
@@ -166,6 +188,7 @@ int main(int argc, char **argv)
         else if (a == "-O" && i + 1 < argc) loops = strtoull(argv[++i], nullptr, 10);
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
+        else if (a == "--engine" && i + 1 < argc) { std::string e(argv[++i]); g_engine = e == "literal" ? 1 : e == "fast" ? 2 : 0; }
         else if (a == "--replay") replay_only = true;    // print the program of candidate --seed, no search
         else filename = a;
     }

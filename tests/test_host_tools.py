@@ -108,3 +108,25 @@ def test_stored_slps_verify_against_their_matrices():
         assert rc == 0 and "SUCCESS" in err, (slp, err)
         n += 1
     assert n >= 50
+
+
+@pytest.mark.parametrize("engine", ["literal", "fast"])
+def test_both_host_engines_on_synthetic_triangle_cases(engine, tmp_path):
+    """The scalable engine (plo_fast.hpp) and the literal replay must print the oracle's text on
+    matrices that exercise FactorOutColumns/Rows and Triangle (incl. its never-reset `found`)."""
+    import synth
+    for s in range(120):
+        m, n, rows = synth.small_valued(s, P)
+        rp, c, v = synth.to_csr(rows, P)
+        M = OracleMatrix(m, n, rp, c, v, P)
+        path = tmp_path / ("s%d.sms" % s)
+        with open(path, "w") as fh:
+            fh.write("%d %d M\n" % (m, n))
+            for i in range(m):
+                for k in range(rp[i], rp[i + 1]):
+                    fh.write("%d %d %d\n" % (i + 1, c[k] + 1, v[k]))
+            fh.write("0 0 0\n")
+        a, mu, txt = M.optimizer(s)
+        rc, out, err = run([OPT, "-q", str(P), "--replay", "--seed", str(s), "--engine", engine, str(path)])
+        assert rc == 0, err
+        assert out == txt, (s, rows)
