@@ -73,6 +73,12 @@ int plo_device_count(void);
 /* Upload one matrix (replaces the per-restart copies `FMatrix lM(M,F), lT(T,F)`
  * of include/plinopt_optimize.inl:1206-1207: the matrix is converted once). */
 int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **plan);
+/* flags: PLO_PLAN_HBM forces the HBM-resident kernel family (one workgroup per candidate,
+ * plo_cse_big.hip) that plo_cse_plan_create selects by itself when a candidate does not fit LDS. */
+#define PLO_PLAN_HBM 1u
+int plo_cse_plan_create_ex(const plo_csr_t *A, uint32_t p, uint32_t flags, plo_plan_t **plan);
+/* 1 if the plan runs on the HBM-resident kernel family, 0 for the LDS-resident wave kernel */
+int plo_cse_plan_is_hbm(const plo_plan_t *plan);
 int plo_cse_plan_destroy(plo_plan_t *plan);
 
 /* Replaces the body of `#pragma omp parallel for` in CSEOptimiser,

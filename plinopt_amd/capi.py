@@ -12,11 +12,12 @@ LIB_PATH = os.path.join(_HERE, "libplinopt_hip.so")
 PLO_OK = 0
 PLO_E_ARG, PLO_E_HIP, PLO_E_CAPACITY, PLO_E_UNSUPPORTED, PLO_E_INTERNAL = -1, -2, -3, -4, -5
 COST_SUM_THEN_ADD, COST_ADD_THEN_MUL, COST_SUM = 0, 1, 2
+PLAN_HBM = 1
 
 # every symbol include/plinopt_hip.h declares
 EXPORTS = [
     "plo_init", "plo_shutdown", "plo_last_error", "plo_device_count",
-    "plo_cse_plan_create", "plo_cse_plan_destroy",
+    "plo_cse_plan_create", "plo_cse_plan_create_ex", "plo_cse_plan_is_hbm", "plo_cse_plan_destroy",
     "plo_cse_search_plan", "plo_cse_search",
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_pack_cost",
@@ -71,6 +72,9 @@ def lib():
         L.plo_last_error.restype = ctypes.c_char_p
         L.plo_init.argtypes = [ctypes.c_int]
         L.plo_cse_plan_create.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_cse_plan_create_ex.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_cse_plan_is_hbm.argtypes = [ctypes.c_void_p]
         L.plo_cse_plan_destroy.argtypes = [ctypes.c_void_p]
         L.plo_cse_search_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
                                           ctypes.POINTER(Best), ctypes.POINTER(Stats)]

@@ -65,7 +65,7 @@ template <class F> std::string replay_text(const F &f, const SparseMat<typename 
             if (g_engine == 2) std::clog << "# engine: index " << std::chrono::duration<double>(t1 - t0).count() << " s, candidate " << std::chrono::duration<double>(t2 - t1).count()
                 << " s; decs " << C.st.decs << ", fresh pairs " << C.st.fresh_inst << " (" << C.st.fresh_distinct << " distinct), level rebuilds " << C.st.rebuilds
                 << " (scanned " << C.st.rebuild_scan << "), select scanned " << C.st.select_scan << ", candidate rows " << C.st.cand_rows << ", affected rows " << C.st.aff_rows
-                << ", top frequency " << C.st.max_level0 << ", nnz at ProgramGen " << C.st.live_nnz_end << ", columns " << C.st.cols_end << std::endl;
+                << ", top frequency " << C.st.max_level0 << ", nnz at ProgramGen " << C.st.live_nnz_end << ", columns " << C.st.cols_end << ", sum of tie-set sizes " << C.st.sum_T << " (max " << C.st.max_T << "), steps at level 2: " << C.st.steps_l2 << " (sum T " << C.st.sum_T_l2 << "), steps at level<=4: " << C.st.steps_le4 << ", largest fresh batch " << C.st.max_fresh << std::endl;
             if (g_engine == 2) std::clog << "# engine: scalable, " << C.steps() << " CSE steps, " << S.keys.size() << " initial triples, " << S.pairs0 << " pair instances" << std::endl;
             return os.str();
         }

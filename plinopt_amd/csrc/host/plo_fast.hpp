@@ -94,7 +94,7 @@ class FastCand {
     std::unordered_map<MKey, size_t, MHash> multiples;   // (column, value) -> first variable index
     size_t nbadd = 0, nbmul = 0, steps_ = 0;
 public:
-    struct Stats { uint64_t decs = 0, fresh_inst = 0, fresh_distinct = 0, rebuilds = 0, rebuild_scan = 0, select_scan = 0, aff_rows = 0, cand_rows = 0, max_level0 = 0, live_nnz_end = 0, cols_end = 0; } st;
+    struct Stats { uint64_t decs = 0, fresh_inst = 0, fresh_distinct = 0, rebuilds = 0, rebuild_scan = 0, select_scan = 0, aff_rows = 0, cand_rows = 0, max_level0 = 0, live_nnz_end = 0, cols_end = 0, sum_T = 0, max_T = 0, steps_l2 = 0, sum_T_l2 = 0, steps_le4 = 0, max_fresh = 0, live_keys_max = 0; } st;
 private:
 
     void emit_mul(char c, size_t i, uint32_t e) { if (out) { *out << c << i; } if (!absOne(f, e)) { ++nbmul; if (out) *out << '*' << e; } }
@@ -190,7 +190,7 @@ private:
         }
         colrows[lm] = aff;
         std::sort(fresh.begin(), fresh.end());
-        st.fresh_inst += fresh.size();
+        st.fresh_inst += fresh.size(); if (fresh.size() > st.max_fresh) st.max_fresh = fresh.size();
         for (size_t k = 0; k < fresh.size();) {                        // PairMap[newrow]++ (:140-142)
             ++st.fresh_distinct;
             size_t j = k; while (j < fresh.size() && fresh[j] == fresh[k]) ++j;
@@ -394,6 +394,7 @@ public:
             while (M >= 2 && hist[M] == 0) { --M; if (M >= 2 && hist[M]) rebuild_level(); }
             if (M <= 1) break;                                         // :255
             const uint64_t Tn = hist[M];
+            st.sum_T += Tn; if (Tn > st.max_T) st.max_T = Tn; if (M == 2) { st.steps_l2++; st.sum_T_l2 += Tn; } if (M <= 4) st.steps_le4++;
             uint64_t k = 0;
             if (Tn > 1) k = rng.next() % Tn;                           // :260-265
             uint32_t a, b, r; select(k, a, b, r);

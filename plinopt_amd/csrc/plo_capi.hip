@@ -9,6 +9,7 @@
 // entry point fails with PLO_E_HIP.
 // ===========================================================================
 #include "plo_cse_wave.hip"
+#include "plo_cse_big.hip"
 #include "../../include/plinopt_hip.h"
 
 #include <algorithm>
@@ -53,6 +54,13 @@ struct plo_plan {
     std::vector<uint32_t> rowptr, col, val;
     uint32_t m = 0, n = 0;
     uint32_t cap_scale = 2;
+    // HBM-resident variant (one workgroup per candidate)
+    bool big = false;
+    plo::BigPlan B{};
+    std::vector<void *> big_bufs;          // shared immutable device buffers
+    void *d_ws = nullptr; uint64_t ws_slices = 0;
+    unsigned long long *d_next = nullptr; uint32_t *d_stats = nullptr;
+    uint32_t big_lds = 0;
 };
 
 namespace {
@@ -166,6 +174,148 @@ int build_plan(plo_plan *pl)
     return PLO_OK;
 }
 
+
+template <class T> int upload(plo_plan *pl, const std::vector<T> &v, const T **dst)
+{
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    pl->big_bufs.push_back(d);
+    *dst = (const T *)d;
+    return PLO_OK;
+}
+
+// Plan for the HBM-resident kernel family (plo_cse_big.hip)
+int build_big_plan(plo_plan *pl)
+{
+    const uint32_t m = pl->m, n = pl->n, p = pl->p;
+    const auto &rowptr = pl->rowptr; const auto &col = pl->col; const auto &val = pl->val;
+    const uint32_t nnz = rowptr[m];
+    plo::BigPlan &B = pl->B; B = plo::BigPlan{};
+    if (m == 0) return fail(PLO_E_CAPACITY, "empty matrix");
+    uint32_t maxlen = 1, naive = 0; bool unit = true;
+    for (uint32_t i = 0; i < m; ++i) { uint32_t l = rowptr[i + 1] - rowptr[i]; maxlen = std::max(maxlen, l); if (l > 1) naive += l - 1; }
+    for (uint32_t k = 0; k < nnz; ++k) unit = unit && (val[k] == 1u || val[k] == p - 1);
+    const uint32_t rb = ceil_log2(p);
+    if (rb > 30 || (48u - rb) / 2u < 2u) return fail(PLO_E_CAPACITY, "modulus too large for the 48-bit pair key");
+    const uint32_t bbmax = (48u - rb) / 2u;
+    uint64_t NC = (uint64_t)n + naive / 2 + 2;
+    if (n + 2ull > (1ull << bbmax)) return fail(PLO_E_CAPACITY, "too many columns for the 48-bit pair key");
+    NC = std::min<uint64_t>(NC, 1ull << bbmax);            // exceeding it at run time is reported by the device (BERR_COLS)
+    const uint32_t bb = ceil_log2((uint32_t)NC);
+    if (m >= 0x7FFFu) return fail(PLO_E_CAPACITY, "more than 32766 rows: frequency does not fit the table slot");
+    if (maxlen > 8192) return fail(PLO_E_CAPACITY, "row longer than 8192 entries");
+
+    std::vector<uint32_t> inv(nnz), tptr(n + 1, 0), trows(nnz), ucount(n, 0);
+    for (uint32_t k = 0; k < nnz; ++k) { inv[k] = inv_mod(val[k], p); ++tptr[col[k] + 1]; if (val[k] == 1u || val[k] == p - 1) ++ucount[col[k]]; }
+    for (uint32_t c = 0; c < n; ++c) tptr[c + 1] += tptr[c];
+    { std::vector<uint32_t> pos(tptr.begin(), tptr.end() - 1);
+      for (uint32_t i = 0; i < m; ++i) for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) trows[pos[col[k]]++] = i; }
+    // distinct pair triples, per first column (listpairs :30-41, PairMap :220-225)
+    std::vector<uint64_t> keys; std::vector<uint32_t> cnts; uint64_t pairs0 = 0; uint32_t maxf = 0;
+    {
+        std::vector<uint64_t> tmp;
+        for (uint32_t a = 0; a < n; ++a) {
+            tmp.clear();
+            for (uint32_t q = tptr[a]; q < tptr[a + 1]; ++q) {
+                const uint32_t i = trows[q]; uint32_t x = rowptr[i];
+                while (col[x] != a) ++x;
+                for (uint32_t y = x + 1; y < rowptr[i + 1]; ++y)
+                    tmp.push_back(((uint64_t)a << (bb + rb)) | ((uint64_t)col[y] << rb) | (uint32_t)((uint64_t)val[y] * inv[x] % p));
+            }
+            pairs0 += tmp.size();
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t k = 0; k < tmp.size();) {
+                size_t j = k; while (j < tmp.size() && tmp[j] == tmp[k]) ++j;
+                keys.push_back(tmp[k]); cnts.push_back((uint32_t)(j - k)); maxf = std::max(maxf, (uint32_t)(j - k)); k = j;
+            }
+        }
+    }
+    pl->pairs0 = pairs0; pl->distinct0 = keys.size();
+    pl->algo_bytes = 8ull * nnz + 16ull * keys.size();       // distinct-triple form of B_cand for HBM-resident candidates
+    const uint32_t multcap = (uint32_t)std::min<uint64_t>((uint64_t)naive / 2 + 8, NC);
+    uint64_t cap = 1024;
+    while (cap < 2ull * keys.size() + 1024ull || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;
+    const uint32_t hbits = ceil_log2((uint32_t)std::min<uint64_t>(cap, 1ull << 31));
+    if (cap > (1ull << 30)) return fail(PLO_E_CAPACITY, "pair table above 2^30 slots");
+    std::vector<uint64_t> tab(cap, PLO_GEMPTY);
+    std::vector<uint32_t> hist(maxf + 2, 0);
+    for (size_t k = 0; k < keys.size(); ++k) {
+        uint32_t s = (uint32_t)((keys[k] * 0x9E3779B97F4A7C15ull) >> (64u - hbits));       // == plo::ghash
+        while (tab[s] != PLO_GEMPTY) s = (s + 1) & (uint32_t)(cap - 1);
+        tab[s] = (keys[k] << PLO_GVB) | cnts[k];
+        ++hist[cnts[k]];
+    }
+    B.m = m; B.n = n; B.nnz = nnz; B.p = p; B.NCmax = (uint32_t)NC; B.hbits = hbits; B.rb = rb; B.bb = bb; B.unit = unit ? 1u : 0u;
+    B.maxf0 = maxf + 1; B.M0 = maxf; B.multcap = multcap; B.scr_stride = maxlen;
+    B.dmcap = (uint32_t)std::min<uint64_t>(1u << 20, cap); B.hlcap = (uint32_t)std::min<uint64_t>(1u << 21, cap);
+    B.mu = (~0ull) / p;
+    int rc;
+    if ((rc = upload(pl, pl->rowptr, &B.rs)) || (rc = upload(pl, pl->col, &B.col0)) || (rc = upload(pl, pl->val, &B.val0)) ||
+        (rc = upload(pl, inv, &B.inv0)) || (rc = upload(pl, tptr, &B.tptr)) || (rc = upload(pl, trows, &B.trows)) ||
+        (rc = upload(pl, ucount, &B.ucount0)) || (rc = upload(pl, hist, &B.hist0)) || (rc = upload(pl, tab, &B.tab0))) return rc;
+    // workspace layout of one candidate
+    uint64_t off = 0;
+    auto take = [&](uint64_t bytes) { uint64_t o = off; off = (off + bytes + 255) & ~255ull; return o; };
+    B.o_tab = take(cap * 8); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
+    B.o_len = take((uint64_t)m * 4); B.o_ucount = take(NC * 4); B.o_cntM = take(NC * 4);
+    B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 8); B.o_aff = take((uint64_t)m * 4);
+    B.o_ncrptr = take((NC + 2) * 4); B.o_ncr = take(((uint64_t)nnz + 64) * 4);
+    B.o_multc = take((uint64_t)multcap * 4); B.o_multv = take((uint64_t)multcap * 4);
+    B.o_tcnt = take(NC * 4); B.o_tptr2 = take((NC + 2) * 4); B.o_tlist = take(((uint64_t)nnz + 64) * 4); B.o_cols2 = take(NC * 4);
+    B.ws_stride = off;
+    pl->big_lds = (((B.maxf0 + 2u) & ~1u) + (PLO_BIG_THREADS / 64) * maxlen) * 4u;
+    if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
+    HIPCHK(hipFuncSetAttribute((const void *)plo::cse_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
+    if (!pl->d_err) HIPCHK(hipMalloc((void **)&pl->d_err, sizeof(uint32_t)));
+    if (!pl->d_best) HIPCHK(hipMalloc((void **)&pl->d_best, sizeof(unsigned long long)));
+    if (!pl->d_next) HIPCHK(hipMalloc((void **)&pl->d_next, sizeof(unsigned long long)));
+    if (!pl->d_stats) HIPCHK(hipMalloc((void **)&pl->d_stats, 16 * sizeof(uint32_t)));
+    pl->big = true; pl->waves_per_wg = PLO_BIG_THREADS / 64; pl->lds_bytes = pl->big_lds + (uint32_t)sizeof(plo::BigShared);
+    return PLO_OK;
+}
+
+// launch of the HBM-resident kernel over J.ncand candidates
+int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
+{
+    // one workspace slice per resident workgroup
+    uint64_t want = std::min<uint64_t>(J.ncand, (uint64_t)g_cus * 4);
+    if (const char *e = getenv("PLO_BIG_SLICES")) want = std::min<uint64_t>(want, strtoull(e, nullptr, 10));
+    if (want == 0) want = 1;
+    if (pl->ws_slices < want) {
+        if (pl->d_ws) { (void)hipFree(pl->d_ws); pl->d_ws = nullptr; pl->ws_slices = 0; }
+        size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
+        uint64_t fit = (uint64_t)(fr * 0.85) / pl->B.ws_stride;
+        if (fit == 0) return fail(PLO_E_CAPACITY, "not enough HBM for one candidate workspace");
+        want = std::min(want, fit);
+        HIPCHK(hipMalloc(&pl->d_ws, want * pl->B.ws_stride));
+        pl->ws_slices = want;
+    }
+    const uint64_t grid = std::min<uint64_t>(pl->ws_slices, want);
+    pl->B.ws = (uint8_t *)pl->d_ws;
+    HIPCHK(hipMemsetAsync(pl->d_err, 0, sizeof(uint32_t), g_stream));
+    HIPCHK(hipMemsetAsync(pl->d_next, 0, sizeof(unsigned long long), g_stream));
+    J.err = pl->d_err; J.next = pl->d_next; J.stats = pl->d_stats;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g_stream));
+    hipLaunchKernelGGL(plo::cse_big_kernel, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, g_stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = pl->waves_per_wg; st->algo_bytes = pl->algo_bytes; }
+    if (err) {
+        static const char *names[] = {"pair table", "frequency/row-count mismatch", "column bound", "level list", "window list", "multiplier list", "tie selection", "ProgramGen"};
+        return fail(err == plo::BERR_COLS || err == plo::BERR_DM || err == plo::BERR_HL ? PLO_E_CAPACITY : PLO_E_INTERNAL,
+                    std::string("device (HBM variant): ") + (err >= 11 && err <= 18 ? names[err - 11] : "unknown") + " error " + std::to_string(err));
+    }
+    return PLO_OK;
+}
+
 // one launch over [first, first+count) candidates of a job
 int launch(plo_plan *pl, plo::WaveJob J, plo_stats_t *st, float *ms_out)
 {
@@ -252,7 +402,7 @@ int plo_shutdown(void)
     return PLO_OK;
 }
 
-int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **out)
+int plo_cse_plan_create_ex(const plo_csr_t *A, uint32_t p, uint32_t flags, plo_plan_t **out)
 {
     if (!A || !out || !A->rowptr || (A->rowptr[A->m] && (!A->col || !A->val))) return fail(PLO_E_ARG, "null argument");
     if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
@@ -270,11 +420,16 @@ int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **out)
     pl->rowptr.assign(A->rowptr, A->rowptr + A->m + 1);
     pl->col.assign(A->col, A->col + A->rowptr[A->m]);
     pl->val.assign(A->val, A->val + A->rowptr[A->m]);
-    int rc = build_plan(pl);
+    int rc = (flags & PLO_PLAN_HBM) ? PLO_E_CAPACITY : build_plan(pl);
+    if (rc == PLO_E_CAPACITY) rc = build_big_plan(pl);       // does not fit LDS: HBM-resident kernel family
     if (rc != PLO_OK) { plo_cse_plan_destroy(pl); return rc; }
     *out = pl;
     return PLO_OK;
 }
+
+int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **out) { return plo_cse_plan_create_ex(A, p, 0u, out); }
+
+int plo_cse_plan_is_hbm(const plo_plan_t *pl) { return pl && pl->big ? 1 : 0; }
 
 int plo_cse_plan_destroy(plo_plan_t *pl)
 {
@@ -282,6 +437,10 @@ int plo_cse_plan_destroy(plo_plan_t *pl)
     if (pl->d_tmpl) (void)hipFree(pl->d_tmpl);
     if (pl->d_err) (void)hipFree(pl->d_err);
     if (pl->d_best) (void)hipFree(pl->d_best);
+    for (void *d : pl->big_bufs) (void)hipFree(d);
+    if (pl->d_ws) (void)hipFree(pl->d_ws);
+    if (pl->d_next) (void)hipFree(pl->d_next);
+    if (pl->d_stats) (void)hipFree(pl->d_stats);
     delete pl;
     return PLO_OK;
 }
@@ -309,8 +468,14 @@ int plo_cse_cost_many_plan(plo_plan_t *pl, const uint64_t *seeds, uint64_t seed0
     HIPCHK(hipMalloc((void **)&d_adds, n * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&d_muls, n * sizeof(uint32_t)));
     if (seeds) { HIPCHK(hipMalloc((void **)&d_seeds, n * sizeof(uint64_t))); HIPCHK(hipMemcpy(d_seeds, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice)); }
-    plo::WaveJob J{}; J.seed0 = seed0; J.seeds = d_seeds; J.ncand = n; J.adds = d_adds; J.muls = d_muls; J.best = nullptr; J.cost_mode = 0;
-    int rc = run_job(pl, J, st);
+    int rc;
+    if (pl->big) {
+        plo::BigJob J{}; J.seed0 = seed0; J.seeds = d_seeds; J.ncand = n; J.adds = d_adds; J.muls = d_muls; J.best = nullptr; J.cost_mode = 0;
+        rc = launch_big(pl, J, st);
+    } else {
+        plo::WaveJob J{}; J.seed0 = seed0; J.seeds = d_seeds; J.ncand = n; J.adds = d_adds; J.muls = d_muls; J.best = nullptr; J.cost_mode = 0;
+        rc = run_job(pl, J, st);
+    }
     if (rc == PLO_OK) {
         hipError_t e1 = hipMemcpy(adds, d_adds, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
         hipError_t e2 = hipMemcpy(muls, d_muls, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -343,6 +508,31 @@ int plo_cse_search_plan(plo_plan_t *pl, uint64_t seed0, uint64_t nseeds, int cos
     auto t0 = std::chrono::steady_clock::now();
     out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull;
     uint64_t bkey = ~0ull, bseed = ~0ull;
+    if (pl->big) {
+        const uint64_t CHB = 1ull << 24;                      // 24-bit seed offsets in the 64-bit cost word of the HBM variant
+        uint32_t ba = 0, bm = 0;
+        for (uint64_t done = 0; done < nseeds;) {
+            const uint64_t cnt = std::min<uint64_t>(CHB, nseeds - done);
+            HIPCHK(hipMemsetAsync(pl->d_best, 0xFF, sizeof(unsigned long long), g_stream));
+            plo::BigJob J{}; J.seed0 = seed0 + done; J.seeds = nullptr; J.ncand = cnt; J.best = pl->d_best; J.cost_mode = (uint32_t)cost_mode;
+            int rc = launch_big(pl, J, st);
+            if (rc != PLO_OK) return rc;
+            unsigned long long w = 0;
+            HIPCHK(hipMemcpy(&w, pl->d_best, sizeof w, hipMemcpyDeviceToHost));
+            const uint64_t key = w >> 24, sd = seed0 + done + (w & 0xFFFFFFull);
+            if (key < bkey || (key == bkey && sd < bseed)) { bkey = key; bseed = sd; }
+            done += cnt;
+        }
+        if (nseeds) {
+            if (cost_mode == PLO_COST_SUM_THEN_ADD) { ba = (uint32_t)(bkey & 0xFFFFFu); bm = (uint32_t)(bkey >> 20) - ba; }
+            else if (cost_mode == PLO_COST_ADD_THEN_MUL) { ba = (uint32_t)(bkey >> 20); bm = (uint32_t)(bkey & 0xFFFFFu); }
+            else { plo_stats_t s2{}; int rc = plo_cse_cost_many_plan(pl, &bseed, 0, 1, &ba, &bm, &s2); if (rc != PLO_OK) return rc; }
+            out->adds = ba; out->muls = bm; out->seed = bseed;
+        }
+        st->candidates = nseeds;
+        st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return PLO_OK;
+    }
     const uint64_t CH = 0xFFFFFFFFull;                        // seed offsets inside a launch are 32-bit
     for (uint64_t done = 0; done < nseeds;) {
         const uint64_t cnt = std::min<uint64_t>(CH, nseeds - done);

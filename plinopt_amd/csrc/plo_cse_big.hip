@@ -1,0 +1,710 @@
+// ===========================================================================
+// plo_cse_big.hip -- gfx950 kernel family for candidates that do NOT fit LDS
+// (BASELINE config 5: 32x32x32_15096_L = 15096x1024, 1.26 M non-zeros, 3.15 M
+// distinct pair triples, ~6.8 k CSE steps per candidate).  One WORKGROUP per
+// candidate, candidate state resident in HBM, workgroups persistent over the
+// seed range.  Same per-candidate semantics as plo_cse_wave.hip (reference
+// include/plinopt_optimize.inl:616-631), different bookkeeping:
+//
+//   tab[cap]   u64  global open-addressing pair table, key48<<16 | count16 with
+//                   key = col_a<<(bb+rb) | col_b<<rb | ratio: integer order ==
+//                   std::map order of (size_t,size_t,Element); the initial image
+//                   is built once on the host and copied per candidate.
+//   rows       col/val/inv u32[nnz] at fixed row offsets rs[i] (rows only shrink)
+//   levels     the maximal frequency M never increases during a candidate, and
+//              only ~60 distinct values occur on config 5.  hist[f] (LDS) counts
+//              triples per frequency; cntM[c] counts triples of frequency M whose
+//              first column is c; DM lists the keys that reached M; HL lists keys
+//              with frequency >= theta (a window of levels) so that a level change
+//              re-reads HL instead of the 64 MB table.
+//   tie pick   prefix over cntM -> first column; the few DM keys of that column
+//              are sorted in LDS -> k-th tie in map order (OneSub :244-265).
+//   rows(a)    row lists per column (static transpose for input columns, an
+//              append-only pool for created columns, stale entries filtered);
+//              +-1 counts per column kept incrementally (RemOneCSE :70-77).
+// The work per candidate is ~2.5e8 pair retirements + 1.2e8 pair insertions,
+// each one random 8-byte atomic in a 64 MB table: HBM-latency bound.
+// ===========================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plo {
+
+#define PLO_BIG_THREADS 256
+#define PLO_BIG_SELCAP 1024u
+#define PLO_GVB 16u
+#define PLO_GVMASK 0xFFFFull
+#define PLO_GEMPTY 0xFFFFFFFFFFFF0000ull
+
+struct BigPlan {
+    uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride;
+    uint64_t mu;
+    const uint32_t *rs, *col0, *val0, *inv0, *tptr, *trows, *ucount0, *hist0;
+    const uint64_t *tab0;
+    uint8_t *ws; uint64_t ws_stride;
+    uint64_t o_tab, o_col, o_val, o_inv, o_len, o_ucount, o_cntM, o_dm, o_hl, o_aff, o_ncrptr, o_ncr, o_multc, o_multv,
+             o_tcnt, o_tptr2, o_tlist, o_cols2;
+};
+
+struct BigJob {
+    uint64_t seed0; const uint64_t *seeds; uint64_t ncand;
+    uint32_t *adds, *muls; unsigned long long *best; uint32_t cost_mode; uint32_t *err;
+    unsigned long long *next;     // work counter: candidates are handed out dynamically
+    uint32_t *stats;              // optional: [0]=steps of last candidate, [1]=full scans, [2]=level rebuilds
+};
+
+enum { BERR_TABLE = 11, BERR_FREQ = 12, BERR_COLS = 13, BERR_DM = 14, BERR_HL = 15, BERR_MULT = 16, BERR_SEL = 17, BERR_PGEN = 18 };
+
+__device__ __forceinline__ uint64_t gload64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t gload32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ghash(uint64_t key, uint32_t hbits) {
+    uint64_t x = key * 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(x >> (64u - hbits));
+}
+__device__ __forceinline__ uint32_t bmul(uint32_t a, uint32_t b, uint32_t p, uint64_t mu) {
+    uint64_t x = (uint64_t)a * b;
+    uint64_t q = __umul64hi(x, mu);
+    uint64_t r = x - q * p;
+    while (r >= p) r -= p;
+    return (uint32_t)r;
+}
+__device__ __forceinline__ bool babsone(uint32_t e, uint32_t p) { return e == 1u || e == p - 1u; }
+__device__ __forceinline__ uint32_t babs(uint32_t e, uint32_t p) { uint32_t a = e ? p - e : 0u; return a < e ? a : e; }
+
+// frequency[key] -= 1; returns the frequency before (0 = key not found: corruption)
+__device__ __forceinline__ uint32_t gtab_dec(uint64_t *tab, uint64_t key, uint32_t hbits) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s = ghash(key, hbits);
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        uint64_t v = gload64(&tab[s]);
+        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], ~0ull); return (uint32_t)(old & PLO_GVMASK); }
+        if (v == PLO_GEMPTY) return 0u;
+        s = (s + 1u) & mask;
+    }
+    return 0u;
+}
+// frequency[key] += 1 (claims an empty or dead slot); returns the new frequency (0 = table full)
+__device__ __forceinline__ uint32_t gtab_inc(uint64_t *tab, uint64_t key, uint32_t hbits) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s = ghash(key, hbits);
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        uint64_t v = gload64(&tab[s]);
+        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], 1ull); return (uint32_t)(old & PLO_GVMASK) + 1u; }
+        if ((v & PLO_GVMASK) == 0ull) {
+            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | 1ull));
+            if (old == v) return 1u;
+            continue;
+        }
+        s = (s + 1u) & mask;
+    }
+    return 0u;
+}
+__device__ __forceinline__ uint32_t gtab_find(const uint64_t *tab, uint64_t key, uint32_t hbits) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s = ghash(key, hbits);
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        uint64_t v = gload64(&tab[s]);
+        if ((v >> PLO_GVB) == key) return (uint32_t)(v & PLO_GVMASK);
+        if (v == PLO_GEMPTY) return 0u;
+        s = (s + 1u) & mask;
+    }
+    return 0u;
+}
+// value add with claim of EMPTY slots only (ProgramGen multiset; no dead slots there)
+__device__ __forceinline__ bool gtab_add(uint64_t *tab, uint64_t key, uint32_t incv, uint32_t hbits) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s = ghash(key, hbits);
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        uint64_t v = gload64(&tab[s]);
+        if (v == PLO_GEMPTY) {
+            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | incv));
+            if (old == v) return true;
+            continue;
+        }
+        if ((v >> PLO_GVB) == key) { atomicAdd((unsigned long long *)&tab[s], (unsigned long long)incv); return true; }
+        s = (s + 1u) & mask;
+    }
+    return false;
+}
+
+// set a flag bit on the key's value (insert the key if absent); idempotent, unlike an add
+__device__ __forceinline__ bool gtab_flag(uint64_t *tab, uint64_t key, uint32_t flag, uint32_t hbits) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s = ghash(key, hbits);
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        uint64_t v = gload64(&tab[s]);
+        if (v == PLO_GEMPTY) {
+            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | flag));
+            if (old == v) return true;
+            continue;
+        }
+        if ((v >> PLO_GVB) == key) { atomicOr((unsigned long long *)&tab[s], (unsigned long long)flag); return true; }
+        s = (s + 1u) & mask;
+    }
+    return false;
+}
+
+// position of column c in row [base, base+L) (sorted by column), or -1
+__device__ __forceinline__ int row_find(const uint32_t *col, uint32_t base, uint32_t L, uint32_t c) {
+    uint32_t lo = 0, hi = L;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (col[base + mid] < c) lo = mid + 1; else hi = mid; }
+    return (lo < L && col[base + lo] == c) ? (int)lo : -1;
+}
+
+struct BigShared {
+    uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
+    uint32_t a, b, r; uint64_t kprime; uint64_t selkey;
+    uint32_t part[PLO_BIG_THREADS];
+    uint64_t sel[PLO_BIG_SELCAP];
+};
+
+#define BSYNC() __syncthreads()
+
+// ---------------------------------------------------------------------------
+// One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
+// ---------------------------------------------------------------------------
+__device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint32_t *errw)
+{
+    const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
+    uint64_t *tab   = (uint64_t *)(ws + P.o_tab);
+    uint32_t *col   = (uint32_t *)(ws + P.o_col), *val = (uint32_t *)(ws + P.o_val), *inv = (uint32_t *)(ws + P.o_inv);
+    uint32_t *len   = (uint32_t *)(ws + P.o_len), *ucount = (uint32_t *)(ws + P.o_ucount), *cntM = (uint32_t *)(ws + P.o_cntM);
+    uint64_t *DM    = (uint64_t *)(ws + P.o_dm), *HL = (uint64_t *)(ws + P.o_hl);
+    uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
+    uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
+    const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m;
+    const uint64_t mu = P.mu, cap = 1ull << P.hbits;
+#define BKEY(a_, b_, r_) (((uint64_t)(a_) << abits) | ((uint64_t)(b_) << rb) | (uint64_t)(r_))
+
+    // ---- load the candidate image
+    for (uint64_t s = tid; s < cap; s += nth) tab[s] = P.tab0[s];
+    for (uint32_t k = tid; k < P.nnz; k += nth) { col[k] = P.col0[k]; val[k] = P.val0[k]; inv[k] = P.inv0[k]; }
+    for (uint32_t i = tid; i < m; i += nth) len[i] = P.rs[i + 1] - P.rs[i];
+    for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; }
+    for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = P.hist0[f];
+    if (tid == 0) {
+        uint64_t x = seed + 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
+        sh.rng = 1u + (uint32_t)(x % 2147483646ull);
+        sh.M = P.M0; sh.theta = P.M0 + 1u; sh.ncols = n; sh.nbadd = 0; sh.nbmul = 0; sh.nmult = 0; sh.dmcount = 0; sh.hlcount = 0;
+        sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0;
+    }
+    __threadfence(); BSYNC();
+
+    bool need_rebuild = true;
+    for (;;) {
+        if (sh.errflag) break;
+        // ---- level bookkeeping: lower M while empty (thread 0), decide on a window rescan
+        if (tid == 0) {
+            uint32_t M = sh.M;
+            while (M >= 2u && hist[M] == 0u) --M;
+            sh.part[0] = (M != sh.M) ? 1u : 0u;
+            sh.M = M;
+        }
+        BSYNC();
+        const uint32_t M = sh.M;
+        if (M <= 1u) break;                                               // OneSub :255
+        if (sh.part[0]) need_rebuild = true;
+        BSYNC();
+        if (need_rebuild) {
+            if (M < sh.theta || sh.hlbad) {
+                // full table scan: new window [theta', M] holding at most hlcap/2 keys
+                if (tid == 0) {
+                    uint64_t acc = 0; uint32_t th = M;
+                    for (uint32_t f = M; f >= 2u; --f) { if (acc + hist[f] > P.hlcap / 2u) break; acc += hist[f]; th = f; }
+                    if (hist[M] > P.hlcap / 2u) atomicMax(&sh.errflag, (uint32_t)BERR_HL);
+                    sh.theta = th; sh.hlcount = 0; sh.hlbad = 0; ++sh.fullscans;
+                }
+                BSYNC();
+                const uint32_t th = sh.theta;
+                for (uint64_t s = tid; s < cap; s += nth) {
+                    uint64_t v = gload64(&tab[s]);
+                    if ((uint32_t)(v & PLO_GVMASK) >= th && v != PLO_GEMPTY) {
+                        uint32_t idx = atomicAdd(&sh.hlcount, 1u);
+                        if (idx < P.hlcap) HL[idx] = v >> PLO_GVB; else atomicMax(&sh.errflag, (uint32_t)BERR_HL);
+                    }
+                }
+                BSYNC();
+            }
+            // per-column counters and key list of the current level from the window list
+            for (uint32_t c = tid; c < sh.ncols; c += nth) cntM[c] = 0u;
+            if (tid == 0) { sh.dmcount = 0; ++sh.rebuilds; }
+            __threadfence(); BSYNC();
+            const uint32_t hn = sh.hlcount < P.hlcap ? sh.hlcount : P.hlcap;
+            for (uint32_t k = tid; k < hn; k += nth) {
+                const uint64_t key = HL[k];
+                if (gtab_find(tab, key, hbits) == M) {
+                    atomicAdd(&cntM[(uint32_t)(key >> abits)], 1u);
+                    uint32_t idx = atomicAdd(&sh.dmcount, 1u);
+                    if (idx < P.dmcap) DM[idx] = key; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
+                }
+            }
+            need_rebuild = false;
+            __threadfence(); BSYNC();
+            if (sh.errflag) break;
+        }
+        // ---- tie pick (OneSub :244-265): k-th triple of frequency M in map order
+        const uint32_t ncols = sh.ncols;
+        {
+            const uint32_t chunk = (ncols + nth - 1u) / nth;
+            uint32_t s0 = tid * chunk, acc = 0;
+            for (uint32_t c = s0; c < s0 + chunk && c < ncols; ++c) acc += gload32(&cntM[c]);
+            sh.part[tid] = acc;
+            BSYNC();
+            if (tid == 0) {
+                const uint32_t T = hist[M];
+                uint64_t k = 0;
+                if (T > 1u) { uint64_t x = 950706376ull * (uint64_t)sh.rng; sh.rng = (uint32_t)(x % 2147483647ull); k = sh.rng % T; }
+                uint32_t t = 0; uint64_t run = 0;
+                for (; t < nth; ++t) { if (k < run + sh.part[t]) break; run += sh.part[t]; }
+                if (t >= nth) { atomicMax(&sh.errflag, (uint32_t)BERR_SEL); sh.a = 0; sh.kprime = 0; }
+                else {
+                    uint32_t c = t * chunk;
+                    for (; c < ncols; ++c) { uint32_t q = gload32(&cntM[c]); if (k < run + q) break; run += q; }
+                    if (c >= ncols) atomicMax(&sh.errflag, (uint32_t)BERR_SEL);
+                    sh.a = c < ncols ? c : 0u; sh.kprime = k - run;
+                }
+                sh.sel_n = 0; sh.sel_over = 0;
+            }
+            BSYNC();
+            if (sh.errflag) break;
+            const uint32_t a = sh.a;
+            const uint32_t dn = sh.dmcount < P.dmcap ? sh.dmcount : P.dmcap;
+            for (uint32_t k = tid; k < dn; k += nth) {
+                const uint64_t key = DM[k];
+                if ((uint32_t)(key >> abits) == a && gtab_find(tab, key, hbits) == M) {
+                    uint32_t idx = atomicAdd(&sh.sel_n, 1u);
+                    if (idx < PLO_BIG_SELCAP) sh.sel[idx] = key; else sh.sel_over = 1u;
+                }
+            }
+            BSYNC();
+            if (sh.sel_over) {
+                // rare: more ties in one column than the LDS list holds -> bisection on the key value
+                uint64_t lo = (uint64_t)a << abits, hi = (((uint64_t)a + 1ull) << abits) - 1ull;
+                while (lo < hi) {
+                    const uint64_t mid = lo + ((hi - lo) >> 1);
+                    if (tid == 0) sh.sel_n = 0;
+                    BSYNC();
+                    uint32_t c = 0;
+                    for (uint32_t k = tid; k < dn; k += nth) {
+                        const uint64_t key = DM[k];
+                        if ((uint32_t)(key >> abits) == a && key <= mid && gtab_find(tab, key, hbits) == M) ++c;
+                    }
+                    if (c) atomicAdd(&sh.sel_n, c);
+                    BSYNC();
+                    const uint32_t tot = sh.sel_n;
+                    BSYNC();
+                    if ((uint64_t)tot >= sh.kprime + 1ull) hi = mid; else lo = mid + 1ull;
+                }
+                if (tid == 0) sh.selkey = lo;
+            } else {
+                const uint32_t sn = sh.sel_n;
+                for (uint32_t x = tid; x < sn; x += nth) {
+                    const uint64_t mine = sh.sel[x]; uint32_t rank = 0;
+                    for (uint32_t y = 0; y < sn; ++y) rank += (sh.sel[y] < mine) ? 1u : 0u;
+                    if ((uint64_t)rank == sh.kprime) sh.selkey = mine;
+                }
+                if (tid == 0 && (uint64_t)sn <= sh.kprime) atomicMax(&sh.errflag, (uint32_t)BERR_SEL);
+            }
+            BSYNC();
+            if (sh.errflag) break;
+        }
+        const uint64_t key = sh.selkey;
+        const uint32_t r = (uint32_t)(key & ((1ull << rb) - 1ull)), b = (uint32_t)(key >> rb) & ((1u << P.bb) - 1u), a = (uint32_t)(key >> abits);
+        const uint32_t lm = ncols;
+        if (lm + 1u >= P.NCmax) { if (tid == 0) atomicMax(&sh.errflag, (uint32_t)BERR_COLS); BSYNC(); break; }
+        // ---- RemOneCSE :60-194
+        const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
+        const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
+        if (tid == 0) sh.naff = 0;
+        BSYNC();
+        {   // rows holding the triple: walk the shorter row list of the two columns
+            const uint32_t *la, *lb; uint32_t na, nb;
+            if (a < n) { la = P.trows + P.tptr[a]; na = P.tptr[a + 1] - P.tptr[a]; } else { la = ncr + ncrptr[a - n]; na = ncrptr[a - n + 1] - ncrptr[a - n]; }
+            if (b < n) { lb = P.trows + P.tptr[b]; nb = P.tptr[b + 1] - P.tptr[b]; } else { lb = ncr + ncrptr[b - n]; nb = ncrptr[b - n + 1] - ncrptr[b - n]; }
+            const uint32_t *lst = na <= nb ? la : lb; const uint32_t ln = na <= nb ? na : nb;
+            for (uint32_t k = tid; k < ln; k += nth) {
+                const uint32_t i = lst[k], base = P.rs[i], L = len[i];
+                const int pa = row_find(col, base, L, a);
+                if (pa < 0) continue;
+                const int pb = row_find(col, base, L, b);
+                if (pb < 0) continue;
+                const uint32_t va = val[base + pa], vb = val[base + pb];
+                if (vb != bmul(r, va, p, mu)) continue;
+                const uint32_t idx = atomicAdd(&sh.naff, 1u);
+                aff[idx] = i;
+                if (idx == 0) sh.invr = bmul(va, inv[base + pb], p, mu);   // 1/r
+            }
+        }
+        __threadfence(); BSYNC();
+        const uint32_t naff = sh.naff;
+        if (naff != M) { if (tid == 0) atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); BSYNC(); break; }   // frequency must equal the row count
+        // sweep 1: retire the old pairs of the affected rows (:115-118)
+        for (uint32_t q = wave; q < naff; q += nwaves) {
+            const uint32_t i = aff[q], base = P.rs[i], L = len[i];
+            const int pa = row_find(col, base, L, a), pb = row_find(col, base, L, b);
+            const uint32_t va = val[base + pa], ia = inv[base + pa], vb = val[base + pb], ib = inv[base + pb];
+            for (uint32_t z = lane; z < L; z += 64u) {
+                if ((int)z == pa || (int)z == pb) continue;
+                const uint32_t c = col[base + z], v = val[base + z], iv = inv[base + z];
+                const uint64_t k1 = c < a ? BKEY(c, a, bmul(va, iv, p, mu)) : BKEY(a, c, bmul(v, ia, p, mu));
+                const uint64_t k2 = c < b ? BKEY(c, b, bmul(vb, iv, p, mu)) : BKEY(b, c, bmul(v, ib, p, mu));
+                uint32_t o1 = gtab_dec(tab, k1, hbits), o2 = gtab_dec(tab, k2, hbits);
+                if (!o1 || !o2) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                atomicSub(&hist[o1], 1u); if (o1 > 1u) atomicAdd(&hist[o1 - 1u], 1u);
+                if (o1 == M) atomicSub(&cntM[c < a ? c : a], 1u);
+                atomicSub(&hist[o2], 1u); if (o2 > 1u) atomicAdd(&hist[o2 - 1u], 1u);
+                if (o2 == M) atomicSub(&cntM[c < b ? c : b], 1u);
+            }
+            if (lane == 0) {
+                uint32_t o = gtab_dec(tab, key, hbits);
+                if (!o) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
+                else { atomicSub(&hist[o], 1u); if (o > 1u) atomicAdd(&hist[o - 1u], 1u); if (o == M) atomicSub(&cntM[a], 1u); }
+            }
+        }
+        __threadfence(); BSYNC();
+        if (sh.errflag) break;
+        // sweep 2: rewrite the rows, insert the pairs with the new column (:96-110, :132-142)
+        for (uint32_t q = wave; q < naff; q += nwaves) {
+            const uint32_t i = aff[q], base = P.rs[i], L = len[i];
+            const int pa = row_find(col, base, L, a), pb = row_find(col, base, L, b);
+            const int p0 = (l0 == a) ? pa : pb;
+            const uint32_t coeff = val[base + p0], icoeff = inv[base + p0];
+            const bool ua = babsone(val[base + pa], p), ub = babsone(val[base + pb], p);
+            for (uint32_t z0 = 0; z0 < L; z0 += 64u) {
+                const uint32_t z = z0 + lane; const bool have = z < L;
+                uint32_t c = 0, v = 0, iv = 0;
+                if (have) { c = col[base + z]; v = val[base + z]; iv = inv[base + z]; }
+                __builtin_amdgcn_wave_barrier();
+                if (have && (int)z != pa && (int)z != pb) {
+                    const uint32_t np = base + z - ((int)z > pa ? 1u : 0u) - ((int)z > pb ? 1u : 0u);
+                    col[np] = c; val[np] = v; inv[np] = iv;
+                    const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu));
+                    const uint32_t nc = gtab_inc(tab, nk, hbits);
+                    if (!nc) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                    if (nc > P.maxf0) { atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
+                    if (nc > 1u) atomicSub(&hist[nc - 1u], 1u);
+                    atomicAdd(&hist[nc], 1u);
+                    if (nc == sh.theta) { uint32_t idx = atomicAdd(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = nk; else sh.hlbad = 1u; }
+                    if (nc == M) {
+                        atomicAdd(&cntM[c], 1u);
+                        uint32_t idx = atomicAdd(&sh.dmcount, 1u);
+                        if (idx < P.dmcap) DM[idx] = nk; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) {
+                col[base + L - 2u] = lm; val[base + L - 2u] = coeff; inv[base + L - 2u] = icoeff;
+                len[i] = L - 1u;
+                if (ua) atomicSub(&ucount[a], 1u);
+                if (ub) atomicSub(&ucount[b], 1u);
+                if (babsone(coeff, p)) atomicAdd(&ucount[lm], 1u);
+            }
+        }
+        // row list of the new column, multiplier reuse (:153-169), counters
+        {
+            const uint32_t o = ncrptr[lm - n];
+            for (uint32_t k = tid; k < naff; k += nth) ncr[o + k] = aff[k];
+            if (tid == 0) { ncrptr[lm - n + 1u] = o + naff; sh.part[0] = 0; }
+        }
+        BSYNC();
+        if (!P.unit) {
+            const uint32_t rho = swap ? sh.invr : r, asgs = babs(rho, p);
+            if (!babsone(asgs, p)) {
+                const uint32_t nm = sh.nmult; bool hit = false;
+                for (uint32_t k = tid; k < nm; k += nth) hit |= (multc[k] == l1 && multv[k] == asgs);
+                if (hit) sh.part[0] = 1u;
+                BSYNC();
+                if (tid == 0 && !sh.part[0]) {
+                    if (nm >= P.multcap) atomicMax(&sh.errflag, (uint32_t)BERR_MULT);
+                    else { multc[nm] = l1; multv[nm] = asgs; sh.nmult = nm + 1u; ++sh.nbmul; }
+                }
+            }
+        }
+        if (tid == 0) { ++sh.nbadd; ++sh.steps; sh.ncols = lm + 1u; }      // :292, :190-191
+        __threadfence(); BSYNC();
+    }
+    BSYNC();
+    if (sh.errflag) { if (tid == 0) atomicMax(errw, sh.errflag); return 0; }
+    return 1;   // CSE phase done; ProgramGen follows in the caller
+#undef BKEY
+}
+
+
+#define PLO_PGFLAG 0x8000u
+#define PLO_PGCNT 0x7FFFu
+#define PLO_BFRESH 0xFFFFFFFFu
+
+// ProgramGen at scale, counts only (reference :513-611; counting rules derived in
+// plo_cse_wave.hip).  Workgroup-parallel for the factoring passes and the output
+// count; the Triangle pass walks, with one wave, only the columns that still hold
+// two or more non +-1 entries (after FactorOutColumns those have pairwise distinct
+// |values|, so they are few and short).
+__device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *scratch, uint32_t *errw)
+{
+    const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
+    uint64_t *tab   = (uint64_t *)(ws + P.o_tab);
+    uint32_t *col   = (uint32_t *)(ws + P.o_col), *val = (uint32_t *)(ws + P.o_val), *inv = (uint32_t *)(ws + P.o_inv);
+    uint32_t *len   = (uint32_t *)(ws + P.o_len);
+    uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
+    uint32_t *tcnt  = (uint32_t *)(ws + P.o_tcnt), *tptr2 = (uint32_t *)(ws + P.o_tptr2), *tlist = (uint32_t *)(ws + P.o_tlist), *cols2 = (uint32_t *)(ws + P.o_cols2);
+    const uint32_t p = P.p, rb = P.rb, m = P.m, ncols0 = sh.ncols;
+    const uint64_t mu = P.mu;
+
+    if (tid == 0) { sh.acc0 = 0; sh.acc1 = 0; sh.errflag = 0; }
+    BSYNC();
+    if (P.unit) {                                                      // all +-1: len-1 additions per row (:576)
+        uint32_t acc = 0;
+        for (uint32_t i = tid; i < m; i += nth) { uint32_t L = len[i]; acc += L > 1u ? L - 1u : 0u; }
+        if (acc) atomicAdd(&sh.acc0, acc);
+        BSYNC();
+        return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | sh.nbmul;
+    }
+    // table region for the (column,|v|) multiset, sized by the live entries
+    {
+        uint32_t acc = 0;
+        for (uint32_t i = tid; i < m; i += nth) acc += len[i];
+        if (acc) atomicAdd(&sh.acc0, acc);
+        BSYNC();
+    }
+    const uint32_t live = sh.acc0 + sh.nmult;
+    uint32_t hb = 6; while ((1ull << hb) < 4ull * live + 64ull && hb < P.hbits) ++hb;
+    if ((1ull << hb) < 2ull * live + 16ull) { if (tid == 0) { atomicMax(errw, (uint32_t)BERR_PGEN); sh.errflag = BERR_PGEN; } BSYNC(); return 0; }
+    for (uint64_t s = tid; s < (1ull << hb); s += nth) tab[s] = PLO_GEMPTY;
+    BSYNC();
+    if (tid == 0) sh.acc0 = 0;
+    __threadfence(); BSYNC();
+    for (uint32_t k = tid; k < sh.nmult; k += nth)
+        if (!gtab_flag(tab, ((uint64_t)multc[k] << rb) | multv[k], PLO_PGFLAG, hb)) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
+    __threadfence(); BSYNC();
+    // A1 occurrences of (j,e)
+    for (uint32_t i = wave; i < m; i += nwaves) {
+        const uint32_t base = P.rs[i], L = len[i];
+        for (uint32_t z = lane; z < L; z += 64u) {
+            const uint32_t e = babs(val[base + z], p);
+            if (!babsone(e, p)) if (!gtab_add(tab, ((uint64_t)col[base + z] << rb) | e, 1u, hb)) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
+        }
+    }
+    __threadfence(); BSYNC();
+    // A2 one multiplication per repeated (j,e) not yet in multiples (:335-352)
+    {
+        uint32_t cnt = 0;
+        for (uint64_t s = tid; s < (1ull << hb); s += nth) {
+            uint64_t v = gload64(&tab[s]);
+            if (v != PLO_GEMPTY && ((uint32_t)v & PLO_PGCNT) >= 2u && !((uint32_t)v & PLO_PGFLAG)) { ++cnt; atomicOr((unsigned long long *)&tab[s], (unsigned long long)PLO_PGFLAG); }
+        }
+        if (cnt) atomicAdd(&sh.acc1, cnt);
+    }
+    __threadfence(); BSYNC();
+    if (tid == 0) { sh.nbmul += sh.acc1; sh.acc1 = 0; }
+    // A3 repeated entries become +-1 entries of a fresh column (:358-368)
+    for (uint32_t i = wave; i < m; i += nwaves) {
+        const uint32_t base = P.rs[i], L = len[i];
+        for (uint32_t z = lane; z < L; z += 64u) {
+            const uint32_t v = val[base + z], e = babs(v, p), c = col[base + z];
+            if (!babsone(e, p) && (gtab_find(tab, ((uint64_t)c << rb) | e, hb) & PLO_PGCNT) >= 2u) {
+                const uint32_t u = (v == e) ? 1u : p - 1u;
+                col[base + z] = PLO_BFRESH; val[base + z] = u; inv[base + z] = u;
+            }
+        }
+    }
+    __threadfence(); BSYNC();
+    // B FactorOutRows on every row (:375-420): |v| values of the row in per-wave LDS scratch
+    {
+        uint32_t *sc = scratch + (size_t)wave * P.scr_stride;             // per-wave scratch, stride = longest input row
+        uint32_t addacc = 0;
+        for (uint32_t i = wave; i < m; i += nwaves) {
+            const uint32_t base = P.rs[i], L = len[i];
+            bool any = false;
+            for (uint32_t z = lane; z < L; z += 64u) { uint32_t e = babs(val[base + z], p); if (babsone(e, p)) e = 0u; sc[z] = e; any |= e != 0u; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (!__ballot(any)) continue;
+            uint32_t kept = 0;                                             // entries written so far (wave-uniform)
+            for (uint32_t z0 = 0; z0 < L; z0 += 64u) {
+                const uint32_t z = z0 + lane; const bool have = z < L;
+                uint32_t c = 0, v = 0, iv = 0, e = 0, freq = 0, first = 0xFFFFFFFFu;
+                if (have) { c = col[base + z]; v = val[base + z]; iv = inv[base + z]; e = sc[z]; }
+                if (e != 0u) for (uint32_t y = 0; y < L; ++y) if (sc[y] == e) { ++freq; if (first == 0xFFFFFFFFu) first = y; }
+                const bool grouped = e != 0u && freq > 1u, leader = grouped && first == z;
+                if (leader) addacc += freq - 1u;
+                const bool keep = have && (!grouped || leader);
+                const uint64_t km = __ballot(keep);
+                __builtin_amdgcn_wave_barrier();
+                if (keep) {
+                    const uint32_t np = base + kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                    if (leader) { col[np] = PLO_BFRESH; val[np] = e; inv[np] = (v == e) ? iv : p - iv; }
+                    else { col[np] = c; val[np] = v; inv[np] = iv; }
+                }
+                kept += (uint32_t)__popcll(km);
+            }
+            if (lane == 0) len[i] = kept;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        if (addacc) atomicAdd(&sh.acc0, addacc);
+    }
+    __threadfence(); BSYNC();
+    if (tid == 0) { sh.nbadd += sh.acc0; sh.acc0 = 0; }
+    // C Triangle (:427-507).  Columns with >= 2 non +-1 entries, ascending; rows of each in ascending order.
+    for (uint32_t c = tid; c < ncols0; c += nth) tcnt[c] = 0u;
+    __threadfence(); BSYNC();
+    for (uint32_t i = wave; i < m; i += nwaves) {
+        const uint32_t base = P.rs[i], L = len[i];
+        for (uint32_t z = lane; z < L; z += 64u) { const uint32_t c = col[base + z]; if (c != PLO_BFRESH && !babsone(val[base + z], p)) atomicAdd(&tcnt[c], 1u); }
+    }
+    __threadfence(); BSYNC();
+    if (tid == 0) {                                                        // ordered compaction (a few thousand columns)
+        uint32_t nc2 = 0, off = 0;
+        for (uint32_t c = 0; c < ncols0; ++c) { const uint32_t k = gload32(&tcnt[c]); if (k >= 2u) { cols2[nc2] = c; tptr2[nc2] = off; off += k; ++nc2; } }
+        tptr2[nc2] = off; sh.naff = nc2;
+    }
+    __threadfence(); BSYNC();
+    const uint32_t nc2 = sh.naff;
+    if (nc2) {
+        // fill the row lists (binary search of the column in cols2), then sort each list
+        for (uint32_t c = tid; c < ncols0; c += nth) tcnt[c] = 0u;
+        __threadfence(); BSYNC();
+        for (uint32_t i = wave; i < m; i += nwaves) {
+            const uint32_t base = P.rs[i], L = len[i];
+            for (uint32_t z = lane; z < L; z += 64u) {
+                const uint32_t c = col[base + z];
+                if (c == PLO_BFRESH || babsone(val[base + z], p)) continue;
+                uint32_t lo = 0, hi = nc2;
+                while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cols2[mid] < c) lo = mid + 1; else hi = mid; }
+                if (lo < nc2 && cols2[lo] == c) tlist[tptr2[lo] + atomicAdd(&tcnt[c], 1u)] = i;
+            }
+        }
+        __threadfence(); BSYNC();
+        for (uint32_t x = tid; x < nc2; x += nth) {                         // insertion sort, lists are short
+            uint32_t *l = tlist + tptr2[x]; const uint32_t k = tptr2[x + 1] - tptr2[x];
+            for (uint32_t u = 1; u < k; ++u) { uint32_t t = l[u], w = u; while (w > 0 && l[w - 1] > t) { l[w] = l[w - 1]; --w; } l[w] = t; }
+        }
+        __threadfence(); BSYNC();
+        if (wave == 0) {
+            uint32_t mulacc = 0, addacc = 0;
+            for (uint32_t x = 0; x < nc2; ++x) {
+                const uint32_t j = cols2[x], k = tptr2[x + 1] - tptr2[x];
+                if (k > 64u) { if (lane == 0) atomicMax(&sh.errflag, (uint32_t)BERR_PGEN); break; }
+                const uint32_t row = lane < k ? tlist[tptr2[x] + lane] : 0xFFFFFFFFu;
+                bool found = false;
+                for (;;) {
+                    uint32_t vj = 0, ivj = 0; bool mine = false;
+                    if (row != 0xFFFFFFFFu) {
+                        const uint32_t base = P.rs[row], L = len[row];
+                        for (uint32_t z = 0; z < L; ++z) if (col[base + z] == j) { vj = val[base + z]; ivj = inv[base + z]; mine = !babsone(vj, p); break; }
+                    }
+                    const uint64_t NU = __ballot(mine);
+                    if (__popcll(NU) < 2) break;
+                    int it = -1, nx = -1;
+                    uint64_t scan = found ? (1ull << __builtin_ctzll(NU)) : NU;
+                    while (scan) {
+                        const uint32_t i0 = (uint32_t)__builtin_ctzll(scan); scan &= scan - 1ull;
+                        const uint32_t iv1 = (uint32_t)__shfl((int)ivj, (int)i0);
+                        uint64_t cand = NU & ~(1ull << i0);
+                        if (found) cand = 1ull << __builtin_ctzll(cand);
+                        bool hit = false;
+                        if ((cand >> lane) & 1ull) {
+                            const uint32_t quot = bmul(vj, iv1, p, mu), nq = p - quot;
+                            const uint32_t base = P.rs[row], L = len[row];
+                            for (uint32_t z = 0; z < L; ++z) {
+                                const uint32_t tv = val[base + z];
+                                if (col[base + z] != j && !babsone(tv, p) && (tv == quot || tv == nq)) { hit = true; break; }
+                            }
+                        }
+                        const uint64_t hm = __ballot(hit);
+                        if (hm) { it = (int)i0; nx = (int)__builtin_ctzll(hm); break; }
+                    }
+                    if (it < 0) break;
+                    found = true;                                           // :453-498
+                    const uint32_t v1 = (uint32_t)__shfl((int)vj, it), iv1 = (uint32_t)__shfl((int)ivj, it);
+                    ++mulacc;
+                    if (lane == 0) if (!gtab_flag(tab, ((uint64_t)j << rb) | v1, PLO_PGFLAG, hb)) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
+                    if ((int)lane == it) {
+                        const uint32_t base = P.rs[row], L = len[row];
+                        for (uint32_t z = 0; z < L; ++z) if (col[base + z] == j) { col[base + z] = PLO_BFRESH; val[base + z] = 1u; inv[base + z] = 1u; break; }
+                    }
+                    uint32_t addone = 0;
+                    if ((int)lane == nx) {
+                        const uint32_t quot = bmul(vj, iv1, p, mu), iquot = bmul(ivj, v1, p, mu);
+                        const uint32_t eq = babs(quot, p), ieq = (quot == eq) ? iquot : p - iquot;
+                        const uint32_t base = P.rs[row], L = len[row];
+                        uint32_t w = 0, f = 1;
+                        for (uint32_t z = 0; z < L; ++z) {
+                            const uint32_t cz = col[base + z], tv = val[base + z], ti = inv[base + z];
+                            if (cz == j) continue;
+                            if (babs(tv, p) == eq) { ++f; continue; }
+                            col[base + w] = cz; val[base + w] = tv; inv[base + w] = ti; ++w;
+                        }
+                        col[base + w] = PLO_BFRESH; val[base + w] = eq; inv[base + w] = ieq; ++w;
+                        len[row] = w;
+                        addone = f - 1u;
+                    }
+                    addacc += (uint32_t)__shfl((int)addone, nx);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (lane == 0) { sh.nbmul += mulacc; sh.nbadd += addacc; }
+        }
+        __threadfence(); BSYNC();
+    }
+    // D output rows (:547-604)
+    {
+        uint32_t addacc = 0, mulacc = 0;
+        for (uint32_t i = wave; i < m; i += nwaves) {
+            const uint32_t base = P.rs[i], L = len[i];
+            if (lane == 0 && L > 1u) addacc += L - 1u;
+            for (uint32_t z = lane; z < L; z += 64u) {
+                const uint32_t e = babs(val[base + z], p), c = col[base + z];
+                if (!babsone(e, p)) {
+                    const bool reuse = c != PLO_BFRESH && (gtab_find(tab, ((uint64_t)c << rb) | e, hb) & PLO_PGFLAG);
+                    if (!reuse) ++mulacc;
+                }
+            }
+        }
+        if (addacc) atomicAdd(&sh.acc0, addacc);
+        if (mulacc) atomicAdd(&sh.acc1, mulacc);
+    }
+    BSYNC();
+    if (sh.errflag) { if (tid == 0) atomicMax(errw, sh.errflag); return 0; }
+    return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | (sh.nbmul + sh.acc1);
+}
+
+__global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, BigJob J)
+{
+    extern __shared__ uint32_t bigdyn[];                 // hist[maxf0+1] then per-wave scratch (nwaves * stride)
+    __shared__ BigShared sh;
+    __shared__ unsigned long long cur;
+    uint32_t *hist = bigdyn;
+    uint32_t *scratch = bigdyn + ((P.maxf0 + 2u) & ~1u);
+    uint8_t *ws = P.ws + (uint64_t)blockIdx.x * P.ws_stride;
+    uint64_t best = ~0ull;
+    for (;;) {
+        if (threadIdx.x == 0) cur = atomicAdd(J.next, 1ull);
+        __syncthreads();
+        const uint64_t c = cur;
+        __syncthreads();
+        if (c >= J.ncand) break;
+        const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
+        uint64_t ok = big_candidate(P, ws, seed, sh, hist, J.err);
+        uint64_t res = 0;
+        __syncthreads();
+        if (ok) res = big_program_gen(P, ws, sh, scratch, J.err);
+        __syncthreads();
+        if (sh.errflag) ok = 0;
+        if (threadIdx.x == 0) {
+            const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
+            if (J.adds) J.adds[c] = a;
+            if (J.muls) J.muls[c] = mu_;
+            if (J.stats) { J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; }
+            // 64-bit cost word: the op-counts of config 5 do not fit 16 bits
+            uint64_t ck;
+            switch (J.cost_mode) { case 1: ck = ((uint64_t)a << 20) | mu_; break; case 2: ck = (uint64_t)(a + mu_) << 20; break; default: ck = ((uint64_t)(a + mu_) << 20) | a; }
+            const uint64_t packed = (ck << 24) | (c & 0xFFFFFFull);
+            if (ok) best = packed < best ? packed : best;
+        }
+        __syncthreads();
+    }
+    if (J.best && threadIdx.x == 0 && best != ~0ull) atomicMin(J.best, (unsigned long long)best);
+}
+
+} // namespace plo

@@ -168,6 +168,22 @@ __device__ __forceinline__ bool tab_add(uint64_t *tab, uint64_t key, uint32_t in
     }
     return false;
 }
+// set a flag bit on the key's value (insert the key if absent); idempotent, unlike an add
+__device__ __forceinline__ bool tab_flag(uint64_t *tab, uint64_t key, uint32_t flag, uint32_t cap, uint32_t hbits) {
+    volatile uint64_t *vt = tab;
+    uint32_t s = tab_hash(key, hbits);
+    for (uint32_t pr = 0; pr < 2u * cap + 64u; ++pr) {
+        uint64_t v = vt[s];
+        if (v == PLO_EMPTY) {
+            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_VB) | flag));
+            if (old == v) return true;
+            continue;
+        }
+        if ((v >> PLO_VB) == key) { atomicOr((unsigned long long *)&tab[s], (unsigned long long)flag); return true; }
+        s = (s + 1u) & (cap - 1u);
+    }
+    return false;
+}
 __device__ __forceinline__ uint32_t tab_find(const uint64_t *tab, uint64_t key, uint32_t cap, uint32_t hbits) {
     uint32_t s = tab_hash(key, hbits);
     for (uint32_t pr = 0; pr < cap; ++pr) {
@@ -219,7 +235,7 @@ __device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const u
     for (uint32_t s = lane; s < cap; s += 64u) tab[s] = PLO_EMPTY;
     PLO_WAVE_SYNC();
     for (uint32_t s0 = 0; s0 < nmult; s0 += 64u)
-        if (s0 + lane < nmult) bad |= !tab_add(tab, ((uint64_t)multc[s0 + lane] << rb) | multv[s0 + lane], PLO_MFLAG, cap, hbits);
+        if (s0 + lane < nmult) bad |= !tab_flag(tab, ((uint64_t)multc[s0 + lane] << rb) | multv[s0 + lane], PLO_MFLAG, cap, hbits);
     PLO_WAVE_SYNC();
     // A1: occurrences of (j, e)
     for (uint32_t r0 = 0; r0 < m; r0 += G) {
@@ -328,7 +344,7 @@ __device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const u
             found = true;
             const uint32_t v1 = bcast(vj, (uint32_t)it), iv1 = bcast(ivj, (uint32_t)it);
             ++nbmul;                                                          // t_m := t_j * |a|
-            if (lane == 0) bad |= !tab_add(tab, ((uint64_t)j << rb) | v1, PLO_MFLAG, cap, hbits);   // multiples gets the SIGNED value (:464)
+            if (lane == 0) bad |= !tab_flag(tab, ((uint64_t)j << rb) | v1, PLO_MFLAG, cap, hbits);   // multiples gets the SIGNED value (:464)
             if (lane == (uint32_t)it) {
                 const uint32_t base = rs[lane], ln = len[lane];
                 for (uint32_t z = 0; z < ln; ++z) if (col[base + z] == j) { col[base + z] = (uint16_t)PLO_FRESH; val[base + z] = 1u; inv[base + z] = 1u; break; }

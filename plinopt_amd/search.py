@@ -14,7 +14,7 @@ from . import capi
 class CSEPlan:
     """A matrix over Z_p prepared once and resident in HBM (plo_cse_plan_create)."""
 
-    def __init__(self, m, n, rowptr, col, val, p, device=None):
+    def __init__(self, m, n, rowptr, col, val, p, device=None, hbm=False):
         L = capi.lib()
         if device is not None:
             capi.check(L.plo_init(int(device)))
@@ -22,8 +22,9 @@ class CSEPlan:
         self.nnz = len(col)
         csr, self._keep = capi.make_csr(m, n, rowptr, col, val)
         h = ctypes.c_void_p()
-        capi.check(L.plo_cse_plan_create(ctypes.byref(csr), p, ctypes.byref(h)))
+        capi.check(L.plo_cse_plan_create_ex(ctypes.byref(csr), p, capi.PLAN_HBM if hbm else 0, ctypes.byref(h)))
         self._h = h
+        self.is_hbm = bool(L.plo_cse_plan_is_hbm(h))     # HBM-resident kernel family (one workgroup per candidate)
         self.last_stats = None
 
     def close(self):

@@ -1,0 +1,63 @@
+"""The HBM-resident kernel family (plo_cse_big.hip, one workgroup per candidate) against the CPU
+oracle on inputs the oracle finishes in seconds: the same per-seed (adds, muls) and the same argmin as
+the LDS-resident wave kernel, forced with PLO_PLAN_HBM."""
+import glob
+import os
+
+import pytest
+
+import synth
+from plo_testlib import DATA, OracleMatrix
+
+pytestmark = pytest.mark.gpu
+P = 131071
+SOME = ["2x2x2_7_Winograd_L.sms", "cyclic.sms", "4x4x4_49_156_L.sms", "4x4x4_49_156_P.sms", "3x3x3_23_58_R.sms",
+        "2x2x2_7_DPS-accurate_L.sms", "4x4x4_48_rational_P.sms", "3o3o6_Toom4_P.sms", "3x3x6_40_DPS-accurate_P.sms",
+        "2o2o4_5_Toom3_P.sms", "4x4x4_48_accurate-CoB_R.sms", "3x4x7_63_rational_R.sms", "4o4o8_Toom5_P.sms"]
+
+
+def _plan(M):
+    from plinopt_amd import CSEPlan
+    pl = CSEPlan(M.m, M.n, M.rowptr, M.col, M.val, M.p, hbm=True)
+    assert pl.is_hbm
+    return pl
+
+
+@pytest.mark.parametrize("name", SOME)
+def test_hbm_variant_matches_oracle(hip, name):
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    plan = _plan(M)
+    n = 200
+    assert plan.cost_many(seed0=77, n=n) == tuple(M.cost_many(seed0=77, nseeds=n, nthreads=8))
+
+
+def test_hbm_variant_search_argmin(hip):
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), P)
+    plan = _plan(M)
+    for mode in (0, 1, 2):
+        assert plan.search(5, 1500, cost_mode=mode) == M.search(5, 1500, cost_mode=mode, nthreads=8)
+
+
+def test_hbm_variant_synthetic(hip):
+    from plinopt_amd import CSEPlan
+    for s in range(60):
+        m, n, rows = synth.small_valued(s, P)
+        rp, c, v = synth.to_csr(rows, P)
+        M = OracleMatrix(m, n, rp, c, v, P)
+        plan = CSEPlan(m, n, rp, c, v, P, hbm=True)
+        assert plan.cost_many(seed0=s, n=16) == tuple(M.cost_many(seed0=s, nseeds=16)), (s, rows)
+        plan.close()
+
+
+def test_rows_longer_than_the_wave_kernel_limit_select_hbm_automatically(hip):
+    """A 100-entry row does not fit the wave kernel (64 lanes per row): plo_cse_plan_create picks the
+    HBM family by itself; results still equal the oracle."""
+    import random
+    from plinopt_amd import CSEPlan
+    rng = random.Random(3)
+    rows = [{j: rng.choice([1, P - 1, 2, P - 2]) for j in range(100) if rng.random() < 0.8} for _ in range(12)]
+    rp, c, v = synth.to_csr(rows, P)
+    M = OracleMatrix(12, 100, rp, c, v, P)
+    plan = CSEPlan(12, 100, rp, c, v, P)
+    assert plan.is_hbm
+    assert plan.cost_many(seed0=0, n=24) == tuple(M.cost_many(seed0=0, nseeds=24, nthreads=8))
