@@ -125,7 +125,16 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
                           << (st.kernel_ms > 0 ? st.candidates / (st.kernel_ms * 1e-3) : 0.0) << " candidates/s" << std::endl;
             L.shutdown();
         }
-        if (!on_gpu) have = host_search(f, lM, seed0, loops, dops, seed);
+        if (!on_gpu) {
+            auto ts = std::chrono::steady_clock::now();
+            have = host_search(f, lM, seed0, loops, dops, seed);
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+            int nthr = 1;
+#ifdef _OPENMP
+            nthr = omp_get_max_threads();
+#endif
+            if (verbose > 0) std::clog << "# host search: " << loops << " candidates in " << dt << " s on " << nthr << " threads (index build included)" << std::endl;
+        }
         if (have) {
             Ops rops; std::string t = replay_text(f, lM, seed, rops);
             if (rops != dops) { std::cerr << "# \033[1;31mERROR: replay of seed " << seed << " gives " << rops.first << '|' << rops.second

@@ -279,7 +279,9 @@ int build_big_plan(plo_plan *pl)
 int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
 {
     // one workspace slice per resident workgroup
-    uint64_t want = std::min<uint64_t>(J.ncand, (uint64_t)g_cus * 4);
+    uint64_t per_cu = 4;
+    if (const char *e = getenv("PLO_BIG_WG_PER_CU")) per_cu = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    uint64_t want = std::min<uint64_t>(J.ncand, (uint64_t)g_cus * per_cu);
     if (const char *e = getenv("PLO_BIG_SLICES")) want = std::min<uint64_t>(want, strtoull(e, nullptr, 10));
     if (want == 0) want = 1;
     if (pl->ws_slices < want) {

@@ -16,36 +16,67 @@ def shard_range(seed0, nseeds, rank, world):
 
 
 def pack_key(adds, muls, seed_off, cost_mode=capi.COST_SUM_THEN_ADD):
-    """63-bit word, integer order == (cmpOpCount, seed) order: cost in the high 31 bits."""
+    """63-bit word whose integer order is the (cmpOpCount, seed) order:
+    [cost field 1 : 20 bits][cost field 2 : 20 bits][seed offset : 23 bits].
+    Returns None when a field does not fit (the caller then reduces in two stages)."""
     if cost_mode == capi.COST_ADD_THEN_MUL:
-        hi = (adds << 15) | muls
-        assert adds < (1 << 16) and muls < (1 << 15)
+        f1, f2 = adds, muls
     elif cost_mode == capi.COST_SUM:
-        hi = (adds + muls) << 15
+        f1, f2 = adds + muls, 0
     else:
-        hi = ((adds + muls) << 15) | adds
-        assert adds < (1 << 15)
-    assert hi < (1 << 31) and 0 <= seed_off < (1 << 32)
-    return (hi << 32) | seed_off
+        f1, f2 = adds + muls, adds
+    if f1 >= (1 << 20) or f2 >= (1 << 20) or not (0 <= seed_off < (1 << 23)):
+        return None
+    return (f1 << 43) | (f2 << 23) | seed_off
 
 
 def unpack_seed_off(word):
-    return word & 0xFFFFFFFF
+    return word & ((1 << 23) - 1)
+
+
+def cost_word(adds, muls, cost_mode=capi.COST_SUM_THEN_ADD):
+    """cost only (no seed), for the two-stage reduction"""
+    if cost_mode == capi.COST_ADD_THEN_MUL:
+        return (adds << 31) | muls
+    if cost_mode == capi.COST_SUM:
+        return (adds + muls) << 31
+    return ((adds + muls) << 31) | adds
 
 
 def allreduce_best(local, seed0, cost_mode=capi.COST_SUM_THEN_ADD, group=None, device=None):
-    """local = (adds, muls, seed) or None.  Returns the global winner's seed and packed word.
-    One all_reduce(MIN) of a single int64."""
+    """local = (adds, muls, seed) or None.  Returns (winning seed, reduced word).
+    ONE all_reduce(MIN) of a single int64 when (cost, seed offset) packs into 63 bits on every rank
+    (always the case for the workloads of bench.py); otherwise two 8-byte MIN all-reduces
+    (cost first, then the smallest seed among the ranks holding that cost)."""
     import torch
     import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    dev = device if device is not None else "cpu"
     word = INF
+    fits = 1
     if local is not None:
         adds, muls, seed = local
-        word = pack_key(adds, muls, seed - seed0, cost_mode)
-    t = torch.tensor([word], dtype=torch.int64, device=device if device is not None else "cpu")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        w = pack_key(adds, muls, seed - seed0, cost_mode)
+        if w is None:
+            fits = 0
+        else:
+            word = w
+    t = torch.tensor([word, -fits], dtype=torch.int64, device=dev)     # MIN of -fits == -1 iff every rank fits
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-    w = int(t.item())
-    if w == INF:
-        return None, w
-    return seed0 + unpack_seed_off(w), w
+    if int(t[1].item()) == -1 or (not multi and fits):
+        w = int(t[0].item())
+        return (None, w) if w == INF else (seed0 + unpack_seed_off(w), w)
+    # two-stage fallback: wide costs or far-apart seeds
+    c = INF if local is None else cost_word(local[0], local[1], cost_mode)
+    tc = torch.tensor([c], dtype=torch.int64, device=dev)
+    if multi:
+        dist.all_reduce(tc, op=dist.ReduceOp.MIN, group=group)
+    best_c = int(tc.item())
+    if best_c == INF:
+        return None, INF
+    sd = local[2] - seed0 if (local is not None and c == best_c) else INF
+    ts = torch.tensor([sd], dtype=torch.int64, device=dev)
+    if multi:
+        dist.all_reduce(ts, op=dist.ReduceOp.MIN, group=group)
+    return seed0 + int(ts.item()), best_c

@@ -23,6 +23,13 @@ for mode in (0, 1, 2):
     seed, word = allreduce_best(local, seed0, mode)
     exp = M.search(seed0, n, cost_mode=mode)
     assert seed == exp[2], (mode, seed, exp)
+# costs / seed offsets too wide for one word: two-stage reduction gives the same winner
+big0 = 10 ** 12
+s, cnt = shard_range(big0, 40, rank, world)
+local = M.search(s, cnt)
+seed, word = allreduce_best((local[0] + (1 << 20), local[1], local[2]), 0, 0)
+exp = M.search(big0, 40)
+assert seed == exp[2], (seed, exp)
 # a rank with an empty shard must not disturb the reduction
 s, cnt = shard_range(5, 1, rank, world)
 local = M.search(s, cnt) if cnt else None
@@ -61,4 +68,5 @@ def test_pack_key_order():
     assert pack_key(10, 2, 5) < pack_key(11, 1, 0) < pack_key(9, 4, 0)
     assert pack_key(10, 2, 5) < pack_key(10, 2, 6)
     assert pack_key(3, 100, 0, 1) < pack_key(4, 0, 0, 1)
-    assert pack_key(0, 0, 0) >= 0 and pack_key(32767, 0, 2 ** 32 - 1) < 2 ** 63
+    assert pack_key(0, 0, 0) >= 0 and pack_key(34409, 4546, 2 ** 23 - 1) < 2 ** 63     # config-5 sized costs fit
+    assert pack_key(2 ** 20, 0, 0) is None and pack_key(1, 1, 2 ** 23) is None          # -> two-stage reduction

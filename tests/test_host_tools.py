@@ -130,3 +130,21 @@ def test_both_host_engines_on_synthetic_triangle_cases(engine, tmp_path):
         rc, out, err = run([OPT, "-q", str(P), "--replay", "--seed", str(s), "--engine", engine, str(path)])
         assert rc == 0, err
         assert out == txt, (s, rows)
+
+
+def test_config5_host_engine_program_verifies(tmp_path):
+    """32x32x32_15096_L end to end on the host: the scalable engine's program for seed 6 computes the
+    matrix (SLPchecker) and its cost equals the committed golden value (~25 s)."""
+    import json
+    from plo_testlib import GOLDEN
+    sms = tmp_path / "l32.sms"
+    rc, out, err = run([CHK, "-q", str(P), os.path.join(DATA, "32x32x32_15096_L.slp")])
+    assert rc == 0
+    sms.write_text(out)
+    rc, prog, err = run([OPT, "-q", str(P), "--replay", "--seed", "6", str(sms)])
+    assert rc == 0, err
+    G = json.load(open(os.path.join(GOLDEN, "config5_costs.json")))
+    a, mu = G["costs"]["6"]
+    assert "# %d\tadditions" % a in err and "# %d\tmultiplications" % mu in err
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", str(sms)], stdin=prog)
+    assert rc == 0 and "SUCCESS" in err2 and ("%d,%d" % (a, mu)) in err2, err2
