@@ -259,12 +259,16 @@ int build_big_plan(plo_plan *pl)
     auto take = [&](uint64_t bytes) { uint64_t o = off; off = (off + bytes + 255) & ~255ull; return o; };
     B.o_tab = take(cap * 8); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
     B.o_len = take((uint64_t)m * 4); B.o_ucount = take(NC * 4); B.o_cntM = take(NC * 4);
-    B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 8); B.o_aff = take((uint64_t)m * 4);
+    B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 8); B.o_aff = take((uint64_t)m * 32);
     B.o_ncrptr = take((NC + 2) * 4); B.o_ncr = take(((uint64_t)nnz + 64) * 4);
     B.o_multc = take((uint64_t)multcap * 4); B.o_multv = take((uint64_t)multcap * 4);
     B.o_tcnt = take(NC * 4); B.o_tptr2 = take((NC + 2) * 4); B.o_tlist = take(((uint64_t)nnz + 64) * 4); B.o_cols2 = take(NC * 4);
     B.ws_stride = off;
-    pl->big_lds = (((B.maxf0 + 2u) & ~1u) + (PLO_BIG_THREADS / 64) * maxlen) * 4u;
+    // dynamic LDS: histogram + max(ProgramGen scratch, aggregation table of 2^aggbits u64)
+    B.aggbits = std::min(13u, std::max(6u, ceil_log2((uint32_t)std::min<uint64_t>(4 * pairs0 + 64, 1u << 13))));
+    if (const char *e = getenv("PLO_BIG_AGGBITS")) B.aggbits = (uint32_t)std::min(14l, std::max(6l, strtol(e, nullptr, 10)));
+    const uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, 2u << B.aggbits);
+    pl->big_lds = (((B.maxf0 + 2u) & ~1u) + scr_words) * 4u;
     if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
     HIPCHK(hipFuncSetAttribute((const void *)plo::cse_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
     if (!pl->d_err) HIPCHK(hipMalloc((void **)&pl->d_err, sizeof(uint32_t)));
@@ -310,6 +314,12 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     uint32_t err = 0;
     HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = pl->waves_per_wg; st->algo_bytes = pl->algo_bytes; }
+    if (getenv("PLO_BIG_STATS")) {
+        uint32_t hs[16] = {0};
+        if (hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "# big kernel (last candidate): steps %u, full scans %u, level rebuilds %u; phase us: level %u select %u rows %u sweep1 %u flush1 %u sweep2 %u flush2 %u tail %u\n",
+                    hs[0], hs[1], hs[2], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11]);
+    }
     if (err) {
         static const char *names[] = {"pair table", "frequency/row-count mismatch", "column bound", "level list", "window list", "multiplier list", "tie selection", "ProgramGen"};
         return fail(err == plo::BERR_COLS || err == plo::BERR_DM || err == plo::BERR_HL ? PLO_E_CAPACITY : PLO_E_INTERNAL,

@@ -30,14 +30,14 @@
 
 namespace plo {
 
-#define PLO_BIG_THREADS 256
+#define PLO_BIG_THREADS 512
 #define PLO_BIG_SELCAP 1024u
 #define PLO_GVB 16u
 #define PLO_GVMASK 0xFFFFull
 #define PLO_GEMPTY 0xFFFFFFFFFFFF0000ull
 
 struct BigPlan {
-    uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride;
+    uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride, aggbits;
     uint64_t mu;
     const uint32_t *rs, *col0, *val0, *inv0, *tptr, *trows, *ucount0, *hist0;
     const uint64_t *tab0;
@@ -144,6 +144,56 @@ __device__ __forceinline__ bool gtab_flag(uint64_t *tab, uint64_t key, uint32_t 
     return false;
 }
 
+// frequency[key] -= d; returns the frequency before (0 = key not found)
+__device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint32_t d, uint32_t hbits) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s = ghash(key, hbits);
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        uint64_t v = gload64(&tab[s]);
+        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], (unsigned long long)(0ull - (uint64_t)d)); return (uint32_t)(old & PLO_GVMASK); }
+        if (v == PLO_GEMPTY) return 0u;
+        s = (s + 1u) & mask;
+    }
+    return 0u;
+}
+// frequency[key] += d (claims an empty or dead slot); returns the frequency before, 0xFFFFFFFF = table full
+__device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint32_t d, uint32_t hbits) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s = ghash(key, hbits);
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        uint64_t v = gload64(&tab[s]);
+        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], (unsigned long long)d); return (uint32_t)(old & PLO_GVMASK); }
+        if ((v & PLO_GVMASK) == 0ull) {
+            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | d));
+            if (old == v) return 0u;
+            continue;
+        }
+        s = (s + 1u) & mask;
+    }
+    return 0xFFFFFFFFu;
+}
+
+// LDS aggregation table: the rows rewritten by one CSE step retire / create the same triples many times
+// (x21 on config 5); the duplicates are summed here and each distinct triple costs one global atomic.
+// key48<<16 | count16, open addressing, at most 16 probes; `false` = no room, the caller goes to HBM directly.
+#define PLO_AGG_PROBES 16u
+__device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_t key) {
+    volatile uint64_t *va = agg;
+    const uint32_t mask = (1u << aggbits) - 1u;
+    uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - aggbits));
+    for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
+        uint64_t v = va[s];
+        if ((v >> PLO_GVB) == key) { atomicAdd((unsigned long long *)&agg[s], 1ull); return true; }
+        if (v == PLO_GEMPTY) {
+            uint64_t old = atomicCAS((unsigned long long *)&agg[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | 1ull));
+            if (old == v) return true;
+            continue;                      // somebody took the slot: look at it again
+        }
+        s = (s + 1u) & mask; ++pr;
+    }
+    return false;
+}
+
 // position of column c in row [base, base+L) (sorted by column), or -1
 __device__ __forceinline__ int row_find(const uint32_t *col, uint32_t base, uint32_t L, uint32_t c) {
     uint32_t lo = 0, hi = L;
@@ -154,16 +204,18 @@ __device__ __forceinline__ int row_find(const uint32_t *col, uint32_t base, uint
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r; uint64_t kprime; uint64_t selkey;
+    unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
     uint32_t part[PLO_BIG_THREADS];
     uint64_t sel[PLO_BIG_SELCAP];
 };
 
 #define BSYNC() __syncthreads()
+#define PLO_STAMP(q_) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); sh.tph[q_] += t_ - tstamp; tstamp = t_; } } while (0)
 
 // ---------------------------------------------------------------------------
 // One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
 // ---------------------------------------------------------------------------
-__device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint32_t *errw)
+__device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, uint32_t *errw)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
     uint64_t *tab   = (uint64_t *)(ws + P.o_tab);
@@ -182,16 +234,19 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
     for (uint32_t i = tid; i < m; i += nth) len[i] = P.rs[i + 1] - P.rs[i];
     for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; }
     for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = P.hist0[f];
+    for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = PLO_GEMPTY;
     if (tid == 0) {
         uint64_t x = seed + 0x9E3779B97F4A7C15ull;
         x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
         sh.rng = 1u + (uint32_t)(x % 2147483646ull);
         sh.M = P.M0; sh.theta = P.M0 + 1u; sh.ncols = n; sh.nbadd = 0; sh.nbmul = 0; sh.nmult = 0; sh.dmcount = 0; sh.hlcount = 0;
+        for (int q = 0; q < 8; ++q) sh.tph[q] = 0;
         sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0;
     }
     __threadfence(); BSYNC();
 
     bool need_rebuild = true;
+    unsigned long long tstamp = wall_clock64();
     for (;;) {
         if (sh.errflag) break;
         // ---- level bookkeeping: lower M while empty (thread 0), decide on a window rescan
@@ -243,6 +298,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             __threadfence(); BSYNC();
             if (sh.errflag) break;
         }
+        PLO_STAMP(0);
         // ---- tie pick (OneSub :244-265): k-th triple of frequency M in map order
         const uint32_t ncols = sh.ncols;
         {
@@ -310,6 +366,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             if (sh.errflag) break;
         }
         const uint64_t key = sh.selkey;
+        PLO_STAMP(1);
         const uint32_t r = (uint32_t)(key & ((1ull << rb) - 1ull)), b = (uint32_t)(key >> rb) & ((1u << P.bb) - 1u), a = (uint32_t)(key >> abits);
         const uint32_t lm = ncols;
         if (lm + 1u >= P.NCmax) { if (tid == 0) atomicMax(&sh.errflag, (uint32_t)BERR_COLS); BSYNC(); break; }
@@ -332,45 +389,69 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 const uint32_t va = val[base + pa], vb = val[base + pb];
                 if (vb != bmul(r, va, p, mu)) continue;
                 const uint32_t idx = atomicAdd(&sh.naff, 1u);
-                aff[idx] = i;
-                if (idx == 0) sh.invr = bmul(va, inv[base + pb], p, mu);   // 1/r
+                const uint32_t ia = inv[base + pa], ib = inv[base + pb];
+                uint32_t *rec = aff + 8u * idx;                             // record: row, positions and values of the two entries
+                rec[0] = i; rec[1] = (uint32_t)pa; rec[2] = (uint32_t)pb; rec[3] = va; rec[4] = ia; rec[5] = vb; rec[6] = ib;
+                if (idx == 0) sh.invr = bmul(va, ib, p, mu);               // 1/r
             }
         }
         __threadfence(); BSYNC();
         const uint32_t naff = sh.naff;
+        PLO_STAMP(2);
         if (naff != M) { if (tid == 0) atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); BSYNC(); break; }   // frequency must equal the row count
         // sweep 1: retire the old pairs of the affected rows (:115-118)
         for (uint32_t q = wave; q < naff; q += nwaves) {
-            const uint32_t i = aff[q], base = P.rs[i], L = len[i];
-            const int pa = row_find(col, base, L, a), pb = row_find(col, base, L, b);
-            const uint32_t va = val[base + pa], ia = inv[base + pa], vb = val[base + pb], ib = inv[base + pb];
+            const uint32_t *rec = aff + 8u * q;
+            const uint32_t i = rec[0], base = P.rs[i], L = len[i];
+            const int pa = (int)rec[1], pb = (int)rec[2];
+            const uint32_t va = rec[3], ia = rec[4], vb = rec[5], ib = rec[6];
             for (uint32_t z = lane; z < L; z += 64u) {
                 if ((int)z == pa || (int)z == pb) continue;
                 const uint32_t c = col[base + z], v = val[base + z], iv = inv[base + z];
                 const uint64_t k1 = c < a ? BKEY(c, a, bmul(va, iv, p, mu)) : BKEY(a, c, bmul(v, ia, p, mu));
                 const uint64_t k2 = c < b ? BKEY(c, b, bmul(vb, iv, p, mu)) : BKEY(b, c, bmul(v, ib, p, mu));
-                uint32_t o1 = gtab_dec(tab, k1, hbits), o2 = gtab_dec(tab, k2, hbits);
-                if (!o1 || !o2) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-                atomicSub(&hist[o1], 1u); if (o1 > 1u) atomicAdd(&hist[o1 - 1u], 1u);
-                if (o1 == M) atomicSub(&cntM[c < a ? c : a], 1u);
-                atomicSub(&hist[o2], 1u); if (o2 > 1u) atomicAdd(&hist[o2 - 1u], 1u);
-                if (o2 == M) atomicSub(&cntM[c < b ? c : b], 1u);
+                if (!agg_add(agg, aggbits, k1)) {
+                    uint32_t o1 = gtab_dec(tab, k1, hbits);
+                    if (!o1) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                    atomicSub(&hist[o1], 1u); if (o1 > 1u) atomicAdd(&hist[o1 - 1u], 1u);
+                    if (o1 == M) atomicSub(&cntM[c < a ? c : a], 1u);
+                }
+                if (!agg_add(agg, aggbits, k2)) {
+                    uint32_t o2 = gtab_dec(tab, k2, hbits);
+                    if (!o2) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                    atomicSub(&hist[o2], 1u); if (o2 > 1u) atomicAdd(&hist[o2 - 1u], 1u);
+                    if (o2 == M) atomicSub(&cntM[c < b ? c : b], 1u);
+                }
             }
-            if (lane == 0) {
+            if (lane == 0 && !agg_add(agg, aggbits, key)) {
                 uint32_t o = gtab_dec(tab, key, hbits);
                 if (!o) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
                 else { atomicSub(&hist[o], 1u); if (o > 1u) atomicAdd(&hist[o - 1u], 1u); if (o == M) atomicSub(&cntM[a], 1u); }
             }
         }
+        BSYNC();
+        PLO_STAMP(3);
+        // flush the summed retirements: one global atomic per distinct triple
+        for (uint32_t s = tid; s < (1u << aggbits); s += nth) {
+            const uint64_t v = agg[s];
+            if (v == PLO_GEMPTY) continue;
+            agg[s] = PLO_GEMPTY;
+            const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+            const uint32_t o = gtab_subn(tab, k, d, hbits);
+            if (o < d) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+            atomicSub(&hist[o], 1u); if (o > d) atomicAdd(&hist[o - d], 1u);
+            if (o == M) atomicSub(&cntM[(uint32_t)(k >> abits)], 1u);
+        }
         __threadfence(); BSYNC();
+        PLO_STAMP(4);
         if (sh.errflag) break;
         // sweep 2: rewrite the rows, insert the pairs with the new column (:96-110, :132-142)
         for (uint32_t q = wave; q < naff; q += nwaves) {
-            const uint32_t i = aff[q], base = P.rs[i], L = len[i];
-            const int pa = row_find(col, base, L, a), pb = row_find(col, base, L, b);
-            const int p0 = (l0 == a) ? pa : pb;
-            const uint32_t coeff = val[base + p0], icoeff = inv[base + p0];
-            const bool ua = babsone(val[base + pa], p), ub = babsone(val[base + pb], p);
+            const uint32_t *rec = aff + 8u * q;
+            const uint32_t i = rec[0], base = P.rs[i], L = len[i];
+            const int pa = (int)rec[1], pb = (int)rec[2];
+            const uint32_t coeff = (l0 == a) ? rec[3] : rec[5], icoeff = (l0 == a) ? rec[4] : rec[6];
+            const bool ua = babsone(rec[3], p), ub = babsone(rec[5], p);
             for (uint32_t z0 = 0; z0 < L; z0 += 64u) {
                 const uint32_t z = z0 + lane; const bool have = z < L;
                 uint32_t c = 0, v = 0, iv = 0;
@@ -380,6 +461,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                     const uint32_t np = base + z - ((int)z > pa ? 1u : 0u) - ((int)z > pb ? 1u : 0u);
                     col[np] = c; val[np] = v; inv[np] = iv;
                     const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu));
+                    if (agg_add(agg, aggbits, nk)) continue;
                     const uint32_t nc = gtab_inc(tab, nk, hbits);
                     if (!nc) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
                     if (nc > P.maxf0) { atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
@@ -402,10 +484,32 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (babsone(coeff, p)) atomicAdd(&ucount[lm], 1u);
             }
         }
+        BSYNC();
+        PLO_STAMP(5);
+        // flush the summed insertions
+        for (uint32_t s = tid; s < (1u << aggbits); s += nth) {
+            const uint64_t v = agg[s];
+            if (v == PLO_GEMPTY) continue;
+            agg[s] = PLO_GEMPTY;
+            const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+            const uint32_t o = gtab_addn(tab, k, d, hbits);
+            if (o == 0xFFFFFFFFu) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+            const uint32_t nc = o + d;
+            if (nc > P.maxf0 || nc > M) { atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
+            if (o > 0u) atomicSub(&hist[o], 1u);
+            atomicAdd(&hist[nc], 1u);
+            if (o < sh.theta && nc >= sh.theta) { uint32_t idx = atomicAdd(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = k; else sh.hlbad = 1u; }
+            if (nc == M) {
+                atomicAdd(&cntM[(uint32_t)(k >> abits)], 1u);
+                uint32_t idx = atomicAdd(&sh.dmcount, 1u);
+                if (idx < P.dmcap) DM[idx] = k; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
+            }
+        }
+        PLO_STAMP(6);
         // row list of the new column, multiplier reuse (:153-169), counters
         {
             const uint32_t o = ncrptr[lm - n];
-            for (uint32_t k = tid; k < naff; k += nth) ncr[o + k] = aff[k];
+            for (uint32_t k = tid; k < naff; k += nth) ncr[o + k] = aff[8u * k];
             if (tid == 0) { ncrptr[lm - n + 1u] = o + naff; sh.part[0] = 0; }
         }
         BSYNC();
@@ -424,6 +528,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         }
         if (tid == 0) { ++sh.nbadd; ++sh.steps; sh.ncols = lm + 1u; }      // :292, :190-191
         __threadfence(); BSYNC();
+        PLO_STAMP(7);
     }
     BSYNC();
     if (sh.errflag) { if (tid == 0) atomicMax(errw, sh.errflag); return 0; }
@@ -671,11 +776,12 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
 
 __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, BigJob J)
 {
-    extern __shared__ uint32_t bigdyn[];                 // hist[maxf0+1] then per-wave scratch (nwaves * stride)
+    extern __shared__ __attribute__((aligned(16))) uint32_t bigdyn[];                 // hist[maxf0+1] then per-wave scratch (nwaves * stride)
     __shared__ BigShared sh;
     __shared__ unsigned long long cur;
     uint32_t *hist = bigdyn;
-    uint32_t *scratch = bigdyn + ((P.maxf0 + 2u) & ~1u);
+    uint32_t *scratch = bigdyn + ((P.maxf0 + 2u) & ~1u);           // ProgramGen scratch and the CSE aggregation table share this space
+    uint64_t *agg = (uint64_t *)scratch;
     uint8_t *ws = P.ws + (uint64_t)blockIdx.x * P.ws_stride;
     uint64_t best = ~0ull;
     for (;;) {
@@ -685,7 +791,7 @@ __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, Big
         __syncthreads();
         if (c >= J.ncand) break;
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        uint64_t ok = big_candidate(P, ws, seed, sh, hist, J.err);
+        uint64_t ok = big_candidate(P, ws, seed, sh, hist, agg, P.aggbits, J.err);
         uint64_t res = 0;
         __syncthreads();
         if (ok) res = big_program_gen(P, ws, sh, scratch, J.err);
@@ -695,7 +801,7 @@ __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, Big
             const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
-            if (J.stats) { J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; }
+            if (J.stats) { J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull); }   // phase times in us
             // 64-bit cost word: the op-counts of config 5 do not fit 16 bits
             uint64_t ck;
             switch (J.cost_mode) { case 1: ck = ((uint64_t)a << 20) | mu_; break; case 2: ck = (uint64_t)(a + mu_) << 20; break; default: ck = ((uint64_t)(a + mu_) << 20) | a; }
