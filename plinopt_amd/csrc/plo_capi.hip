@@ -178,7 +178,7 @@ int build_plan(plo_plan *pl)
 template <class T> int upload(plo_plan *pl, const std::vector<T> &v, const T **dst)
 {
     void *d = nullptr;
-    HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T) + 64));      // slack: the kernel copies in 16-byte units
     if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     pl->big_bufs.push_back(d);
     *dst = (const T *)d;
@@ -200,8 +200,8 @@ int build_big_plan(plo_plan *pl)
     if (rb > 30 || (48u - rb) / 2u < 2u) return fail(PLO_E_CAPACITY, "modulus too large for the 48-bit pair key");
     const uint32_t bbmax = (48u - rb) / 2u;
     uint64_t NC = (uint64_t)n + naive / 2 + 2;
-    if (n + 2ull > (1ull << bbmax)) return fail(PLO_E_CAPACITY, "too many columns for the 48-bit pair key");
-    NC = std::min<uint64_t>(NC, 1ull << bbmax);            // exceeding it at run time is reported by the device (BERR_COLS)
+    if (n + 2ull > (1ull << bbmax) || n + 2ull > 32768ull) return fail(PLO_E_CAPACITY, "too many columns for the HBM-resident kernel (48-bit pair key / 32768 columns)");
+    NC = std::min<uint64_t>(std::min<uint64_t>(NC, 1ull << bbmax), 32768);   // 32768 = 512 LDS block sums x 64; exceeding it at run time is reported by the device (BERR_COLS)
     const uint32_t bb = ceil_log2((uint32_t)NC);
     if (m >= 0x7FFFu) return fail(PLO_E_CAPACITY, "more than 32766 rows: frequency does not fit the table slot");
     if (maxlen > 8192) return fail(PLO_E_CAPACITY, "row longer than 8192 entries");
@@ -248,7 +248,7 @@ int build_big_plan(plo_plan *pl)
     }
     B.m = m; B.n = n; B.nnz = nnz; B.p = p; B.NCmax = (uint32_t)NC; B.hbits = hbits; B.rb = rb; B.bb = bb; B.unit = unit ? 1u : 0u;
     B.maxf0 = maxf + 1; B.M0 = maxf; B.multcap = multcap; B.scr_stride = maxlen;
-    B.dmcap = (uint32_t)std::min<uint64_t>(1u << 20, cap); B.hlcap = (uint32_t)std::min<uint64_t>(1u << 21, cap);
+    B.dmcap = (uint32_t)std::min<uint64_t>(1u << 20, cap); B.hlcap = (uint32_t)std::min<uint64_t>(1u << 18, cap);   // window list: <= hlcap/2 keys per window, ping-pong halves
     B.mu = (~0ull) / p;
     int rc;
     if ((rc = upload(pl, pl->rowptr, &B.rs)) || (rc = upload(pl, pl->col, &B.col0)) || (rc = upload(pl, pl->val, &B.val0)) ||
@@ -259,7 +259,7 @@ int build_big_plan(plo_plan *pl)
     auto take = [&](uint64_t bytes) { uint64_t o = off; off = (off + bytes + 255) & ~255ull; return o; };
     B.o_tab = take(cap * 8); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
     B.o_len = take((uint64_t)m * 4); B.o_ucount = take(NC * 4); B.o_cntM = take(NC * 4);
-    B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 8); B.o_aff = take((uint64_t)m * 32);
+    B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 16); B.o_aff = take((uint64_t)m * 32);
     B.o_ncrptr = take((NC + 2) * 4); B.o_ncr = take(((uint64_t)nnz + 64) * 4);
     B.o_multc = take((uint64_t)multcap * 4); B.o_multv = take((uint64_t)multcap * 4);
     B.o_tcnt = take(NC * 4); B.o_tptr2 = take((NC + 2) * 4); B.o_tlist = take(((uint64_t)nnz + 64) * 4); B.o_cols2 = take(NC * 4);

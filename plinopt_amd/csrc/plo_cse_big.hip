@@ -31,7 +31,7 @@
 namespace plo {
 
 #define PLO_BIG_THREADS 512
-#define PLO_BIG_SELCAP 1024u
+#define PLO_BIG_SELCAP 512u
 #define PLO_GVB 16u
 #define PLO_GVMASK 0xFFFFull
 #define PLO_GEMPTY 0xFFFFFFFFFFFF0000ull
@@ -204,8 +204,9 @@ __device__ __forceinline__ int row_find(const uint32_t *col, uint32_t base, uint
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r; uint64_t kprime; uint64_t selkey;
+    uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
-    uint32_t part[PLO_BIG_THREADS];
+    uint32_t part[8];
     uint64_t sel[PLO_BIG_SELCAP];
 };
 
@@ -229,8 +230,18 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
 #define BKEY(a_, b_, r_) (((uint64_t)(a_) << abits) | ((uint64_t)(b_) << rb) | (uint64_t)(r_))
 
     // ---- load the candidate image
-    for (uint64_t s = tid; s < cap; s += nth) tab[s] = P.tab0[s];
-    for (uint32_t k = tid; k < P.nnz; k += nth) { col[k] = P.col0[k]; val[k] = P.val0[k]; inv[k] = P.inv0[k]; }
+    {   // 16-byte copies, 4 in flight per thread (all buffers are 256-byte aligned, sizes padded by the host)
+        const uint4 *s4 = (const uint4 *)P.tab0; uint4 *d4 = (uint4 *)tab; const uint64_t n4 = cap >> 1;
+        for (uint64_t s = tid; s < n4; s += 4ull * nth) {
+            uint4 x0 = s4[s], x1, x2, x3; const bool b1 = s + nth < n4, b2 = s + 2ull * nth < n4, b3 = s + 3ull * nth < n4;
+            if (b1) x1 = s4[s + nth]; if (b2) x2 = s4[s + 2ull * nth]; if (b3) x3 = s4[s + 3ull * nth];
+            d4[s] = x0; if (b1) d4[s + nth] = x1; if (b2) d4[s + 2ull * nth] = x2; if (b3) d4[s + 3ull * nth] = x3;
+        }
+        const uint32_t q4 = (P.nnz + 3u) >> 2;
+        const uint4 *c4 = (const uint4 *)P.col0, *v4 = (const uint4 *)P.val0, *i4 = (const uint4 *)P.inv0;
+        uint4 *dc = (uint4 *)col, *dv = (uint4 *)val, *di = (uint4 *)inv;
+        for (uint32_t k = tid; k < q4; k += nth) { uint4 x = c4[k], y = v4[k], z = i4[k]; dc[k] = x; dv[k] = y; di[k] = z; }
+    }
     for (uint32_t i = tid; i < m; i += nth) len[i] = P.rs[i + 1] - P.rs[i];
     for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; }
     for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = P.hist0[f];
@@ -272,28 +283,42 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 }
                 BSYNC();
                 const uint32_t th = sh.theta;
-                for (uint64_t s = tid; s < cap; s += nth) {
-                    uint64_t v = gload64(&tab[s]);
-                    if ((uint32_t)(v & PLO_GVMASK) >= th && v != PLO_GEMPTY) {
-                        uint32_t idx = atomicAdd(&sh.hlcount, 1u);
-                        if (idx < P.hlcap) HL[idx] = v >> PLO_GVB; else atomicMax(&sh.errflag, (uint32_t)BERR_HL);
-                    }
+                for (uint64_t s = tid; s < cap; s += 4ull * nth) {             // 4 independent loads in flight per thread
+                    uint64_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (s + (uint64_t)u * nth < cap) ? gload64(&tab[s + (uint64_t)u * nth]) : PLO_GEMPTY;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if ((uint32_t)(v[u] & PLO_GVMASK) >= th && v[u] != PLO_GEMPTY) {
+                            uint32_t idx = atomicAdd(&sh.hlcount, 1u);
+                            if (idx < P.hlcap) HL[idx] = v[u] >> PLO_GVB; else atomicMax(&sh.errflag, (uint32_t)BERR_HL);
+                        }
                 }
                 BSYNC();
             }
-            // per-column counters and key list of the current level from the window list
+            // per-column counters and key list of the current level from the window list; keys that fell below
+            // the window are dropped from it (they can never come back)
             for (uint32_t c = tid; c < sh.ncols; c += nth) cntM[c] = 0u;
-            if (tid == 0) { sh.dmcount = 0; ++sh.rebuilds; }
-            __threadfence(); BSYNC();
+            for (uint32_t c = tid; c < 512u; c += nth) sh.cblk[c] = 0u;
             const uint32_t hn = sh.hlcount < P.hlcap ? sh.hlcount : P.hlcap;
+            __threadfence(); BSYNC();
+            if (tid == 0) { sh.dmcount = 0; sh.hlcount = 0; ++sh.rebuilds; }
+            BSYNC();
+            uint64_t *HL2 = HL + P.hlcap;                                       // ping-pong halves of the window list
+            const uint32_t th2 = sh.theta;
             for (uint32_t k = tid; k < hn; k += nth) {
                 const uint64_t key = HL[k];
-                if (gtab_find(tab, key, hbits) == M) {
-                    atomicAdd(&cntM[(uint32_t)(key >> abits)], 1u);
+                const uint32_t c = gtab_find(tab, key, hbits);
+                if (c >= th2) HL2[atomicAdd(&sh.hlcount, 1u)] = key;
+                if (c == M) {
+                    const uint32_t fc = (uint32_t)(key >> abits);
+                    atomicAdd(&cntM[fc], 1u); atomicAdd(&sh.cblk[fc >> 6], 1u);
                     uint32_t idx = atomicAdd(&sh.dmcount, 1u);
                     if (idx < P.dmcap) DM[idx] = key; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
                 }
             }
+            __threadfence(); BSYNC();
+            { const uint32_t hn2 = sh.hlcount; for (uint32_t k = tid; k < hn2; k += nth) HL[k] = HL2[k]; }
             need_rebuild = false;
             __threadfence(); BSYNC();
             if (sh.errflag) break;
@@ -302,25 +327,27 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         // ---- tie pick (OneSub :244-265): k-th triple of frequency M in map order
         const uint32_t ncols = sh.ncols;
         {
-            const uint32_t chunk = (ncols + nth - 1u) / nth;
-            uint32_t s0 = tid * chunk, acc = 0;
-            for (uint32_t c = s0; c < s0 + chunk && c < ncols; ++c) acc += gload32(&cntM[c]);
-            sh.part[tid] = acc;
-            BSYNC();
-            if (tid == 0) {
-                const uint32_t T = hist[M];
-                uint64_t k = 0;
-                if (T > 1u) { uint64_t x = 950706376ull * (uint64_t)sh.rng; sh.rng = (uint32_t)(x % 2147483647ull); k = sh.rng % T; }
-                uint32_t t = 0; uint64_t run = 0;
-                for (; t < nth; ++t) { if (k < run + sh.part[t]) break; run += sh.part[t]; }
-                if (t >= nth) { atomicMax(&sh.errflag, (uint32_t)BERR_SEL); sh.a = 0; sh.kprime = 0; }
-                else {
-                    uint32_t c = t * chunk;
-                    for (; c < ncols; ++c) { uint32_t q = gload32(&cntM[c]); if (k < run + q) break; run += q; }
-                    if (c >= ncols) atomicMax(&sh.errflag, (uint32_t)BERR_SEL);
-                    sh.a = c < ncols ? c : 0u; sh.kprime = k - run;
+            if (wave == 0) {
+                // block of 64 first columns from the LDS block sums (thread 0), then one wave-wide load of that block
+                uint32_t blk = 0; uint64_t k = 0, run = 0;
+                if (lane == 0) {
+                    const uint32_t T = hist[M];
+                    if (T > 1u) { uint64_t x = 950706376ull * (uint64_t)sh.rng; sh.rng = (uint32_t)(x % 2147483647ull); k = sh.rng % T; }
+                    const uint32_t nb = (ncols + 63u) >> 6;
+                    for (; blk < nb; ++blk) { const uint32_t q = sh.cblk[blk]; if (k < run + q) break; run += q; }
+                    if (blk >= nb) { atomicMax(&sh.errflag, (uint32_t)BERR_SEL); blk = 0; }
+                    sh.sel_n = 0; sh.sel_over = 0;
                 }
-                sh.sel_n = 0; sh.sel_over = 0;
+                blk = (uint32_t)__shfl((int)blk, 0);
+                const uint32_t c = blk * 64u + lane;
+                uint32_t q = c < ncols ? gload32(&cntM[c]) : 0u, incl = q;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += t; }
+                const uint64_t kk = (((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k >> 32), 0)) << 32 | (uint32_t)__shfl((int)(uint32_t)k, 0))
+                                    - (((uint64_t)(uint32_t)__shfl((int)(uint32_t)(run >> 32), 0)) << 32 | (uint32_t)__shfl((int)(uint32_t)run, 0));
+                const uint64_t hm = __ballot(kk < (uint64_t)incl);
+                if (!hm) { if (lane == 0) atomicMax(&sh.errflag, (uint32_t)BERR_SEL); }
+                else if (lane == (uint32_t)__builtin_ctzll(hm)) { sh.a = c; sh.kprime = kk - (uint64_t)(incl - q); }
             }
             BSYNC();
             if (sh.errflag) break;
@@ -414,19 +441,19 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                     uint32_t o1 = gtab_dec(tab, k1, hbits);
                     if (!o1) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
                     atomicSub(&hist[o1], 1u); if (o1 > 1u) atomicAdd(&hist[o1 - 1u], 1u);
-                    if (o1 == M) atomicSub(&cntM[c < a ? c : a], 1u);
+                    if (o1 == M) { atomicSub(&cntM[c < a ? c : a], 1u); atomicSub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
                 }
                 if (!agg_add(agg, aggbits, k2)) {
                     uint32_t o2 = gtab_dec(tab, k2, hbits);
                     if (!o2) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
                     atomicSub(&hist[o2], 1u); if (o2 > 1u) atomicAdd(&hist[o2 - 1u], 1u);
-                    if (o2 == M) atomicSub(&cntM[c < b ? c : b], 1u);
+                    if (o2 == M) { atomicSub(&cntM[c < b ? c : b], 1u); atomicSub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
                 }
             }
             if (lane == 0 && !agg_add(agg, aggbits, key)) {
                 uint32_t o = gtab_dec(tab, key, hbits);
                 if (!o) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
-                else { atomicSub(&hist[o], 1u); if (o > 1u) atomicAdd(&hist[o - 1u], 1u); if (o == M) atomicSub(&cntM[a], 1u); }
+                else { atomicSub(&hist[o], 1u); if (o > 1u) atomicAdd(&hist[o - 1u], 1u); if (o == M) { atomicSub(&cntM[a], 1u); atomicSub(&sh.cblk[a >> 6], 1u); } }
             }
         }
         BSYNC();
@@ -440,7 +467,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             const uint32_t o = gtab_subn(tab, k, d, hbits);
             if (o < d) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
             atomicSub(&hist[o], 1u); if (o > d) atomicAdd(&hist[o - d], 1u);
-            if (o == M) atomicSub(&cntM[(uint32_t)(k >> abits)], 1u);
+            if (o == M) { atomicSub(&cntM[(uint32_t)(k >> abits)], 1u); atomicSub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
         }
         __threadfence(); BSYNC();
         PLO_STAMP(4);
@@ -469,7 +496,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                     atomicAdd(&hist[nc], 1u);
                     if (nc == sh.theta) { uint32_t idx = atomicAdd(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = nk; else sh.hlbad = 1u; }
                     if (nc == M) {
-                        atomicAdd(&cntM[c], 1u);
+                        atomicAdd(&cntM[c], 1u); atomicAdd(&sh.cblk[c >> 6], 1u);
                         uint32_t idx = atomicAdd(&sh.dmcount, 1u);
                         if (idx < P.dmcap) DM[idx] = nk; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
                     }
@@ -500,7 +527,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             atomicAdd(&hist[nc], 1u);
             if (o < sh.theta && nc >= sh.theta) { uint32_t idx = atomicAdd(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = k; else sh.hlbad = 1u; }
             if (nc == M) {
-                atomicAdd(&cntM[(uint32_t)(k >> abits)], 1u);
+                atomicAdd(&cntM[(uint32_t)(k >> abits)], 1u); atomicAdd(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u);
                 uint32_t idx = atomicAdd(&sh.dmcount, 1u);
                 if (idx < P.dmcap) DM[idx] = k; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
             }
