@@ -101,7 +101,7 @@ int build_plan(plo_plan *pl)
     pl->pairs0 = pairs0; pl->distinct0 = pm.size();
     pl->algo_bytes = 8ull * nnz + 12ull * pairs0 + 8ull;   // B_cand, SURVEY.md 8(d)
     uint32_t cap = 64;
-    while (cap < pl->cap_scale * (uint32_t)pm.size() + 16u) cap <<= 1;
+    while (cap < (pl->cap_scale * (uint32_t)pm.size() * 3u) / 4u + 16u) cap <<= 1;   // 1.5x the initial triples (cap_scale starts at 2); a full table is detected on the device and the launch repeated with more
     const uint32_t hbits = ceil_log2(cap);
 
     P.m = m; P.n = n; P.nnz = nnz; P.p = p; P.NC = (uint32_t)NC; P.cap = cap; P.hbits = hbits;
@@ -153,10 +153,16 @@ int build_plan(plo_plan *pl)
     rs[m] = (uint16_t)nnz;
 
     // waves per workgroup / LDS
-    uint32_t W = 4;
-    while (W > 1 && P.rs_bytes + W * P.region_bytes > g_lds_max) W >>= 1;
-    if (P.rs_bytes + W * P.region_bytes > g_lds_max)
+    // waves (= candidates) per workgroup: the choice that puts most waves on a CU
+    if (P.rs_bytes + P.region_bytes > g_lds_max)
         return fail(PLO_E_CAPACITY, "candidate state does not fit the 160 KiB LDS of one CU");
+    uint32_t W = 1, bestw = 0;
+    for (uint32_t w : {4u, 2u, 1u}) {
+        const uint32_t lds = P.rs_bytes + w * P.region_bytes;
+        if (lds > g_lds_max) continue;
+        const uint32_t waves = std::min<uint32_t>(32u, (uint32_t)(g_lds_max / lds) * w);
+        if (waves > bestw) { bestw = waves; W = w; }
+    }
     pl->waves_per_wg = W; pl->lds_bytes = P.rs_bytes + W * P.region_bytes;
 
     if (pl->d_tmpl) { (void)hipFree(pl->d_tmpl); pl->d_tmpl = nullptr; }
