@@ -100,6 +100,18 @@ int plo_cse_cost_many_plan(plo_plan_t *plan, const uint64_t *seeds, uint64_t see
 int plo_cse_cost_many(const plo_csr_t *A, uint32_t p, const uint64_t *seeds, uint64_t seed0,
                       uint64_t n, uint32_t *adds, uint32_t *muls);
 
+/* Two matrices per candidate, one random stream.  Replaces the body of the restart loop of
+ * LUOptimiser, include/plinopt_optimize.inl:1056-1100: Optimizer() on a copy of U (:1068) and then
+ * on a copy of L (:1072), op-counts added (:1078-1079), best kept under cmpOpCount (:1081-1099).
+ * Both matrices must fit the LDS-resident kernel. */
+typedef struct plo_chain plo_chain_t;
+int plo_cse_chain_create(const plo_csr_t *first, const plo_csr_t *second, uint32_t p, plo_chain_t **chain);
+int plo_cse_chain_destroy(plo_chain_t *chain);
+int plo_cse_chain_search(plo_chain_t *chain, uint64_t seed0, uint64_t nseeds, int cost_mode,
+                         plo_best_t *out, plo_stats_t *stats);
+int plo_cse_chain_cost_many(plo_chain_t *chain, const uint64_t *seeds, uint64_t seed0, uint64_t n,
+                            uint32_t *adds, uint32_t *muls, plo_stats_t *stats);
+
 /* Pack / unpack the (cost, seed) word used by the grid reduction and by the
  * single 8-byte MIN all-reduce across ranks (the `#pragma omp critical`
  * best-so-far of include/plinopt_optimize.inl:1214-1237).  seed_off is the

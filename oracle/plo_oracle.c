@@ -445,6 +445,25 @@ int plo_oracle_optimizer(uint32_t m, uint32_t n, const uint32_t *rowptr, const u
     return 0;
 }
 
+/* LUOptimiser restart body, plinopt_optimize.inl:1056-1100: Optimizer() on U (:1068) then on L (:1072) with
+ * the thread's generator running on; op-counts added (:1078-1079).  Two CSR matrices, one stream per seed.
+ * texts (optional, 2 malloc'd strings) use the letters of the reference: ('v','t','r') then ('x','v','g'). */
+int plo_oracle_chain(uint32_t m1, uint32_t n1, const uint32_t *rp1, const uint32_t *c1, const uint32_t *v1,
+                     uint32_t m2, uint32_t n2, const uint32_t *rp2, const uint32_t *c2, const uint32_t *v2,
+                     uint32_t p, uint64_t seed, uint32_t *adds, uint32_t *muls, char **text1, char **text2) {
+    if (p < 2) return -1;
+    cand_t A; cand_load(&A, m1, n1, rp1, c1, v1, p, seed, "vtri", text1 != NULL);
+    optimizer(&A);
+    cand_t B; cand_load(&B, m2, n2, rp2, c2, v2, p, seed, "xvgi", text2 != NULL);
+    B.rng = A.rng;                                    /* the generator keeps running */
+    optimizer(&B);
+    *adds = A.nbadd + B.nbadd; *muls = A.nbmul + B.nbmul;
+    if (text1) { if (!A.out.s) { A.out.s = (char *)xrealloc(NULL, 1); A.out.s[0] = 0; } *text1 = A.out.s; }
+    if (text2) { if (!B.out.s) { B.out.s = (char *)xrealloc(NULL, 1); B.out.s[0] = 0; } *text2 = B.out.s; }
+    cand_free(&A); cand_free(&B);
+    return 0;
+}
+
 int plo_oracle_cost_many(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col,
                          const uint32_t *val, uint32_t p, const uint64_t *seeds, uint64_t seed0,
                          uint64_t nseeds, uint32_t *adds, uint32_t *muls, int nthreads) {

@@ -45,6 +45,12 @@ int plo_oracle_optimizer(uint32_t m, uint32_t n, const uint32_t *rowptr,
                          uint64_t seed, const char letters[4],
                          uint32_t *adds, uint32_t *muls, char **text);
 
+/* LUOptimiser restart body (plinopt_optimize.inl:1056-1100): Optimizer() on the first matrix, then on the
+ * second with the generator running on; (adds, muls) summed.  text1/text2 optional (malloc'd). */
+int plo_oracle_chain(uint32_t m1, uint32_t n1, const uint32_t *rp1, const uint32_t *c1, const uint32_t *v1,
+                     uint32_t m2, uint32_t n2, const uint32_t *rp2, const uint32_t *c2, const uint32_t *v2,
+                     uint32_t p, uint64_t seed, uint32_t *adds, uint32_t *muls, char **text1, char **text2);
+
 /* Costs of many seeds (count only).  OpenMP-parallel over seeds when
  * nthreads > 1.  seeds == NULL means seed0, seed0+1, ... */
 int plo_oracle_cost_many(uint32_t m, uint32_t n, const uint32_t *rowptr,

@@ -20,6 +20,7 @@ EXPORTS = [
     "plo_cse_plan_create", "plo_cse_plan_create_ex", "plo_cse_plan_is_hbm", "plo_cse_plan_destroy",
     "plo_cse_search_plan", "plo_cse_search",
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
+    "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many",
     "plo_pack_cost",
 ]
 
@@ -84,6 +85,12 @@ def lib():
                                              ctypes.POINTER(Stats)]
         L.plo_cse_cost_many.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, u64p, ctypes.c_uint64,
                                         ctypes.c_uint64, u32p, u32p]
+        L.plo_cse_chain_create.argtypes = [ctypes.POINTER(CSR), ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_cse_chain_destroy.argtypes = [ctypes.c_void_p]
+        L.plo_cse_chain_search.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                                           ctypes.POINTER(Best), ctypes.POINTER(Stats)]
+        L.plo_cse_chain_cost_many.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p,
+                                              ctypes.POINTER(Stats)]
         L.plo_pack_cost.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
         L.plo_pack_cost.restype = ctypes.c_uint64
         _lib = L

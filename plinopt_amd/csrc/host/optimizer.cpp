@@ -33,6 +33,9 @@ struct HipLib {
     decltype(&plo_init) init = nullptr;
     decltype(&plo_last_error) last_error = nullptr;
     decltype(&plo_cse_search) cse_search = nullptr;
+    decltype(&plo_cse_chain_create) chain_create = nullptr;
+    decltype(&plo_cse_chain_search) chain_search = nullptr;
+    decltype(&plo_cse_chain_destroy) chain_destroy = nullptr;
     decltype(&plo_shutdown) shutdown = nullptr;
     bool load(const char *argv0) {
         std::vector<std::string> cand;
@@ -45,7 +48,9 @@ struct HipLib {
         if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
         init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
         cse_search = (decltype(cse_search))dlsym(h, "plo_cse_search"); shutdown = (decltype(shutdown))dlsym(h, "plo_shutdown");
-        return init && last_error && cse_search && shutdown;
+        chain_create = (decltype(chain_create))dlsym(h, "plo_cse_chain_create"); chain_search = (decltype(chain_search))dlsym(h, "plo_cse_chain_search");
+        chain_destroy = (decltype(chain_destroy))dlsym(h, "plo_cse_chain_destroy");
+        return init && last_error && cse_search && shutdown && chain_create && chain_search && chain_destroy;
     }
 };
 
@@ -92,6 +97,62 @@ template <class F> bool host_search(const F &f, const SparseMat<typename F::Elt>
         }
     }
     return have;
+}
+
+
+// program text of the LU method for one seed (include/plinopt_optimize.inl:1058-1079)
+template <class F> std::string lu_text(const F &f, const LUFactors<F> &lu, uint64_t seed, Ops &ops) {
+    std::ostringstream os;
+    for (size_t k = 0; k < lu.P.size(); ++k) os << 't' << k << ":=" << 'i' << lu.P[k] << ";\n";          // :1064
+    CandRng rng(seed);
+    Replay<F> RU(f, lu.U, rng, os, 'v', 't', 'r'); Ops uo = RU.optimizer();                                 // :1068
+    Replay<F> RL(f, lu.L, rng, os, 'x', 'v', 'g'); Ops lo = RL.optimizer();                                 // :1072
+    for (size_t i = 0; i < lu.Q.size(); ++i) os << 'o' << i << ":=" << 'x' << lu.Q[i] << ";\n";          // :1076
+    ops = {uo.first + lo.first, uo.second + lo.second};
+    return os.str();
+}
+
+template <class E> void to_csr(const SparseMat<E> &A, std::vector<uint32_t> &rp, std::vector<uint32_t> &cc, std::vector<uint32_t> &vv) {
+    rp.assign(1, 0); cc.clear(); vv.clear();
+    for (auto &r : A.rows) { for (auto &e : r) { cc.push_back((uint32_t)e.first); vv.push_back((uint32_t)e.second); } rp.push_back((uint32_t)cc.size()); }
+}
+
+// LUOptimiser :1021-1109.  Returns false when the method could not run (reported on stderr).
+template <class F> bool lu_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
+                                  int verbose, Ops &gops, std::string &gtext, const char *argv0) {
+    const LUFactors<F> lu = sparse_lu(f, lM);
+    uint64_t seed = 0; Ops best; bool have = false;
+    if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+        HipLib L;
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -G: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        std::vector<uint32_t> rp1, c1, v1, rp2, c2, v2;
+        to_csr(lu.U, rp1, c1, v1); to_csr(lu.L, rp2, c2, v2);
+        plo_csr_t A{(uint32_t)lu.U.rowdim(), (uint32_t)lu.U.coldim(), rp1.data(), c1.data(), v1.data()};
+        plo_csr_t B{(uint32_t)lu.L.rowdim(), (uint32_t)lu.L.coldim(), rp2.data(), c2.data(), v2.data()};
+        plo_chain_t *ch = nullptr;
+        int rc = L.chain_create(&A, &B, q, &ch);
+        if (rc != PLO_OK) { std::clog << "# -G skipped: " << L.last_error() << std::endl; return false; }
+        plo_best_t b{}; plo_stats_t st{};
+        rc = L.chain_search(ch, seed0, loops, PLO_COST_SUM_THEN_ADD, &b, &st);
+        L.chain_destroy(ch);
+        if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: -G GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
+        best = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
+        if (verbose > 0) std::clog << "# GPU (LU): " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms" << std::endl;
+    }
+    if (!have) {
+#pragma omp parallel for schedule(dynamic)
+        for (long long k = 0; k < (long long)loops; ++k) {
+            Ops ops; (void)lu_text(f, lu, seed0 + (uint64_t)k, ops);
+#pragma omp critical
+            { uint64_t s = seed0 + (uint64_t)k; if (!have || cmp_op_count(ops, best) || (!cmp_op_count(best, ops) && s < seed)) { best = ops; seed = s; have = true; } }
+        }
+    }
+    if (!have) return false;
+    Ops rops; std::string t = lu_text(f, lu, seed, rops);
+    if (rops != best) { std::cerr << "# \033[1;31mERROR: -G replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (verbose > 0) std::clog << "# Found G: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed << "] (rank " << lu.rank << ')' << std::endl;
+    if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                               // :1103-1107
+    return true;
 }
 
 template <class F>
@@ -145,7 +206,10 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         }
     }
     if (tryKernel && verbose > 1) std::clog << "# -K (kernel method) is not part of this build (SURVEY.md 8f)" << std::endl;
-    if (tryLU && verbose > 1) std::clog << "# -G (LU method) is not part of this build (SURVEY.md 8f)" << std::endl;
+    if (tryLU) {
+        try { lu_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
+        catch (const std::exception &e) { std::clog << "# -G skipped: " << e.what() << std::endl; }
+    }
     if (allkernels) std::clog << "# -N (exhaustive nullspace permutations) is not part of this build" << std::endl;
     if (mostCSE) std::clog << "# -E (exhaustive CSE tree) is not part of this build (SURVEY.md 8f)" << std::endl;
 
@@ -177,7 +241,7 @@ int main(int argc, char **argv)
         std::string a(argv[i]);
         if (a == "-h") {
             std::clog << "Usage: " << argv[0] << " [-h|-M|-P|-K|-D|-G|-E|-N|-A|-q #|-O #|--gpu #|--seed #] [stdin|matrixfile.sms]\n"
-                      << "  -D/-K/-G: direct/kernel/LU methods (default is all; this build runs -D)\n"
+                      << "  -D/-K/-G: direct/kernel/LU methods (default is all; this build runs -D and -G)\n"
                       << "  -q #: search modulo (default is Rationals, on the host)\n"
                       << "  -O #: randomized search with that many loops (default " << loops << " loops)\n"
                       << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only\n"

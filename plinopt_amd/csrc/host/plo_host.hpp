@@ -341,7 +341,7 @@ template <class F> class Replay {
         }
     };
     struct Mult { size_t idx, col; E val; };
-    const F &f; Mat M; CandRng rng; std::ostream &out;
+    const F &f; Mat M; CandRng own_rng; CandRng &rng; std::ostream &out;
     char ouv, tev, rav;
     std::vector<Mult> multiples;
     size_t nbadd = 0, nbmul = 0;
@@ -530,7 +530,10 @@ template <class F> class Replay {
     }
 public:
     Replay(const F &ff, const Mat &A, uint64_t seed, std::ostream &os, char o = 'o', char t = 't', char r = 'r')
-        : f(ff), M(A), rng(seed), out(os), ouv(o), tev(t), rav(r) {}
+        : f(ff), M(A), own_rng(seed), rng(own_rng), out(os), ouv(o), tev(t), rav(r) {}
+    // the candidate's generator is shared with other Optimizer() calls of the same candidate (LU method)
+    Replay(const F &ff, const Mat &A, CandRng &shared, std::ostream &os, char o, char t, char r)
+        : f(ff), M(A), own_rng(0), rng(shared), out(os), ouv(o), tev(t), rav(r) {}
     // Optimizer(), include/plinopt_optimize.inl:616-631
     std::pair<size_t, size_t> optimizer() { while (one_sub()) {} program_gen(); return {nbadd, nbmul}; }
     // the fallback of OptMethods :1473-1485: ProgramGen on the untouched matrix
@@ -542,6 +545,64 @@ template <class E> void input2temps(std::ostream &os, const SparseMat<E> &M, cha
     std::vector<char> used(M.coldim(), 0);
     for (auto &r : M.rows) for (auto &e : r) used[e.first] = 1;
     for (size_t j = 0; j < M.coldim(); ++j) if (used[j]) os << tev << j << ":=" << inv << j << ";\n";
+}
+
+// Sparse LU with row and column pivoting, M = Qm . L . U . Pm, as LUOptimiser needs it
+// (include/plinopt_optimize.inl:1032-1044 calls LinBox GaussDomain::QLUPin, whose pivot choices are not
+// specified anywhere in the reference tree).  Pivot rule of this build: the unused row of smallest index that
+// still has an entry, and in it the entry of smallest column index.  Conventions of the emitted program
+// (:1064-1076): t_k := i_{P[k]};  v := U.t;  x := L.v;  o_i := x_{Q[i]}.
+template <class F> struct LUFactors {
+    SparseMat<typename F::Elt> U, L;
+    std::vector<size_t> P, Q;
+    size_t rank = 0;
+};
+template <class F> LUFactors<F> sparse_lu(const F &f, const SparseMat<typename F::Elt> &M) {
+    using E = typename F::Elt;
+    const size_t m = M.rowdim(), n = M.coldim();
+    std::vector<std::map<size_t, E>> A(m);
+    for (size_t i = 0; i < m; ++i) for (auto &e : M.rows[i]) A[i][e.first] = e.second;
+    std::vector<char> usedr(m, 0), usedc(n, 0);
+    std::vector<size_t> prow, pcol;
+    std::vector<std::vector<std::pair<size_t, E>>> mult(m);
+    for (;;) {
+        size_t r = m;
+        for (size_t i = 0; i < m; ++i) if (!usedr[i] && !A[i].empty()) { r = i; break; }
+        if (r == m) break;
+        const size_t c = A[r].begin()->first, k = prow.size();
+        const E piv = A[r].begin()->second;
+        usedr[r] = 1; usedc[c] = 1; prow.push_back(r); pcol.push_back(c);
+        for (size_t i = 0; i < m; ++i) {
+            if (usedr[i]) continue;
+            auto it = A[i].find(c);
+            if (it == A[i].end()) continue;
+            const E l = f.div(it->second, piv);
+            for (auto &e : A[r]) {
+                E v = f.add(A[i].count(e.first) ? A[i][e.first] : f.zero(), f.neg(f.mul(l, e.second)));
+                if (f.isZero(v)) A[i].erase(e.first); else A[i][e.first] = v;
+            }
+            mult[i].emplace_back(k, l);
+        }
+    }
+    LUFactors<F> R; R.rank = prow.size();
+    R.P = pcol; for (size_t j = 0; j < n; ++j) if (!usedc[j]) R.P.push_back(j);
+    std::vector<size_t> invP(n); for (size_t k = 0; k < n; ++k) invP[R.P[k]] = k;
+    std::vector<size_t> pos(m); size_t nx = R.rank;
+    for (size_t k = 0; k < R.rank; ++k) pos[prow[k]] = k;
+    for (size_t i = 0; i < m; ++i) if (!usedr[i]) pos[i] = nx++;
+    R.Q = pos;
+    R.U = SparseMat<E>(m, n); R.L = SparseMat<E>(m, m);
+    for (size_t k = 0; k < R.rank; ++k) {
+        auto &row = R.U.rows[k];
+        for (auto &e : A[prow[k]]) row.emplace_back(invP[e.first], e.second);
+        std::sort(row.begin(), row.end(), [](const std::pair<size_t, E> &x, const std::pair<size_t, E> &y) { return x.first < y.first; });
+    }
+    for (size_t i = 0; i < m; ++i) {
+        auto &row = R.L.rows[pos[i]];
+        for (auto &e : mult[i]) row.emplace_back(e.first, e.second);
+        if (usedr[i]) row.emplace_back(pos[i], f.one());
+    }
+    return R;
 }
 
 // cmpOpCount, include/plinopt_optimize.h:53-64 (mode 0 default, 1 OPTIMIZE_ADDITIONS, 2 OPTIMIZE_SUMS)

@@ -385,6 +385,67 @@ int run_job(plo_plan *pl, plo::WaveJob J, plo_stats_t *st)
     return device_error(plo::ERR_TABLE);
 }
 
+
+} // namespace
+
+// Two prepared matrices evaluated back to back per candidate with one random stream (LU method)
+struct plo_chain {
+    plo_plan *st[2] = {nullptr, nullptr};
+    uint32_t W = 1, lds = 0, blocks_per_cu = 1;
+};
+
+namespace {
+
+int chain_config(plo_chain *ch)
+{
+    const plo::WavePlan &A = ch->st[0]->P, &B = ch->st[1]->P;
+    const uint32_t region = std::max(A.region_bytes, B.region_bytes), fixed = A.rs_bytes + B.rs_bytes;
+    if (fixed + region > g_lds_max) return fail(PLO_E_CAPACITY, "chained candidate state does not fit LDS");
+    uint32_t W = 1, bestw = 0;
+    for (uint32_t w : {4u, 2u, 1u}) {
+        const uint32_t lds = fixed + w * region;
+        if (lds > g_lds_max) continue;
+        const uint32_t waves = std::min<uint32_t>(32u, (uint32_t)(g_lds_max / lds) * w);
+        if (waves > bestw) { bestw = waves; W = w; }
+    }
+    ch->W = W; ch->lds = fixed + W * region;
+    HIPCHK(hipFuncSetAttribute((const void *)plo::cse_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ch->lds));
+    int nb = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)plo::cse_chain_kernel, (int)(W * 64), ch->lds));
+    ch->blocks_per_cu = (uint32_t)std::max(nb, 1);
+    return PLO_OK;
+}
+
+int run_chain(plo_chain *ch, plo::WaveJob J, plo_stats_t *st)
+{
+    plo_plan *p0 = ch->st[0];
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const uint64_t need = (J.ncand + ch->W - 1) / ch->W;
+        const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g_cus * ch->blocks_per_cu, need));
+        HIPCHK(hipMemsetAsync(p0->d_err, 0, sizeof(uint32_t), g_stream));
+        J.err = p0->d_err;
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, g_stream));
+        hipLaunchKernelGGL(plo::cse_chain_kernel, dim3((uint32_t)grid), dim3(ch->W * 64), ch->lds, g_stream, ch->st[0]->P, ch->st[1]->P, J);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, g_stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        uint32_t err = 0;
+        HIPCHK(hipMemcpy(&err, p0->d_err, sizeof err, hipMemcpyDeviceToHost));
+        if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = ch->lds; st->waves_per_wg = ch->W;
+                  st->algo_bytes = ch->st[0]->algo_bytes + ch->st[1]->algo_bytes; }
+        if (err == 0) return PLO_OK;
+        if (err != plo::ERR_TABLE) return device_error((int)err);
+        for (int k = 0; k < 2; ++k) { ch->st[k]->cap_scale *= 2; int rc = build_plan(ch->st[k]); if (rc != PLO_OK) return rc; }
+        int rc = chain_config(ch); if (rc != PLO_OK) return rc;
+        if (J.best) HIPCHK(hipMemset(p0->d_best, 0xFF, sizeof(unsigned long long)));
+    }
+    return device_error(plo::ERR_TABLE);
+}
+
 } // namespace
 
 extern "C" {
@@ -590,6 +651,79 @@ int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nsee
     rc = plo_cse_search_plan(pl, seed0, nseeds, cost_mode, out, stats);
     plo_cse_plan_destroy(pl);
     return rc;
+}
+
+int plo_cse_chain_destroy(plo_chain_t *ch)
+{
+    if (!ch) return PLO_OK;
+    for (int k = 0; k < 2; ++k) plo_cse_plan_destroy(ch->st[k]);
+    delete ch;
+    return PLO_OK;
+}
+
+int plo_cse_chain_create(const plo_csr_t *first, const plo_csr_t *second, uint32_t p, plo_chain_t **out)
+{
+    if (!first || !second || !out) return fail(PLO_E_ARG, "null argument");
+    plo_chain *ch = new plo_chain();
+    int rc = plo_cse_plan_create(first, p, &ch->st[0]);
+    if (rc == PLO_OK) rc = plo_cse_plan_create(second, p, &ch->st[1]);
+    if (rc == PLO_OK && (ch->st[0]->big || ch->st[1]->big)) rc = fail(PLO_E_CAPACITY, "chained search needs both matrices on the LDS-resident wave kernel");
+    if (rc == PLO_OK) rc = chain_config(ch);
+    if (rc != PLO_OK) { plo_cse_chain_destroy(ch); return rc; }
+    *out = ch;
+    return PLO_OK;
+}
+
+int plo_cse_chain_cost_many(plo_chain_t *ch, const uint64_t *seeds, uint64_t seed0, uint64_t n,
+                            uint32_t *adds, uint32_t *muls, plo_stats_t *st)
+{
+    if (!ch || !adds || !muls) return fail(PLO_E_ARG, "null argument");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    if (n == 0) return PLO_OK;
+    uint32_t *d_adds = nullptr, *d_muls = nullptr; uint64_t *d_seeds = nullptr;
+    HIPCHK(hipMalloc((void **)&d_adds, n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&d_muls, n * sizeof(uint32_t)));
+    if (seeds) { HIPCHK(hipMalloc((void **)&d_seeds, n * sizeof(uint64_t))); HIPCHK(hipMemcpy(d_seeds, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice)); }
+    plo::WaveJob J{}; J.seed0 = seed0; J.seeds = d_seeds; J.ncand = n; J.adds = d_adds; J.muls = d_muls; J.best = nullptr; J.cost_mode = 0;
+    int rc = run_chain(ch, J, st);
+    if (rc == PLO_OK) {
+        hipError_t e1 = hipMemcpy(adds, d_adds, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipError_t e2 = hipMemcpy(muls, d_muls, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(PLO_E_HIP, "copy back failed");
+    }
+    (void)hipFree(d_adds); (void)hipFree(d_muls); if (d_seeds) (void)hipFree(d_seeds);
+    st->candidates = n;
+    return rc;
+}
+
+int plo_cse_chain_search(plo_chain_t *ch, uint64_t seed0, uint64_t nseeds, int cost_mode, plo_best_t *out, plo_stats_t *st)
+{
+    if (!ch || !out) return fail(PLO_E_ARG, "null argument");
+    if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull;
+    uint64_t bkey = ~0ull, bseed = ~0ull;
+    plo_plan *p0 = ch->st[0];
+    for (uint64_t done = 0; done < nseeds;) {
+        const uint64_t cnt = std::min<uint64_t>(0xFFFFFFFFull, nseeds - done);
+        HIPCHK(hipMemsetAsync(p0->d_best, 0xFF, sizeof(unsigned long long), g_stream));
+        plo::WaveJob J{}; J.seed0 = seed0 + done; J.ncand = cnt; J.best = p0->d_best; J.cost_mode = (uint32_t)cost_mode;
+        int rc = run_chain(ch, J, st);
+        if (rc != PLO_OK) return rc;
+        unsigned long long w = 0;
+        HIPCHK(hipMemcpy(&w, p0->d_best, sizeof w, hipMemcpyDeviceToHost));
+        const uint64_t key = w >> 32, sd = seed0 + done + (w & 0xFFFFFFFFull);
+        if (key < bkey || (key == bkey && sd < bseed)) { bkey = key; bseed = sd; }
+        done += cnt;
+    }
+    if (nseeds) {
+        uint32_t a = 0, mu = 0; plo_stats_t s2{};
+        int rc = plo_cse_chain_cost_many(ch, &bseed, 0, 1, &a, &mu, &s2);
+        if (rc != PLO_OK) return rc;
+        out->adds = a; out->muls = mu; out->seed = bseed;
+    }
+    st->candidates = nseeds;
+    return PLO_OK;
 }
 
 } // extern "C"

@@ -393,7 +393,7 @@ __device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const u
 
 // One candidate.  Returns packed (adds<<32 | muls); sets *errw on failure.
 template <bool UNIT>
-__device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_t *rs, uint64_t seed,
+__device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_t *rs, uint32_t &rng,
                                   uint32_t lane, uint32_t *errw)
 {
     uint64_t *tab   = (uint64_t *)(reg + P.off_tab);
@@ -416,7 +416,6 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
     const uint32_t g = lane >> P.lpr_log2, t = lane & (LPR - 1u), gbase = g << P.lpr_log2;
     const uint64_t gmask = (LPR == 64u) ? ~0ull : (((1ull << LPR) - 1ull) << gbase);
 
-    uint32_t rng = 1u + (uint32_t)(splitmix64(seed) % 2147483646ull);
     uint32_t ncols = P.n, nbadd = 0, nbmul = 0, nmult = 0;
 
     for (;;) {
@@ -596,7 +595,8 @@ __global__ __launch_bounds__(256) void cse_wave_kernel(WavePlan P, WaveJob J)
         for (uint32_t i = lane; i < tw; i += 64u) ((uint64_t *)reg)[i] = P.tmpl[i];     // matrix image -> LDS
         PLO_WAVE_SYNC();
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        const uint64_t res = run_candidate<UNIT>(P, reg, rs, seed, lane, J.err);
+        uint32_t rng = 1u + (uint32_t)(splitmix64(seed) % 2147483646ull);
+        const uint64_t res = run_candidate<UNIT>(P, reg, rs, rng, lane, J.err);
         const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
         if (lane == 0) {
             if (J.adds) J.adds[c] = a;
@@ -608,6 +608,53 @@ __global__ __launch_bounds__(256) void cse_wave_kernel(WavePlan P, WaveJob J)
     }
     if (J.best) {
         // grid min-reduce: wave value is uniform; waves -> LDS -> one atomicMin per workgroup
+        __syncthreads();
+        if (lane == 0) lds64[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = lds64[0];
+            for (uint32_t w = 1; w < nwaves; ++w) b = lds64[w] < b ? lds64[w] : b;
+            if (b != ~0ull) atomicMin(J.best, (unsigned long long)b);
+        }
+    }
+}
+
+// Two matrices per candidate, one random stream: the restart loop of LUOptimiser (reference
+// include/plinopt_optimize.inl:1056-1100) runs Optimizer() on a copy of U and then on a copy of L and adds
+// the two op-counts (:1068-1079); the thread's generator simply keeps running from one call to the next.
+__global__ __launch_bounds__(256) void cse_chain_kernel(WavePlan P1, WavePlan P2, WaveJob J)
+{
+    extern __shared__ uint64_t lds64[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t rw1 = P1.rs_bytes >> 3, rw2 = P2.rs_bytes >> 3, tw1 = P1.tmpl_bytes >> 3, tw2 = P2.tmpl_bytes >> 3;
+    for (uint32_t i = threadIdx.x; i < rw1; i += blockDim.x) lds64[i] = P1.tmpl[tw1 + i];
+    for (uint32_t i = threadIdx.x; i < rw2; i += blockDim.x) lds64[rw1 + i] = P2.tmpl[tw2 + i];
+    __syncthreads();
+    const uint16_t *rs1 = (const uint16_t *)lds64, *rs2 = (const uint16_t *)(lds64 + rw1);
+    const uint32_t region = P1.region_bytes > P2.region_bytes ? P1.region_bytes : P2.region_bytes;
+    uint8_t *reg = (uint8_t *)lds64 + P1.rs_bytes + P2.rs_bytes + (size_t)wave * region;
+    uint64_t best = ~0ull;
+    const uint64_t stride = (uint64_t)gridDim.x * nwaves;
+    for (uint64_t c = (uint64_t)blockIdx.x * nwaves + wave; c < J.ncand; c += stride) {
+        const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
+        uint32_t rng = 1u + (uint32_t)(splitmix64(seed) % 2147483646ull);
+        for (uint32_t i = lane; i < tw1; i += 64u) ((uint64_t *)reg)[i] = P1.tmpl[i];
+        PLO_WAVE_SYNC();
+        const uint64_t r1 = P1.unit ? run_candidate<true>(P1, reg, rs1, rng, lane, J.err) : run_candidate<false>(P1, reg, rs1, rng, lane, J.err);
+        PLO_WAVE_SYNC();
+        for (uint32_t i = lane; i < tw2; i += 64u) ((uint64_t *)reg)[i] = P2.tmpl[i];
+        PLO_WAVE_SYNC();
+        const uint64_t r2 = P2.unit ? run_candidate<true>(P2, reg, rs2, rng, lane, J.err) : run_candidate<false>(P2, reg, rs2, rng, lane, J.err);
+        const uint32_t a = (uint32_t)(r1 >> 32) + (uint32_t)(r2 >> 32), mu_ = (uint32_t)r1 + (uint32_t)r2;
+        if (lane == 0) {
+            if (J.adds) J.adds[c] = a;
+            if (J.muls) J.muls[c] = mu_;
+        }
+        const uint64_t packed = ((uint64_t)cost_key32(a, mu_, J.cost_mode) << 32) | (uint32_t)c;
+        best = packed < best ? packed : best;
+        PLO_WAVE_SYNC();
+    }
+    if (J.best) {
         __syncthreads();
         if (lane == 0) lds64[wave] = best;
         __syncthreads();

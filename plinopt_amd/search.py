@@ -69,3 +69,51 @@ def cmp_op_count_key(adds, muls, cost_mode=capi.COST_SUM_THEN_ADD):
     if cost_mode == capi.COST_SUM:
         return (adds + muls,)
     return (adds + muls, adds)
+
+
+class CSEChain:
+    """Two matrices per candidate with one random stream: the restart loop of `LUOptimiser`
+    (reference include/plinopt_optimize.inl:1056-1100) -- Optimizer() on U, then on L, costs added."""
+
+    def __init__(self, first, second, p, device=None):
+        L = capi.lib()
+        if device is not None:
+            capi.check(L.plo_init(int(device)))
+        c1, self._k1 = capi.make_csr(*first)
+        c2, self._k2 = capi.make_csr(*second)
+        h = ctypes.c_void_p()
+        capi.check(L.plo_cse_chain_create(ctypes.byref(c1), ctypes.byref(c2), p, ctypes.byref(h)))
+        self._h = h
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().plo_cse_chain_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cost_many(self, seeds=None, seed0=0, n=0):
+        L = capi.lib()
+        if seeds is not None:
+            n = len(seeds)
+            sp = (ctypes.c_uint64 * max(n, 1))(*seeds)
+        else:
+            sp = None
+        adds = (ctypes.c_uint32 * max(n, 1))()
+        muls = (ctypes.c_uint32 * max(n, 1))()
+        st = capi.Stats()
+        capi.check(L.plo_cse_chain_cost_many(self._h, sp, seed0, n, adds, muls, ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return list(adds[:n]), list(muls[:n])
+
+    def search(self, seed0, nseeds, cost_mode=capi.COST_SUM_THEN_ADD):
+        L = capi.lib()
+        b, st = capi.Best(), capi.Stats()
+        capi.check(L.plo_cse_chain_search(self._h, seed0, nseeds, cost_mode, ctypes.byref(b), ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return b.adds, b.muls, b.seed

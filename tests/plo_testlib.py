@@ -266,6 +266,9 @@ def oracle():
                                             ctypes.c_int]
         L.plo_oracle_first_ties.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32,
                                             u32p, ctypes.c_int, u32p]
+        L.plo_oracle_chain.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p,
+                                       ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32, ctypes.c_uint64,
+                                       u32p, u32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
         L.plo_oracle_naive_ops.argtypes = [ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p, u32p]
         L.plo_oracle_naive_ops.restype = None
         L.plo_oracle_free.argtypes = [ctypes.c_void_p]
@@ -346,3 +349,19 @@ class OracleMatrix:
         a, mu = ctypes.c_uint32(), ctypes.c_uint32()
         oracle().plo_oracle_naive_ops(self.m, self._rp, self._v, self.p, ctypes.byref(a), ctypes.byref(mu))
         return a.value, mu.value
+
+
+def oracle_chain(A, B, seed, text=False):
+    """Optimizer() on OracleMatrix A then on B with one random stream (LU method); returns (adds, muls[, textA, textB])."""
+    a, mu = ctypes.c_uint32(), ctypes.c_uint32()
+    t1, t2 = ctypes.c_void_p(), ctypes.c_void_p()
+    rc = oracle().plo_oracle_chain(A.m, A.n, A._rp, A._c, A._v, B.m, B.n, B._rp, B._c, B._v, A.p, seed,
+                                   ctypes.byref(a), ctypes.byref(mu),
+                                   ctypes.byref(t1) if text else None, ctypes.byref(t2) if text else None)
+    assert rc == 0
+    if not text:
+        return a.value, mu.value
+    s1, s2 = ctypes.string_at(t1).decode(), ctypes.string_at(t2).decode()
+    oracle().plo_oracle_free(t1)
+    oracle().plo_oracle_free(t2)
+    return a.value, mu.value, s1, s2

@@ -50,3 +50,20 @@ def test_optimizer_cli_on_gpu(name, loops, bound):
         assert seed <= sseed
     rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2, err2
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_DPS-accurate_L.sms", "4x4x4_49_156_L.sms", "4x4x4_48_rational_P.sms"])
+def test_lu_method_on_gpu_equals_host_search(name):
+    """-G on the GPU (chained candidates: Optimizer on U then on L, one stream) returns the same winner, the same
+    program as the host loop (--gpu 0), and the program verifies."""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "-q", str(P), "-G", "-O", "3000", path])
+    assert rc == 0, err
+    rc0, out0, err0 = run([OPT, "-q", str(P), "-G", "-O", "3000", "--gpu", "0", path])
+    assert rc0 == 0, err0
+    g = re.search(r"# Found G: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\]", err)
+    g0 = re.search(r"# Found G: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\]", err0)
+    assert g and g0 and g.groups() == g0.groups(), (err, err0)
+    assert out == out0
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2

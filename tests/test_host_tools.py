@@ -148,3 +148,22 @@ def test_config5_host_engine_program_verifies(tmp_path):
     assert "# %d\tadditions" % a in err and "# %d\tmultiplications" % mu in err
     rc, _, err2 = run([CHK, "-q", str(P), "-M", str(sms)], stdin=prog)
     assert rc == 0 and "SUCCESS" in err2 and ("%d,%d" % (a, mu)) in err2, err2
+
+
+@pytest.mark.parametrize("name", ["cyclic.sms", "2x2x2_7_Winograd_L.sms", "4x4x4_49_156_L.sms", "2x2x2_7_DPS-accurate_L.sms",
+                                  "4x4x4_48_rational_P.sms", "3o3o6_Toom4_P.sms", "3x4x7_63_rational-ALT_L.sms", "4o4o4_F32_Standard_L.sms"])
+@pytest.mark.parametrize("field", ["Q", "p"])
+def test_lu_method_programs_verify(name, field):
+    """-G (LUOptimiser, plinopt_optimize.inl:1021-1109) on the host: factor with the build's pivot rule, optimise U
+    and L with one random stream, glue with the two permutations; the program must compute the matrix and the
+    printed count must equal the checker's count whenever -G wins."""
+    path = os.path.join(DATA, name)
+    q = ["-q", str(P), "--gpu", "0"] if field == "p" else []
+    rc, out, err = run([OPT, "-G", "-O", "12"] + q + [path])
+    assert rc == 0, err
+    assert "# Found G:" in err
+    rc, _, err2 = run([CHK] + (["-q", str(P)] if field == "p" else []) + ["-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+    m = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
+    final_adds = int(m.group(1)) if m else 0          # the statistics lines are omitted for a 0|0 program (src/optimizer.cpp:89)
+    assert int(re.search(r"# \S*?(\d+)\tadditions", err2).group(1)) == final_adds
