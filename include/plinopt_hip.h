@@ -112,6 +112,21 @@ int plo_cse_chain_search(plo_chain_t *chain, uint64_t seed0, uint64_t nseeds, in
 int plo_cse_chain_cost_many(plo_chain_t *chain, const uint64_t *seeds, uint64_t seed0, uint64_t n,
                             uint32_t *adds, uint32_t *muls, plo_stats_t *stats);
 
+/* Change-of-basis (CoB) search of bin/sparsifier: one (block,row) enumeration of `localSparsifier`,
+ * include/plinopt_sparsify.inl:282-314, i.e. |coeffs|^4 calls of `testLinComb` (:167-197).  TM is the n x m
+ * matrix being sparsified (dense, row major, residues mod p), Cand the n x n matrix whose rows 0..row-1 are the
+ * rows already chosen; candidate (i,j,k,l) is the row w with w[offsetblock+t] = coeffs[(i,j,k,l)[t]] (positions
+ * >= n dropped, :305-310).  Result: the first candidate in lexicographic (i,j,k,l) order that is independent of
+ * the chosen rows and maximises (zeros(TM^T w), zeros(w)), if it beats (w0,w1) strictly; index = ((i*C+j)*C+k)*C+l. */
+typedef struct {
+    int32_t  zeros_v, zeros_w;   /* score of the winner (or the incoming w0,w1 when nothing beats them) */
+    uint64_t index;              /* flattened (i,j,k,l) */
+    uint32_t found;              /* 1 if some candidate beat (w0,w1) */
+} plo_cob_best_t;
+int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
+                   const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
+                   plo_cob_best_t *out, plo_stats_t *stats);
+
 /* Pack / unpack the (cost, seed) word used by the grid reduction and by the
  * single 8-byte MIN all-reduce across ranks (the `#pragma omp critical`
  * best-so-far of include/plinopt_optimize.inl:1214-1237).  seed_off is the

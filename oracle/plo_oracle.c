@@ -529,6 +529,48 @@ void plo_oracle_naive_ops(uint32_t m, const uint32_t *rowptr, const uint32_t *va
     *adds = a; *muls = mu;
 }
 
+/* ---- change-of-basis search: one (block,row) enumeration of localSparsifier, plinopt_sparsify.inl:282-314 ----
+ * Literal: for every (i,j,k,l) in lexicographic order build w, put it in row `row` of a copy of Cand, compute the
+ * rank by Gaussian elimination (rank(), :38-45), v = TM^T w, and keep w when (zeros(v), zeros(w)) is strictly
+ * better (testLinComb :167-197). */
+static uint32_t rank_mod(uint32_t *A, uint32_t r, uint32_t c, uint32_t p) {
+    uint32_t rk = 0;
+    for (uint32_t col = 0; col < c && rk < r; col++) {
+        uint32_t q = rk; while (q < r && A[(size_t)q * c + col] == 0) q++;
+        if (q == r) continue;
+        if (q != rk) for (uint32_t j = 0; j < c; j++) { uint32_t t = A[(size_t)q * c + j]; A[(size_t)q * c + j] = A[(size_t)rk * c + j]; A[(size_t)rk * c + j] = t; }
+        uint32_t iv = f_inv(A[(size_t)rk * c + col], p);
+        for (uint32_t i = rk + 1; i < r; i++) {
+            uint32_t l = f_mul(A[(size_t)i * c + col], iv, p);
+            if (!l) continue;
+            for (uint32_t j = col; j < c; j++) A[(size_t)i * c + j] = (uint32_t)(((uint64_t)A[(size_t)i * c + j] + (uint64_t)(p - l) * A[(size_t)rk * c + j]) % p);
+        }
+        rk++;
+    }
+    return rk;
+}
+int plo_oracle_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
+                          const uint32_t *coeffs, uint32_t C, uint32_t p, int32_t w0, int32_t w1,
+                          int32_t *zeros_v, int32_t *zeros_w, uint64_t *index, uint32_t *found) {
+    uint32_t *A = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n * n), *w = (uint32_t *)calloc(n, sizeof(uint32_t));
+    int32_t bv = w0, bw = w1; *found = 0; *index = 0;
+    for (uint32_t i = 0; i < C; i++) for (uint32_t j = 0; j < C; j++) for (uint32_t k = 0; k < C; k++) for (uint32_t l = 0; l < C; l++) {
+        const uint32_t cf[4] = { coeffs[i], coeffs[j], coeffs[k], coeffs[l] };
+        memset(w, 0, sizeof(uint32_t) * n);
+        for (uint32_t t = 0; t < 4; t++) if (offsetblock + t < n) w[offsetblock + t] = cf[t] % p;      /* w.resize(TM.rowdim()) :310 */
+        memcpy(A, Cand, sizeof(uint32_t) * (size_t)n * n);
+        for (uint32_t q = 0; q < n; q++) A[(size_t)row * n + q] = w[q];                                    /* setRow(Cand,num,w) :171 */
+        if (rank_mod(A, n, n, p) <= row) continue;                                                       /* r > num :174 */
+        int32_t zv = 0, zw = 0;
+        for (uint32_t c = 0; c < m; c++) { uint64_t sacc = 0; for (uint32_t q = 0; q < n; q++) sacc = (sacc + (uint64_t)w[q] * TM[(size_t)q * m + c]) % p; if (!sacc) zv++; }
+        for (uint32_t q = 0; q < n; q++) if (!w[q]) zw++;
+        if (zv > bv || (zv == bv && zw > bw)) { bv = zv; bw = zw; *index = (((uint64_t)i * C + j) * C + k) * C + l; *found = 1; }
+    }
+    *zeros_v = bv; *zeros_w = bw;
+    free(A); free(w);
+    return 0;
+}
+
 void plo_oracle_free(void *q) { free(q); }
 int plo_oracle_max_threads(void) {
 #ifdef _OPENMP

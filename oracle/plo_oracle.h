@@ -75,6 +75,13 @@ int plo_oracle_first_ties(uint32_t m, uint32_t n, const uint32_t *rowptr,
                           const uint32_t *col, const uint32_t *val, uint32_t p,
                           uint32_t *tri_abr, int cap, uint32_t *maxfrq);
 
+/* One (block,row) enumeration of localSparsifier (plinopt_sparsify.inl:282-314) = |coeffs|^4 calls of testLinComb
+ * (:167-197), rank by Gaussian elimination of a copy per candidate as in the reference.  TM n x m, Cand n x n,
+ * dense row major, residues mod p.  index = ((i*C+j)*C+k)*C+l of the winner. */
+int plo_oracle_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
+                          const uint32_t *coeffs, uint32_t C, uint32_t p, int32_t w0, int32_t w1,
+                          int32_t *zeros_v, int32_t *zeros_w, uint64_t *index, uint32_t *found);
+
 /* naiveOps: plinopt_library.inl:227-235 */
 void plo_oracle_naive_ops(uint32_t m, const uint32_t *rowptr,
                           const uint32_t *val, uint32_t p,

@@ -21,6 +21,7 @@ EXPORTS = [
     "plo_cse_search_plan", "plo_cse_search",
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many",
+    "plo_cob_search",
     "plo_pack_cost",
 ]
 
@@ -45,6 +46,10 @@ class Stats(ctypes.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class CobBest(ctypes.Structure):
+    _fields_ = [("zeros_v", ctypes.c_int32), ("zeros_w", ctypes.c_int32), ("index", ctypes.c_uint64), ("found", ctypes.c_uint32)]
 
 
 class PloError(RuntimeError):
@@ -91,6 +96,9 @@ def lib():
                                            ctypes.POINTER(Best), ctypes.POINTER(Stats)]
         L.plo_cse_chain_cost_many.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p,
                                               ctypes.POINTER(Stats)]
+        L.plo_cob_search.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
+                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.POINTER(CobBest), ctypes.POINTER(Stats)]
         L.plo_pack_cost.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
         L.plo_pack_cost.restype = ctypes.c_uint64
         _lib = L

@@ -1,0 +1,155 @@
+// ===========================================================================
+// bin/sparsifier -- front-end keeping the reference CLI contract of
+// src/sparsifier.cpp:89-136: flags -q # -c # -b # -U [1|0] -M/-S/-P/-L; the change of basis CoB goes to
+// stdout, the residue, the density profiles and the "SUCCESS: consistent factorization" line to stderr (:52,
+// plinopt_sparsify.inl:132-155).  New flag: --gpu N (0 = host only).
+//
+// With -q p the exhaustive |Coeffs|^4 enumeration of localSparsifier (plinopt_sparsify.inl:299-314) runs
+// on the GPU through plo_cob_search (include/plinopt_hip.h); over the rationals it runs on the host, as in the
+// reference.  A failing GPU call is fatal: there is no silent fallback.
+// ===========================================================================
+#include "plo_sparsify.hpp"
+#include "../../../include/plinopt_hip.h"
+
+#include <chrono>
+#include <dlfcn.h>
+#include <libgen.h>
+#include <unistd.h>
+
+using namespace plo;
+
+namespace {
+
+struct HipCob {
+    void *h = nullptr;
+    decltype(&plo_init) init = nullptr;
+    decltype(&plo_last_error) last_error = nullptr;
+    decltype(&plo_cob_search) cob_search = nullptr;
+    bool load() {
+        std::vector<std::string> cand;
+        if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
+        char buf[4096]; ssize_t k = readlink("/proc/self/exe", buf, sizeof buf - 1);
+        if (k > 0) { buf[k] = 0; std::string d = dirname(buf); cand.push_back(d + "/../plinopt_amd/libplinopt_hip.so"); cand.push_back(d + "/libplinopt_hip.so"); }
+        cand.emplace_back("libplinopt_hip.so");
+        for (auto &c : cand) { h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
+        init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
+        cob_search = (decltype(cob_search))dlsym(h, "plo_cob_search");
+        return init && last_error && cob_search;
+    }
+};
+
+// GPU backend of the enumeration (Z_p only)
+struct CobGpuBackend : CobBackend<ZpField> {
+    HipCob &L; double kernel_ms = 0;
+    explicit CobGpuBackend(HipCob &l) : L(l) {}
+    CobBest best(const ZpField &f, const DMat<uint32_t> &TM, const DMat<uint32_t> &Cand, size_t row, size_t off,
+                 const std::vector<uint32_t> &coeffs, int w0, int w1) override {
+        const size_t n = TM.size(), m = n ? TM[0].size() : 0;
+        std::vector<uint32_t> tm(n * m), cd(n * n);
+        for (size_t i = 0; i < n; ++i) { std::copy(TM[i].begin(), TM[i].end(), tm.begin() + i * m); std::copy(Cand[i].begin(), Cand[i].end(), cd.begin() + i * n); }
+        plo_cob_best_t b{}; plo_stats_t st{};
+        int rc = L.cob_search((uint32_t)n, (uint32_t)m, tm.data(), cd.data(), (uint32_t)row, (uint32_t)off, coeffs.data(), (uint32_t)coeffs.size(), f.p, w0, w1, &b, &st);
+        if (rc != PLO_OK) throw std::runtime_error(std::string("GPU CoB search failed: ") + L.last_error());
+        this->candidates += st.candidates; kernel_ms += st.kernel_ms;
+        CobBest r; r.zv = b.zeros_v; r.zw = b.zeros_w; r.index = b.index; r.found = b.found != 0;
+        return r;
+    }
+};
+
+enum Fmt { PRETTY, SMS, MAPLE, LINALG };
+
+template <class F> void write_matrix(std::ostream &os, const F &f, const DMat<typename F::Elt> &A, Fmt fmt) {
+    const size_t r = A.size(), c = r ? A[0].size() : 0;
+    if (fmt == SMS) { write_sms(os, f, to_sparse(f, A), std::is_same<F, QField>::value ? 'R' : 'M'); return; }
+    if (fmt == MAPLE || fmt == LINALG) {
+        os << (fmt == MAPLE ? "Matrix(" : "matrix(") << r << ',' << c << ",[";
+        for (size_t i = 0; i < r; ++i) { os << (i ? ",[" : "["); for (size_t j = 0; j < c; ++j) { if (j) os << ','; f.write(os, A[i][j]); } os << ']'; }
+        os << "])";
+        return;
+    }
+    for (size_t i = 0; i < r; ++i) { os << "  [ "; for (size_t j = 0; j < c; ++j) { f.write(os, A[i][j]); os << ' '; } os << "]\n"; }
+}
+
+template <class F> size_t profile_line(std::ostream &os, const F &f, const char *tag, const DMat<typename F::Elt> &A, bool colour) {
+    size_t s = 0; os << "# " << tag << (colour ? "\033[1;36m" : "");
+    for (auto &r : A) { size_t k = 0; for (auto &e : r) if (!f.isZero(e)) ++k; s += k; os << k << ' '; }
+    os << '=' << s << (colour ? "\033[0m" : "") << std::endl;
+    return s;
+}
+
+// TSparsifier, src/sparsifier.cpp:21-56
+template <class F> int tsparsifier(const F &f, const SparseMat<typename F::Elt> &Ms, CobBackend<F> &backend, Fmt fmt, size_t blocksize, size_t maxnumcoeff, bool initialElimination) {
+    const auto M = to_dense(f, Ms);
+    const size_t sc = profile_line(std::clog, f, "[SPRF] Initial profile: ", M, false);
+    std::clog << std::string(30, '#') << std::endl;
+    auto t0 = std::chrono::steady_clock::now();
+    Sparsifier<F> S(f, backend, std::clog);
+    DMat<typename F::Elt> CoB, Res;
+    S.block_sparsifier(CoB, Res, M, blocksize, maxnumcoeff, initialElimination);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::clog << std::string(30, '#') << std::endl;
+    const size_t sb = profile_line(std::clog, f, "[SPRF] chgobase profile: ", CoB, true);          // profileConsistency :132-155
+    write_matrix(std::cout, f, CoB, fmt); std::cout << std::endl;
+    const size_t sa = profile_line(std::clog, f, "[SPRF] residuum profile: ", Res, true);
+    write_matrix(std::clog, f, Res, fmt); std::clog << std::endl;
+    const bool ok = S.consistent(M, Res, CoB);
+    if (ok) std::clog << "# \033[1;32mSUCCESS: consistent factorization!\033[0m";
+    else std::cerr << "# \033[1;31m****** ERROR inconsistency ******\033[0m" << std::endl;
+    std::clog << " \033[1;36m" << Res.size() << 'x' << (Res.empty() ? 0 : Res[0].size()) << " by " << CoB.size() << 'x' << (CoB.empty() ? 0 : CoB[0].size())
+              << " with " << sa << " non-zeroes (" << sb << " alt.) instead of " << sc << "\033[0m: " << secs << "s" << std::endl;
+    std::clog << "# CoB enumeration: " << backend.candidates << " candidate rows" << std::endl;
+    return ok ? 0 : 1;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    Fmt fmt = PRETTY; std::string filename; size_t maxnumcoeff = 11, blocksize = 4; bool initialElimination = true; uint64_t q = 0; int gpu = 1;
+    for (int i = 1; i < argc; ++i) {
+        std::string a(argv[i]);
+        if (a == "-h") {
+            std::clog << "Usage: " << argv[0] << " [-h|-q|-M|-P|-S|-L|-c #|-b #|-U [1|0]|--gpu #] [stdin|matfile.sms]\n"
+                      << "  -c #: max number of coefficients per iteration (default " << maxnumcoeff << ")\n"
+                      << "  -b #: states the blocking dimension (default " << blocksize << ")\n"
+                      << "  -U [1|0]: initial LU factorization (default) or not\n"
+                      << "  -M/-P/-S/-L: selects the ouput format\n"
+                      << "  --gpu #: 1 = enumerate the candidate rows on the MI355X (default with -q), 0 = host only\n";
+            exit(-1);
+        } else if (a == "-q" && i + 1 < argc) q = strtoull(argv[++i], nullptr, 10);
+        else if (a == "-M") fmt = MAPLE;
+        else if (a == "-S") fmt = SMS;
+        else if (a == "-P") fmt = PRETTY;
+        else if (a == "-L") fmt = LINALG;
+        else if (a == "-c" && i + 1 < argc) maxnumcoeff = strtoull(argv[++i], nullptr, 10);
+        else if (a == "-b" && i + 1 < argc) blocksize = strtoull(argv[++i], nullptr, 10);
+        else if (a == "-U" && i + 1 < argc) initialElimination = atoi(argv[++i]) != 0;
+        else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else filename = a;
+    }
+    try {
+        QMat MQ;
+        if (filename.empty()) MQ = read_sms(std::cin);
+        else { std::ifstream in(filename); if (!in) return -1; MQ = read_sms(in); }
+        if (q != 0) {
+            if (q < 3 || q >= (1ull << 31)) { std::cerr << "# ERROR: modulus must be an odd prime below 2^31 in this build" << std::endl; return -1; }
+            ZpField f((uint32_t)q);
+            if (gpu > 0) {
+                HipCob L;
+                if (!L.load() || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return 2; }
+                CobGpuBackend B(L);
+                int rc = tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
+                std::clog << "# GPU: enumeration kernels " << B.kernel_ms << " ms, " << (B.kernel_ms > 0 ? B.candidates / (B.kernel_ms * 1e-3) : 0.0) << " candidate rows/s" << std::endl;
+                return rc;
+            }
+            CobHostBackend<ZpField> B;
+            return tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
+        }
+        QField f; CobHostBackend<QField> B;
+        return tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
+    } catch (const std::exception &e) {
+        std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m" << std::endl;
+        return -1;
+    }
+}

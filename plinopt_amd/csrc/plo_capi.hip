@@ -10,6 +10,7 @@
 // ===========================================================================
 #include "plo_cse_wave.hip"
 #include "plo_cse_big.hip"
+#include "plo_cob.hip"
 #include "../../include/plinopt_hip.h"
 
 #include <algorithm>
@@ -723,6 +724,86 @@ int plo_cse_chain_search(plo_chain_t *ch, uint64_t seed0, uint64_t nseeds, int c
         out->adds = a; out->muls = mu; out->seed = bseed;
     }
     st->candidates = nseeds;
+    return PLO_OK;
+}
+
+int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
+                   const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
+                   plo_cob_best_t *out, plo_stats_t *st)
+{
+    if (!TM || !Cand || !coeffs || !out) return fail(PLO_E_ARG, "null argument");
+    if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
+    if (n == 0 || row >= n || offsetblock >= n || ncoeffs == 0) return fail(PLO_E_ARG, "bad dimensions");
+    if (ncoeffs > 255) return fail(PLO_E_CAPACITY, "more than 255 coefficients: the candidate index does not fit 32 bits");
+    if ((uint64_t)(m + 1) * (n + 1) >= 0xFFFFFFFFull) return fail(PLO_E_CAPACITY, "score does not fit 32 bits");
+    if (g_device < 0) { int rc = plo_init(0); if (rc != PLO_OK) return rc; }
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    auto t0 = std::chrono::steady_clock::now();
+    // right nullspace of the rows already chosen (rows 0..row-1 of Cand), by reduced row echelon form mod p
+    std::vector<std::vector<uint32_t>> A(row, std::vector<uint32_t>(n));
+    for (uint32_t i = 0; i < row; ++i) for (uint32_t j = 0; j < n; ++j) A[i][j] = Cand[(size_t)i * n + j] % p;
+    std::vector<uint32_t> piv; uint32_t r0 = 0;
+    for (uint32_t c = 0; c < n && r0 < row; ++c) {
+        uint32_t q = r0; while (q < row && A[q][c] == 0) ++q;
+        if (q == row) continue;
+        std::swap(A[q], A[r0]);
+        const uint32_t iv = inv_mod(A[r0][c], p);
+        for (uint32_t j = c; j < n; ++j) A[r0][j] = (uint32_t)((uint64_t)A[r0][j] * iv % p);
+        for (uint32_t i = 0; i < row; ++i) if (i != r0 && A[i][c]) { const uint32_t l = A[i][c]; for (uint32_t j = c; j < n; ++j) A[i][j] = (uint32_t)(((uint64_t)A[i][j] + (uint64_t)(p - l) * A[r0][j]) % p); }
+        piv.push_back(c); ++r0;
+    }
+    if (piv.size() != row) {      // chosen rows are dependent: rank(Cand with row := w) can never exceed `row` (:174)
+        out->found = 0; out->zeros_v = w0; out->zeros_w = w1; out->index = 0;
+        st->candidates = (uint64_t)ncoeffs * ncoeffs * ncoeffs * ncoeffs;
+        return PLO_OK;
+    }
+    std::vector<char> isp(n, 0); for (uint32_t c : piv) isp[c] = 1;
+    const uint32_t fb = std::min<uint32_t>(4, n - offsetblock);
+    std::vector<uint32_t> nb; uint32_t qn = 0;           // 4 x qn, only the block positions of each basis vector
+    std::vector<std::vector<uint32_t>> cols;
+    for (uint32_t fc = 0; fc < n; ++fc) {
+        if (isp[fc]) continue;
+        std::vector<uint32_t> x(n, 0); x[fc] = 1;
+        for (size_t k = 0; k < piv.size(); ++k) x[piv[k]] = A[k][fc] ? p - A[k][fc] : 0;
+        bool any = false; for (uint32_t t = 0; t < fb; ++t) any |= x[offsetblock + t] != 0;
+        if (any) cols.push_back({x[offsetblock], fb > 1 ? x[offsetblock + 1] : 0, fb > 2 ? x[offsetblock + 2] : 0, fb > 3 ? x[offsetblock + 3] : 0});
+    }
+    qn = (uint32_t)cols.size(); nb.assign(4 * (size_t)std::max<uint32_t>(qn, 1), 0);
+    for (uint32_t c = 0; c < qn; ++c) for (uint32_t t = 0; t < 4; ++t) nb[(size_t)t * qn + c] = cols[c][t];
+    std::vector<uint32_t> tmb(4 * (size_t)m, 0);
+    for (uint32_t t = 0; t < fb; ++t) for (uint32_t j = 0; j < m; ++j) tmb[(size_t)t * m + j] = TM[(size_t)(offsetblock + t) * m + j] % p;
+    const uint64_t total = (uint64_t)ncoeffs * ncoeffs * ncoeffs * ncoeffs;
+    const int64_t thr = w0 < 0 ? -1 : (int64_t)w0 * (n + 1) + std::max(w1, 0);
+    const unsigned long long init = ((unsigned long long)(thr + 1) << 32) | 0xFFFFFFFFull;
+    const size_t lds = (4 * (size_t)m + 4 * (size_t)qn + ncoeffs) * 4;
+    if (lds > g_lds_max) return fail(PLO_E_CAPACITY, "block of TM does not fit LDS");
+    uint32_t *d_tm = nullptr, *d_nb = nullptr, *d_cf = nullptr; unsigned long long *d_best = nullptr;
+    HIPCHK(hipMalloc((void **)&d_tm, tmb.size() * 4)); HIPCHK(hipMalloc((void **)&d_nb, nb.size() * 4));
+    HIPCHK(hipMalloc((void **)&d_cf, (size_t)ncoeffs * 4)); HIPCHK(hipMalloc((void **)&d_best, 8));
+    HIPCHK(hipMemcpy(d_tm, tmb.data(), tmb.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_nb, nb.data(), nb.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_cf, coeffs, (size_t)ncoeffs * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_best, &init, 8, hipMemcpyHostToDevice));
+    plo::CobJob J{}; J.n = n; J.m = m; J.qn = qn; J.fb = fb; J.C = ncoeffs; J.p = p; J.mu = (~0ull) / p; J.total = total;
+    J.tm = d_tm; J.nb = d_nb; J.coeffs = d_cf; J.best = d_best;
+    HIPCHK(hipFuncSetAttribute((const void *)plo::cob_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)g_cus * 8));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g_stream));
+    hipLaunchKernelGGL(plo::cob_kernel, dim3((uint32_t)grid), dim3(256), lds, g_stream, J);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, g_stream)); HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    unsigned long long w = 0;
+    HIPCHK(hipMemcpy(&w, d_best, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_tm); (void)hipFree(d_nb); (void)hipFree(d_cf); (void)hipFree(d_best);
+    out->found = w != init ? 1u : 0u;
+    if (out->found) { const uint32_t sc = (uint32_t)(w >> 32) - 1u; out->zeros_v = (int32_t)(sc / (n + 1)); out->zeros_w = (int32_t)(sc % (n + 1)); out->index = (uint32_t)~(uint32_t)w; }
+    else { out->zeros_v = w0; out->zeros_w = w1; out->index = 0; }
+    st->kernel_ms = ms; st->launches = 1; st->candidates = total; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)lds; st->waves_per_wg = 4;
+    st->algo_bytes = 16ull * m + 8;                       // the 4 x m block of TM, once, plus the result word
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PLO_OK;
 }
 

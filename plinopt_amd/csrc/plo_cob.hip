@@ -1,0 +1,79 @@
+// ===========================================================================
+// plo_cob.hip -- gfx950 kernel for the change-of-basis search of bin/sparsifier:
+// one (block,row) enumeration of `localSparsifier` (reference
+// include/plinopt_sparsify.inl:282-314), i.e. |Coeffs|^4 evaluations of
+// `testLinComb` (:167-197), one candidate row w per lane:
+//   * w is independent of the rows already chosen  <=>  w . N != 0 for a basis N of
+//     their right nullspace (computed once on the host; the reference copies the
+//     candidate matrix and runs a Gaussian elimination per candidate, :38-45,:172-175);
+//   * v = TM^T w (only the <= 4 block rows of TM matter), score = (zeros(v), zeros(w));
+//   * strictly-better-replaces in lexicographic (i,j,k,l) order == argmax with the
+//     smallest index: packed (score, ~index) and one 64-bit atomicMax per wave.
+// HBM traffic is the 4 x m block of TM (staged in LDS) and one 8-byte result:
+// the kernel is bound by integer VALU issue (4 modular products per column).
+// ===========================================================================
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plo {
+
+struct CobJob {
+    uint32_t n, m, qn, fb, C, p; uint64_t mu; uint64_t total;     // total = C^4
+    const uint32_t *tm;       // 4 x m   block rows of TM (rows beyond n are zero)
+    const uint32_t *nb;       // 4 x qn  block rows of the nullspace basis of the chosen rows
+    const uint32_t *coeffs;   // C
+    unsigned long long *best; // packed (score+1)<<32 | ~index, initialised with the incoming weight
+};
+
+__device__ __forceinline__ uint32_t cob_mul(uint32_t a, uint32_t b, uint32_t p, uint64_t mu) {
+    uint64_t x = (uint64_t)a * b, q = __umul64hi(x, mu), r = x - q * p;
+    while (r >= p) r -= p;
+    return (uint32_t)r;
+}
+__device__ __forceinline__ bool cob_zero4(uint64_t s, uint32_t p) { return s == 0 || s == p || s == 2ull * p || s == 3ull * p; }
+
+__global__ __launch_bounds__(256) void cob_kernel(CobJob J)
+{
+    extern __shared__ uint32_t cl[];                    // tm block (4*m) then nullspace block (4*qn) then coeffs (C)
+    uint32_t *tm = cl, *nb = cl + 4u * J.m, *cf = nb + 4u * J.qn;
+    for (uint32_t i = threadIdx.x; i < 4u * J.m; i += blockDim.x) tm[i] = J.tm[i];
+    for (uint32_t i = threadIdx.x; i < 4u * J.qn; i += blockDim.x) nb[i] = J.nb[i];
+    for (uint32_t i = threadIdx.x; i < J.C; i += blockDim.x) cf[i] = J.coeffs[i];
+    __syncthreads();
+    const uint32_t p = J.p, C = J.C, m = J.m, qn = J.qn, fb = J.fb;
+    const uint64_t mu = J.mu;
+    uint64_t mybest = 0;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < J.total; idx += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)idx, w[4];
+        w[3] = cf[x % C]; x /= C; w[2] = cf[x % C]; x /= C; w[1] = cf[x % C]; x /= C; w[0] = cf[x];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if ((uint32_t)t >= fb) w[t] = 0;                 // positions beyond the matrix are dropped (:310)
+        bool indep = false;
+        for (uint32_t c = 0; c < qn && !indep; ++c) {
+            uint64_t s = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s += cob_mul(w[t], nb[t * qn + c], p, mu);
+            indep = !cob_zero4(s, p);
+        }
+        if (!indep) continue;
+        uint32_t zv = 0, zw = J.n - fb;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if ((uint32_t)t < fb && w[t] == 0) ++zw;
+        for (uint32_t c = 0; c < m; ++c) {
+            uint64_t s = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s += cob_mul(w[t], tm[t * m + c], p, mu);
+            zv += cob_zero4(s, p) ? 1u : 0u;
+        }
+        const uint64_t key = ((uint64_t)(zv * (J.n + 1u) + zw + 1u) << 32) | (uint32_t)(~(uint32_t)idx);
+        mybest = key > mybest ? key : mybest;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mybest, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mybest >> 32), o);
+        const uint64_t v = ((uint64_t)hi << 32) | lo; mybest = v > mybest ? v : mybest;
+    }
+    if ((threadIdx.x & 63u) == 0 && mybest) atomicMax(J.best, (unsigned long long)mybest);
+}
+
+} // namespace plo

@@ -117,3 +117,15 @@ class CSEChain:
         capi.check(L.plo_cse_chain_search(self._h, seed0, nseeds, cost_mode, ctypes.byref(b), ctypes.byref(st)))
         self.last_stats = st.as_dict()
         return b.adds, b.muls, b.seed
+
+
+def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1):
+    """One (block,row) enumeration of `localSparsifier` (reference include/plinopt_sparsify.inl:282-314) on the
+    GPU: |coeffs|^4 candidate rows through `testLinComb`.  TM (n x m) and Cand (n x n) are flat row-major lists of
+    residues.  Returns ((zeros_v, zeros_w, index, found), stats)."""
+    L = capi.lib()
+    b, st = capi.CobBest(), capi.Stats()
+    arr = lambda xs: (ctypes.c_uint32 * max(len(xs), 1))(*xs)
+    capi.check(L.plo_cob_search(n, m, arr(TM), arr(Cand), row, offsetblock, arr(coeffs), len(coeffs), p, w0, w1,
+                                ctypes.byref(b), ctypes.byref(st)))
+    return (b.zeros_v, b.zeros_w, b.index, b.found), st.as_dict()

@@ -269,6 +269,9 @@ def oracle():
         L.plo_oracle_chain.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p,
                                        ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32, ctypes.c_uint64,
                                        u32p, u32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_oracle_cob_search.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
+                                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), u64p, u32p]
         L.plo_oracle_naive_ops.argtypes = [ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p, u32p]
         L.plo_oracle_naive_ops.restype = None
         L.plo_oracle_free.argtypes = [ctypes.c_void_p]
@@ -365,3 +368,13 @@ def oracle_chain(A, B, seed, text=False):
     oracle().plo_oracle_free(t1)
     oracle().plo_oracle_free(t2)
     return a.value, mu.value, s1, s2
+
+
+def oracle_cob_search(n, m, TM, Cand, row, off, coeffs, p, w0=-1, w1=-1):
+    """TM, Cand: flat row-major lists.  Returns (zeros_v, zeros_w, index, found)."""
+    zv, zw = ctypes.c_int32(), ctypes.c_int32()
+    idx, fnd = ctypes.c_uint64(), ctypes.c_uint32()
+    rc = oracle().plo_oracle_cob_search(n, m, _arr(TM), _arr(Cand), row, off, _arr(coeffs), len(coeffs), p, w0, w1,
+                                        ctypes.byref(zv), ctypes.byref(zw), ctypes.byref(idx), ctypes.byref(fnd))
+    assert rc == 0
+    return zv.value, zw.value, idx.value, fnd.value

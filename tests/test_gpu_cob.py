@@ -1,0 +1,89 @@
+"""Change-of-basis search (bin/sparsifier's hot loop): the GPU enumeration of |Coeffs|^4 candidate rows against
+the literal CPU oracle (rank by Gaussian elimination per candidate), and the CLI end to end."""
+import os
+import random
+import re
+import subprocess
+
+import pytest
+
+from plo_testlib import DATA, ROOT, oracle_cob_search, read_sms, to_csr_mod
+
+pytestmark = pytest.mark.gpu
+P = 131071
+SPS = os.path.join(ROOT, "bin", "sparsifier")
+
+
+def _dense_T(name, p):
+    """TM = M^T as a flat row-major n x m list"""
+    m, n, ent = read_sms(os.path.join(DATA, name))
+    rp, c, v = to_csr_mod(m, n, ent, p)
+    TM = [0] * (n * m)
+    for i in range(m):
+        for k in range(rp[i], rp[i + 1]):
+            TM[c[k] * m + i] = v[k]
+    return n, m, TM
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "2x2x2_7_DPS-accurate_L.sms", "3x3x3_23_58_L.sms"])
+def test_cob_enumeration_matches_oracle(hip, name):
+    from plinopt_amd import cob_search
+    n, m, TM = _dense_T(name, P)
+    rng = random.Random(1)
+    coeffs = [0, 1, P - 1, 2, P - 2, pow(2, -1, P), P - pow(2, -1, P)]
+    Cand = [0] * (n * n)
+    for row in range(min(n, 9)):                   # build the change of basis row by row, as localSparsifier does
+        off = (row // 4) * 4
+        for C in (3, 5, 7):
+            for (w0, w1) in ((-1, -1), (m // 3, 1)):
+                got, st = cob_search(n, m, TM, Cand, row, off, coeffs[:C], P, w0, w1)
+                exp = oracle_cob_search(n, m, TM, Cand, row, off, coeffs[:C], P, w0, w1)
+                assert got == exp, (name, row, C, w0, w1)
+                assert st["candidates"] == C ** 4
+        zv, zw, idx, found = oracle_cob_search(n, m, TM, Cand, row, off, coeffs[:5], P)
+        assert found
+        ids = []
+        for _ in range(4):
+            ids.append(idx % 5)
+            idx //= 5
+        ids.reverse()
+        for t in range(4):
+            if off + t < n:
+                Cand[row * n + off + t] = coeffs[ids[t]]
+        assert rng is not None
+
+
+def test_cob_random_blocks(hip):
+    from plinopt_amd import cob_search
+    rng = random.Random(7)
+    for trial in range(40):
+        p = rng.choice([7, 101, 131071, 2147483629])
+        n = rng.randint(1, 7)
+        m = rng.randint(1, 30)
+        TM = [rng.choice([0, 0, 1, p - 1, 2, 3]) % p for _ in range(n * m)]
+        row = rng.randint(0, n - 1)
+        off = (row // 4) * 4
+        Cand = [0] * (n * n)
+        for i in range(row):                        # previous rows: random (possibly dependent) rows
+            for j in range(n):
+                Cand[i * n + j] = rng.choice([0, 1, p - 1, 2]) % p
+        C = rng.randint(1, 5)
+        coeffs = [0, 1, p - 1, 2 % p, (p - 2) % p][:C]
+        w0 = rng.choice([-1, 0, m // 2])
+        got, _ = cob_search(n, m, TM, Cand, row, off, coeffs, p, w0, 0 if w0 >= 0 else -1)
+        exp = oracle_cob_search(n, m, TM, Cand, row, off, coeffs, p, w0, 0 if w0 >= 0 else -1)
+        assert got == exp, (trial, p, n, m, row, C, w0)
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms", "3x3x3_23_58_P.sms"])
+def test_sparsifier_cli_gpu_equals_host(hip, name):
+    """bin/sparsifier -q p -c C on the GPU prints the same change of basis as the host enumeration and the
+    factorization is consistent (the reference's own criterion, bin/FDT.sh:64)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+    path = os.path.join(DATA, name)
+    g = subprocess.run([SPS, "-q", str(P), "-c", "6", "-S", path], capture_output=True, text=True, timeout=600)
+    h = subprocess.run([SPS, "-q", str(P), "-c", "6", "-S", "--gpu", "0", path], capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
+    assert "SUCCESS: consistent factorization" in g.stderr
+    assert g.stdout == h.stdout
+    assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)

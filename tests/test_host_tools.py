@@ -167,3 +167,29 @@ def test_lu_method_programs_verify(name, field):
     m = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
     final_adds = int(m.group(1)) if m else 0          # the statistics lines are omitted for a 0|0 program (src/optimizer.cpp:89)
     assert int(re.search(r"# \S*?(\d+)\tadditions", err2).group(1)) == final_adds
+
+
+SPS = os.path.join(ROOT, "bin", "sparsifier")
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "4x4x4_49_156_P.sms", "2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms",
+                                  "3x3x3_23_58_R.sms", "4x4x4_48_rational_P.sms", "3o3o6_Toom4_P.sms", "cyclic.sms"])
+@pytest.mark.parametrize("args", [[], ["-q", "7", "--gpu", "0"], ["-q", str(P), "--gpu", "0", "-b", "1"], ["-U", "0"]])
+def test_sparsifier_factorization_is_consistent(name, args):
+    """bin/FDT.sh:64-66: `sparsifier [-q 7] -c 5 file` must print SUCCESS (M == Res . CoB); the residue is never
+    denser than the input; stdout carries the change of basis only."""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([SPS, "-c", "5", "-S"] + args + [path])
+    assert rc == 0, err
+    assert "SUCCESS: consistent factorization" in err and "ERROR" not in err
+    mm = re.search(r"with (\d+) non-zeroes \((\d+) alt\.\) instead of (\d+)", err)
+    assert mm and int(mm.group(1)) <= int(mm.group(3))
+    lines = out.strip().splitlines()
+    n = int(lines[0].split()[0])
+    assert lines[0].split()[1] == str(n) and lines[-1] == "0 0 0"          # an n x n matrix in SMS format
+
+
+def test_sparsifier_finds_the_known_sparse_basis_of_winograd():
+    """Winograd's L matrix (14 non-zeros) has an alternative basis with 10 (data/2x2x2_7_DPS-accurate-ALT_L.sms)."""
+    rc, out, err = run([SPS, "-c", "4", "-S", os.path.join(DATA, "2x2x2_7_Winograd_L.sms")])
+    assert rc == 0 and re.search(r"with (\d+) non-zeroes", err).group(1) == "10"
