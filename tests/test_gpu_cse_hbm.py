@@ -61,3 +61,17 @@ def test_rows_longer_than_the_wave_kernel_limit_select_hbm_automatically(hip):
     plan = CSEPlan(12, 100, rp, c, v, P)
     assert plan.is_hbm
     assert plan.cost_many(seed0=0, n=24) == tuple(M.cost_many(seed0=0, nseeds=24, nthreads=8))
+
+
+@pytest.mark.parametrize("shape,unit_frac,seed", [((220, 48), 1.0, 1), ((180, 64), 0.7, 2), ((64, 96), 0.5, 3)])
+def test_hbm_variant_mid_size_random(hip, shape, unit_frac, seed):
+    """Matrices too large for the wave kernel's limits in at least one dimension (rows > 64 entries or op-counts), a few
+    thousand non-zeros, coefficients from {+-1, +-2, +-1/2}: the oracle still finishes in seconds."""
+    from plinopt_amd import CSEPlan
+    m, n = shape
+    mm, nn, rows = synth.sweep(900 + seed, P, m, n, density=0.3, unit_frac=unit_frac)
+    rp, c, v = synth.to_csr(rows, P)
+    M = OracleMatrix(mm, nn, rp, c, v, P)
+    plan = CSEPlan(mm, nn, rp, c, v, P, hbm=True)
+    ncand = 6
+    assert plan.cost_many(seed0=40, n=ncand) == tuple(M.cost_many(seed0=40, nseeds=ncand, nthreads=8))
