@@ -786,11 +786,24 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     HIPCHK(hipMemcpy(d_best, &init, 8, hipMemcpyHostToDevice));
     plo::CobJob J{}; J.n = n; J.m = m; J.qn = qn; J.fb = fb; J.C = ncoeffs; J.p = p; J.mu = (~0ull) / p; J.total = total;
     J.tm = d_tm; J.nb = d_nb; J.coeffs = d_cf; J.best = d_best;
-    HIPCHK(hipFuncSetAttribute((const void *)plo::cob_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)g_cus * 8));
+    // table form when 4*C*(m+qn) products fit LDS (odd strides: the lanes of a wave read rows l, l+1, ... of one column)
+    const uint32_t mstride = m | 1u, qstride = std::max<uint32_t>(qn, 1u) | 1u;
+    const size_t lds_tab = 4ull * ncoeffs * ((size_t)mstride + qstride) * 4;
+    const bool use_tab = lds_tab <= 72u * 1024u && !getenv("PLO_COB_GENERIC");
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, g_stream));
-    hipLaunchKernelGGL(plo::cob_kernel, dim3((uint32_t)grid), dim3(256), lds, g_stream, J);
+    uint64_t grid;
+    if (use_tab) {
+        HIPCHK(hipFuncSetAttribute((const void *)plo::cob_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tab));
+        const uint64_t groups = (uint64_t)ncoeffs * ncoeffs * ncoeffs;
+        grid = std::max<uint64_t>(1, std::min<uint64_t>((groups + 3) / 4, (uint64_t)g_cus * 2));
+        HIPCHK(hipEventRecord(e0, g_stream));
+        hipLaunchKernelGGL(plo::cob_tab_kernel, dim3((uint32_t)grid), dim3(256), lds_tab, g_stream, J, mstride, qstride);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *)plo::cob_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        grid = std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)g_cus * 8));
+        HIPCHK(hipEventRecord(e0, g_stream));
+        hipLaunchKernelGGL(plo::cob_kernel, dim3((uint32_t)grid), dim3(256), lds, g_stream, J);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, g_stream)); HIPCHK(hipEventSynchronize(e1));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -801,7 +814,7 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     out->found = w != init ? 1u : 0u;
     if (out->found) { const uint32_t sc = (uint32_t)(w >> 32) - 1u; out->zeros_v = (int32_t)(sc / (n + 1)); out->zeros_w = (int32_t)(sc % (n + 1)); out->index = (uint32_t)~(uint32_t)w; }
     else { out->zeros_v = w0; out->zeros_w = w1; out->index = 0; }
-    st->kernel_ms = ms; st->launches = 1; st->candidates = total; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)lds; st->waves_per_wg = 4;
+    st->kernel_ms = ms; st->launches = 1; st->candidates = total; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)(use_tab ? lds_tab : lds); st->waves_per_wg = 4;
     st->algo_bytes = 16ull * m + 8;                       // the 4 x m block of TM, once, plus the result word
     st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PLO_OK;

@@ -76,4 +76,70 @@ __global__ __launch_bounds__(256) void cob_kernel(CobJob J)
     if ((threadIdx.x & 63u) == 0 && mybest) atomicMax(J.best, (unsigned long long)mybest);
 }
 
+// Table form of the same enumeration (used whenever the tables fit LDS).  With P[t][x][c] = coeffs[x] * TM[off+t][c]
+// mod p tabulated once per workgroup, v_c(i,j,k,l) = P0[i][c] + P1[j][c] + P2[k][c] + P3[l][c], and v_c == 0 iff
+// P3[l][c] == neg_c, where neg_c = -(P0[i][c]+P1[j][c]+P2[k][c]) mod p depends on (i,j,k) only.  One wavefront
+// takes one (i,j,k); its lanes take l; per column the wave does three broadcast LDS reads and a reduction for
+// neg_c, each lane one LDS read and one compare.  The independence test w.N != 0 has the same shape on the
+// tabulated products with the nullspace block.  ~0.2 wave instructions per candidate and column instead of ~90.
+__global__ __launch_bounds__(256) void cob_tab_kernel(CobJob J, uint32_t ms /* odd row stride >= m */, uint32_t qs /* odd stride >= qn */)
+{
+    extern __shared__ uint32_t cl[];
+    const uint32_t p = J.p, C = J.C, m = J.m, qn = J.qn, fb = J.fb;
+    const uint64_t mu = J.mu;
+    uint32_t *PT = cl;                       // [4][C][ms]
+    uint32_t *PN = cl + 4u * C * ms;         // [4][C][qs]
+    for (uint32_t x = threadIdx.x; x < 4u * C * ms; x += blockDim.x) {
+        const uint32_t c = x % ms, ci = (x / ms) % C, t = x / (ms * C);
+        PT[x] = (c < m && t < fb) ? cob_mul(J.coeffs[ci], J.tm[t * m + c], p, mu) : 0u;
+    }
+    for (uint32_t x = threadIdx.x; x < 4u * C * qs; x += blockDim.x) {
+        const uint32_t c = x % qs, ci = (x / qs) % C, t = x / (qs * C);
+        PN[x] = (c < qn && t < fb) ? cob_mul(J.coeffs[ci], J.nb[t * qn + c], p, mu) : 0u;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
+    const uint64_t ngroups = (uint64_t)C * C * C;
+    uint64_t mybest = 0;
+    for (uint64_t gidx = (uint64_t)blockIdx.x * nwaves + (threadIdx.x >> 6); gidx < ngroups; gidx += (uint64_t)gridDim.x * nwaves) {
+        uint32_t x = (uint32_t)gidx; const uint32_t k = x % C; x /= C; const uint32_t j = x % C, i = x / C;
+        const uint32_t *p0 = PT + (0u * C + i) * ms, *p1 = PT + (1u * C + j) * ms, *p2 = PT + (2u * C + k) * ms;
+        const uint32_t *n0 = PN + (0u * C + i) * qs, *n1 = PN + (1u * C + j) * qs, *n2 = PN + (2u * C + k) * qs;
+        uint32_t zfix = J.n - fb;
+        if (fb > 0u && J.coeffs[i] == 0u) ++zfix;
+        if (fb > 1u && J.coeffs[j] == 0u) ++zfix;
+        if (fb > 2u && J.coeffs[k] == 0u) ++zfix;
+        for (uint32_t l0 = 0; l0 < C; l0 += 64u) {
+            const uint32_t l = l0 + lane; const bool act = l < C;
+            const uint32_t *p3 = PT + (3u * C + (act ? l : 0u)) * ms, *n3 = PN + (3u * C + (act ? l : 0u)) * qs;
+            bool indep = false;
+            for (uint32_t c = 0; c < qn; ++c) {
+                uint64_t s = (uint64_t)n0[c] + n1[c] + n2[c];
+                if (s >= p) s -= p; if (s >= p) s -= p;
+                const uint32_t neg = s ? p - (uint32_t)s : 0u;
+                indep |= n3[c] != neg;
+            }
+            uint32_t zv = 0;
+            for (uint32_t c = 0; c < m; ++c) {
+                uint64_t s = (uint64_t)p0[c] + p1[c] + p2[c];
+                if (s >= p) s -= p; if (s >= p) s -= p;
+                const uint32_t neg = s ? p - (uint32_t)s : 0u;
+                zv += (p3[c] == neg) ? 1u : 0u;
+            }
+            if (act && indep) {
+                const uint32_t zw = zfix + ((fb > 3u && J.coeffs[l] == 0u) ? 1u : 0u);
+                const uint64_t idx = gidx * C + l;
+                const uint64_t key = ((uint64_t)(zv * (J.n + 1u) + zw + 1u) << 32) | (uint32_t)(~(uint32_t)idx);
+                mybest = key > mybest ? key : mybest;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mybest, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mybest >> 32), o);
+        const uint64_t v = ((uint64_t)hi << 32) | lo; mybest = v > mybest ? v : mybest;
+    }
+    if (lane == 0 && mybest) atomicMax(J.best, (unsigned long long)mybest);
+}
+
 } // namespace plo
