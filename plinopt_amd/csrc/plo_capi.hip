@@ -243,6 +243,7 @@ int build_big_plan(plo_plan *pl)
     const uint32_t multcap = (uint32_t)std::min<uint64_t>((uint64_t)naive / 2 + 8, NC);
     uint64_t cap = 1024;
     while (cap < 2ull * keys.size() + 1024ull || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;
+    if (const char *e = getenv("PLO_BIG_HBITS")) { const long hb = strtol(e, nullptr, 10); if (hb >= 10 && hb <= 30 && (1ull << hb) > keys.size() + keys.size() / 8) cap = 1ull << hb; }   // experiment knob
     const uint32_t hbits = ceil_log2((uint32_t)std::min<uint64_t>(cap, 1ull << 31));
     if (cap > (1ull << 30)) return fail(PLO_E_CAPACITY, "pair table above 2^30 slots");
     std::vector<uint64_t> tab(cap, PLO_GEMPTY);
@@ -257,6 +258,7 @@ int build_big_plan(plo_plan *pl)
     B.maxf0 = maxf + 1; B.M0 = maxf; B.multcap = multcap; B.scr_stride = maxlen;
     B.dmcap = (uint32_t)std::min<uint64_t>(1u << 20, cap); B.hlcap = (uint32_t)std::min<uint64_t>(1u << 18, cap);   // window list: <= hlcap/2 keys per window, ping-pong halves
     B.mu = (~0ull) / p;
+    B.mers = 0; for (uint32_t k = 2; k < 31; ++k) if (p == (1u << k) - 1u) B.mers = k;     // Mersenne modulus: shift-and-add reduction
     int rc;
     if ((rc = upload(pl, pl->rowptr, &B.rs)) || (rc = upload(pl, pl->col, &B.col0)) || (rc = upload(pl, pl->val, &B.val0)) ||
         (rc = upload(pl, inv, &B.inv0)) || (rc = upload(pl, tptr, &B.tptr)) || (rc = upload(pl, trows, &B.trows)) ||

@@ -37,7 +37,7 @@ namespace plo {
 #define PLO_GEMPTY 0xFFFFFFFFFFFF0000ull
 
 struct BigPlan {
-    uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride, aggbits;
+    uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride, aggbits, mers;
     uint64_t mu;
     const uint32_t *rs, *col0, *val0, *inv0, *tptr, *trows, *ucount0, *hist0;
     const uint64_t *tab0;
@@ -61,8 +61,12 @@ __device__ __forceinline__ uint32_t ghash(uint64_t key, uint32_t hbits) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> (64u - hbits));
 }
-__device__ __forceinline__ uint32_t bmul(uint32_t a, uint32_t b, uint32_t p, uint64_t mu) {
+__device__ __forceinline__ uint32_t bmul(uint32_t a, uint32_t b, uint32_t p, uint64_t mu, uint32_t mers) {
     uint64_t x = (uint64_t)a * b;
+    if (mers) {                                   // p = 2^mers - 1 (e.g. 131071 = 2^17 - 1): two folds and a correction
+        x = (x & p) + (x >> mers); x = (x & p) + (x >> mers);
+        return (uint32_t)(x >= p ? x - p : x);
+    }
     uint64_t q = __umul64hi(x, mu);
     uint64_t r = x - q * p;
     while (r >= p) r -= p;
@@ -225,7 +229,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
     uint64_t *DM    = (uint64_t *)(ws + P.o_dm), *HL = (uint64_t *)(ws + P.o_hl);
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
-    const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m;
+    const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
     const uint64_t mu = P.mu, cap = 1ull << P.hbits;
 #define BKEY(a_, b_, r_) (((uint64_t)(a_) << abits) | ((uint64_t)(b_) << rb) | (uint64_t)(r_))
 
@@ -414,12 +418,12 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 const int pb = row_find(col, base, L, b);
                 if (pb < 0) continue;
                 const uint32_t va = val[base + pa], vb = val[base + pb];
-                if (vb != bmul(r, va, p, mu)) continue;
+                if (vb != bmul(r, va, p, mu, mers)) continue;
                 const uint32_t idx = atomicAdd(&sh.naff, 1u);
                 const uint32_t ia = inv[base + pa], ib = inv[base + pb];
                 uint32_t *rec = aff + 8u * idx;                             // record: row, positions and values of the two entries
                 rec[0] = i; rec[1] = (uint32_t)pa; rec[2] = (uint32_t)pb; rec[3] = va; rec[4] = ia; rec[5] = vb; rec[6] = ib;
-                if (idx == 0) sh.invr = bmul(va, ib, p, mu);               // 1/r
+                if (idx == 0) sh.invr = bmul(va, ib, p, mu, mers);               // 1/r
             }
         }
         __threadfence(); BSYNC();
@@ -435,8 +439,8 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             for (uint32_t z = lane; z < L; z += 64u) {
                 if ((int)z == pa || (int)z == pb) continue;
                 const uint32_t c = col[base + z], v = val[base + z], iv = inv[base + z];
-                const uint64_t k1 = c < a ? BKEY(c, a, bmul(va, iv, p, mu)) : BKEY(a, c, bmul(v, ia, p, mu));
-                const uint64_t k2 = c < b ? BKEY(c, b, bmul(vb, iv, p, mu)) : BKEY(b, c, bmul(v, ib, p, mu));
+                const uint64_t k1 = c < a ? BKEY(c, a, bmul(va, iv, p, mu, mers)) : BKEY(a, c, bmul(v, ia, p, mu, mers));
+                const uint64_t k2 = c < b ? BKEY(c, b, bmul(vb, iv, p, mu, mers)) : BKEY(b, c, bmul(v, ib, p, mu, mers));
                 if (!agg_add(agg, aggbits, k1)) {
                     uint32_t o1 = gtab_dec(tab, k1, hbits);
                     if (!o1) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
@@ -487,7 +491,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (have && (int)z != pa && (int)z != pb) {
                     const uint32_t np = base + z - ((int)z > pa ? 1u : 0u) - ((int)z > pb ? 1u : 0u);
                     col[np] = c; val[np] = v; inv[np] = iv;
-                    const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu));
+                    const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu, mers));
                     if (agg_add(agg, aggbits, nk)) continue;
                     const uint32_t nc = gtab_inc(tab, nk, hbits);
                     if (!nc) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
@@ -581,7 +585,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
     uint32_t *len   = (uint32_t *)(ws + P.o_len);
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
     uint32_t *tcnt  = (uint32_t *)(ws + P.o_tcnt), *tptr2 = (uint32_t *)(ws + P.o_tptr2), *tlist = (uint32_t *)(ws + P.o_tlist), *cols2 = (uint32_t *)(ws + P.o_cols2);
-    const uint32_t p = P.p, rb = P.rb, m = P.m, ncols0 = sh.ncols;
+    const uint32_t p = P.p, rb = P.rb, m = P.m, ncols0 = sh.ncols, mers = P.mers;
     const uint64_t mu = P.mu;
 
     if (tid == 0) { sh.acc0 = 0; sh.acc1 = 0; sh.errflag = 0; }
@@ -736,7 +740,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
                         if (found) cand = 1ull << __builtin_ctzll(cand);
                         bool hit = false;
                         if ((cand >> lane) & 1ull) {
-                            const uint32_t quot = bmul(vj, iv1, p, mu), nq = p - quot;
+                            const uint32_t quot = bmul(vj, iv1, p, mu, mers), nq = p - quot;
                             const uint32_t base = P.rs[row], L = len[row];
                             for (uint32_t z = 0; z < L; ++z) {
                                 const uint32_t tv = val[base + z];
@@ -757,7 +761,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
                     }
                     uint32_t addone = 0;
                     if ((int)lane == nx) {
-                        const uint32_t quot = bmul(vj, iv1, p, mu), iquot = bmul(ivj, v1, p, mu);
+                        const uint32_t quot = bmul(vj, iv1, p, mu, mers), iquot = bmul(ivj, v1, p, mu, mers);
                         const uint32_t eq = babs(quot, p), ieq = (quot == eq) ? iquot : p - iquot;
                         const uint32_t base = P.rs[row], L = len[row];
                         uint32_t w = 0, f = 1;
