@@ -79,6 +79,7 @@ int build_plan(plo_plan *pl)
     if (maxlen > 64) return fail(PLO_E_CAPACITY, "row longer than 64 entries: not handled by the LDS-resident wave kernel");
     if (m == 0 || m > 31 * 64) return fail(PLO_E_CAPACITY, "row count outside [1,1984] for the wave kernel");
     const uint32_t mw = (m + 63) / 64;
+    if (!unit && mw > 1) return fail(PLO_E_CAPACITY, "more than 64 rows with non +-1 coefficients: ProgramGen of the wave kernel keeps one row per lane");   // -> HBM family
     // every CSE step lowers sum(len-1) by its frequency >= 2, so there are at most naive_adds/2 steps
     uint32_t naive = 0;
     for (uint32_t i = 0; i < m; ++i) { uint32_t l = rowptr[i + 1] - rowptr[i]; if (l > 1) naive += l - 1; }

@@ -75,3 +75,16 @@ def test_hbm_variant_mid_size_random(hip, shape, unit_frac, seed):
     plan = CSEPlan(mm, nn, rp, c, v, P, hbm=True)
     ncand = 6
     assert plan.cost_many(seed0=40, n=ncand) == tuple(M.cost_many(seed0=40, nseeds=ncand, nthreads=8))
+
+
+def test_general_matrix_with_many_rows_goes_to_hbm_family(hip):
+    """> 64 rows with rational coefficients: the wave kernel's general ProgramGen keeps one row per lane, so plan creation
+    selects the HBM family by itself (never a run-time 'unsupported')."""
+    from plinopt_amd import CSEPlan
+    mm, nn, rows = synth.sweep(4242, P, 100, 24, density=0.3, unit_frac=0.6)
+    rp, c, v = synth.to_csr(rows, P)
+    M = OracleMatrix(mm, nn, rp, c, v, P)
+    plan = CSEPlan(mm, nn, rp, c, v, P)
+    assert plan.is_hbm
+    assert plan.cost_many(seed0=3, n=12) == tuple(M.cost_many(seed0=3, nseeds=12, nthreads=8))
+    assert plan.search(3, 12) == M.search(3, 12, nthreads=8)
