@@ -284,7 +284,7 @@ int build_big_plan(plo_plan *pl)
     if (!pl->d_err) HIPCHK(hipMalloc((void **)&pl->d_err, sizeof(uint32_t)));
     if (!pl->d_best) HIPCHK(hipMalloc((void **)&pl->d_best, sizeof(unsigned long long)));
     if (!pl->d_next) HIPCHK(hipMalloc((void **)&pl->d_next, sizeof(unsigned long long)));
-    if (!pl->d_stats) HIPCHK(hipMalloc((void **)&pl->d_stats, 16 * sizeof(uint32_t)));
+    if (!pl->d_stats) HIPCHK(hipMalloc((void **)&pl->d_stats, 32 * sizeof(uint32_t)));
     pl->big = true; pl->waves_per_wg = PLO_BIG_THREADS / 64; pl->lds_bytes = pl->big_lds + (uint32_t)sizeof(plo::BigShared);
     return PLO_OK;
 }
@@ -325,10 +325,15 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = pl->waves_per_wg; st->algo_bytes = pl->algo_bytes; }
     if (getenv("PLO_BIG_STATS")) {
-        uint32_t hs[16] = {0};
-        if (hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess)
+        uint32_t hs[32] = {0};
+        if (hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "# big kernel (last candidate): steps %u, full scans %u, level rebuilds %u; phase us: level %u select %u rows %u sweep1 %u flush1 %u sweep2 %u flush2 %u tail %u\n",
                     hs[0], hs[1], hs[2], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11]);
+#ifdef PLO_BIG_PROFILE
+            fprintf(stderr, "#   steps by rows/step [>=256, 64.., 16.., <16]: %u %u %u %u; sweep1 us %u %u %u %u; sweep2 us %u %u %u %u; fallbacks %u %u; flushed keys %u %u\n",
+                    hs[24], hs[25], hs[26], hs[27], hs[16], hs[17], hs[18], hs[19], hs[20], hs[21], hs[22], hs[23], hs[28], hs[29], hs[30], hs[31]);
+#endif
+        }
     }
     if (err) {
         static const char *names[] = {"pair table", "frequency/row-count mismatch", "column bound", "level list", "window list", "multiplier list", "tie selection", "ProgramGen"};

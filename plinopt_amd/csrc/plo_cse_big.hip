@@ -55,8 +55,27 @@ struct BigJob {
 
 enum { BERR_TABLE = 11, BERR_FREQ = 12, BERR_COLS = 13, BERR_DM = 14, BERR_HL = 15, BERR_MULT = 16, BERR_SEL = 17, BERR_PGEN = 18 };
 
-__device__ __forceinline__ uint64_t gload64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t gload32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A candidate lives in one workgroup: every atomic, atomic load and fence on its workspace is workgroup scope.  On
+// gfx950 agent-scope atomics and sc1 loads are performed at the memory side of the fabric (the 8 XCDs' L2s are not
+// coherent with each other) -- measured: 1.8e7 DRAM atomics per candidate before this change -- while workgroup scope
+// lets the XCD's L2 do them.  Only the work counter, the error word and the best word are shared between workgroups.
+#ifdef PLO_BIG_AGENT_SCOPE
+#define PLO_BIG_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#define PLO_BIG_FENCE() __threadfence()
+#else
+#define PLO_BIG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#define PLO_BIG_FENCE() __threadfence_block()
+#endif
+template <class T> __device__ __forceinline__ T wg_add(T *p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
+template <class T> __device__ __forceinline__ T wg_sub(T *p, T v) { return __hip_atomic_fetch_add(p, (T)(0 - v), __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
+template <class T> __device__ __forceinline__ T wg_or(T *p, T v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
+template <class T> __device__ __forceinline__ T wg_max(T *p, T v) { return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
+template <class T> __device__ __forceinline__ T wg_cas(T *p, T expected, T desired) {
+    __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, PLO_BIG_SCOPE);
+    return expected;
+}
+__device__ __forceinline__ uint64_t gload64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
+__device__ __forceinline__ uint32_t gload32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
 __device__ __forceinline__ uint32_t ghash(uint64_t key, uint32_t hbits) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> (64u - hbits));
@@ -72,6 +91,12 @@ __device__ __forceinline__ uint32_t bmul(uint32_t a, uint32_t b, uint32_t p, uin
     while (r >= p) r -= p;
     return (uint32_t)r;
 }
+// 1/x mod p (x != 0): x^(p-2)
+__device__ __forceinline__ uint32_t binv(uint32_t x, uint32_t p, uint64_t mu, uint32_t mers) {
+    uint32_t res = 1u, bs = x;
+    for (uint32_t e = p - 2u; e; e >>= 1) { if (e & 1u) res = bmul(res, bs, p, mu, mers); bs = bmul(bs, bs, p, mu, mers); }
+    return res;
+}
 __device__ __forceinline__ bool babsone(uint32_t e, uint32_t p) { return e == 1u || e == p - 1u; }
 __device__ __forceinline__ uint32_t babs(uint32_t e, uint32_t p) { uint32_t a = e ? p - e : 0u; return a < e ? a : e; }
 
@@ -81,7 +106,7 @@ __device__ __forceinline__ uint32_t gtab_dec(uint64_t *tab, uint64_t key, uint32
     uint32_t s = ghash(key, hbits);
     for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
         uint64_t v = gload64(&tab[s]);
-        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], ~0ull); return (uint32_t)(old & PLO_GVMASK); }
+        if ((v >> PLO_GVB) == key) { uint64_t old = wg_add((unsigned long long *)&tab[s], ~0ull); return (uint32_t)(old & PLO_GVMASK); }
         if (v == PLO_GEMPTY) return 0u;
         s = (s + 1u) & mask;
     }
@@ -93,9 +118,9 @@ __device__ __forceinline__ uint32_t gtab_inc(uint64_t *tab, uint64_t key, uint32
     uint32_t s = ghash(key, hbits);
     for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
         uint64_t v = gload64(&tab[s]);
-        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], 1ull); return (uint32_t)(old & PLO_GVMASK) + 1u; }
+        if ((v >> PLO_GVB) == key) { uint64_t old = wg_add((unsigned long long *)&tab[s], 1ull); return (uint32_t)(old & PLO_GVMASK) + 1u; }
         if ((v & PLO_GVMASK) == 0ull) {
-            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | 1ull));
+            uint64_t old = wg_cas((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | 1ull));
             if (old == v) return 1u;
             continue;
         }
@@ -121,11 +146,11 @@ __device__ __forceinline__ bool gtab_add(uint64_t *tab, uint64_t key, uint32_t i
     for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
         uint64_t v = gload64(&tab[s]);
         if (v == PLO_GEMPTY) {
-            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | incv));
+            uint64_t old = wg_cas((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | incv));
             if (old == v) return true;
             continue;
         }
-        if ((v >> PLO_GVB) == key) { atomicAdd((unsigned long long *)&tab[s], (unsigned long long)incv); return true; }
+        if ((v >> PLO_GVB) == key) { wg_add((unsigned long long *)&tab[s], (unsigned long long)incv); return true; }
         s = (s + 1u) & mask;
     }
     return false;
@@ -138,11 +163,11 @@ __device__ __forceinline__ bool gtab_flag(uint64_t *tab, uint64_t key, uint32_t 
     for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
         uint64_t v = gload64(&tab[s]);
         if (v == PLO_GEMPTY) {
-            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | flag));
+            uint64_t old = wg_cas((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | flag));
             if (old == v) return true;
             continue;
         }
-        if ((v >> PLO_GVB) == key) { atomicOr((unsigned long long *)&tab[s], (unsigned long long)flag); return true; }
+        if ((v >> PLO_GVB) == key) { wg_or((unsigned long long *)&tab[s], (unsigned long long)flag); return true; }
         s = (s + 1u) & mask;
     }
     return false;
@@ -154,7 +179,7 @@ __device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint3
     uint32_t s = ghash(key, hbits);
     for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
         uint64_t v = gload64(&tab[s]);
-        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], (unsigned long long)(0ull - (uint64_t)d)); return (uint32_t)(old & PLO_GVMASK); }
+        if ((v >> PLO_GVB) == key) { uint64_t old = wg_add((unsigned long long *)&tab[s], (unsigned long long)(0ull - (uint64_t)d)); return (uint32_t)(old & PLO_GVMASK); }
         if (v == PLO_GEMPTY) return 0u;
         s = (s + 1u) & mask;
     }
@@ -166,9 +191,9 @@ __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint3
     uint32_t s = ghash(key, hbits);
     for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
         uint64_t v = gload64(&tab[s]);
-        if ((v >> PLO_GVB) == key) { uint64_t old = atomicAdd((unsigned long long *)&tab[s], (unsigned long long)d); return (uint32_t)(old & PLO_GVMASK); }
+        if ((v >> PLO_GVB) == key) { uint64_t old = wg_add((unsigned long long *)&tab[s], (unsigned long long)d); return (uint32_t)(old & PLO_GVMASK); }
         if ((v & PLO_GVMASK) == 0ull) {
-            uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | d));
+            uint64_t old = wg_cas((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | d));
             if (old == v) return 0u;
             continue;
         }
@@ -187,9 +212,9 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_
     uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - aggbits));
     for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
         uint64_t v = va[s];
-        if ((v >> PLO_GVB) == key) { atomicAdd((unsigned long long *)&agg[s], 1ull); return true; }
+        if ((v >> PLO_GVB) == key) { wg_add((unsigned long long *)&agg[s], 1ull); return true; }
         if (v == PLO_GEMPTY) {
-            uint64_t old = atomicCAS((unsigned long long *)&agg[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | 1ull));
+            uint64_t old = wg_cas((unsigned long long *)&agg[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | 1ull));
             if (old == v) return true;
             continue;                      // somebody took the slot: look at it again
         }
@@ -210,6 +235,9 @@ struct BigShared {
     uint32_t a, b, r; uint64_t kprime; uint64_t selkey;
     uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
+#ifdef PLO_BIG_PROFILE
+    unsigned long long tb1[4], tb2[4]; uint32_t nb[4], fb1, fb2, fl1, fl2;   // sweep clocks by step size class, fallbacks, flushed keys
+#endif
     uint32_t part[8];
     uint64_t sel[PLO_BIG_SELCAP];
 };
@@ -256,9 +284,12 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         sh.rng = 1u + (uint32_t)(x % 2147483646ull);
         sh.M = P.M0; sh.theta = P.M0 + 1u; sh.ncols = n; sh.nbadd = 0; sh.nbmul = 0; sh.nmult = 0; sh.dmcount = 0; sh.hlcount = 0;
         for (int q = 0; q < 8; ++q) sh.tph[q] = 0;
+#ifdef PLO_BIG_PROFILE
+        for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0;
+#endif
         sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0;
     }
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
 
     bool need_rebuild = true;
     unsigned long long tstamp = wall_clock64();
@@ -282,7 +313,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (tid == 0) {
                     uint64_t acc = 0; uint32_t th = M;
                     for (uint32_t f = M; f >= 2u; --f) { if (acc + hist[f] > P.hlcap / 2u) break; acc += hist[f]; th = f; }
-                    if (hist[M] > P.hlcap / 2u) atomicMax(&sh.errflag, (uint32_t)BERR_HL);
+                    if (hist[M] > P.hlcap / 2u) wg_max(&sh.errflag, (uint32_t)BERR_HL);
                     sh.theta = th; sh.hlcount = 0; sh.hlbad = 0; ++sh.fullscans;
                 }
                 BSYNC();
@@ -294,8 +325,8 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if ((uint32_t)(v[u] & PLO_GVMASK) >= th && v[u] != PLO_GEMPTY) {
-                            uint32_t idx = atomicAdd(&sh.hlcount, 1u);
-                            if (idx < P.hlcap) HL[idx] = v[u] >> PLO_GVB; else atomicMax(&sh.errflag, (uint32_t)BERR_HL);
+                            uint32_t idx = wg_add(&sh.hlcount, 1u);
+                            if (idx < P.hlcap) HL[idx] = v[u] >> PLO_GVB; else wg_max(&sh.errflag, (uint32_t)BERR_HL);
                         }
                 }
                 BSYNC();
@@ -305,7 +336,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             for (uint32_t c = tid; c < sh.ncols; c += nth) cntM[c] = 0u;
             for (uint32_t c = tid; c < 512u; c += nth) sh.cblk[c] = 0u;
             const uint32_t hn = sh.hlcount < P.hlcap ? sh.hlcount : P.hlcap;
-            __threadfence(); BSYNC();
+            PLO_BIG_FENCE(); BSYNC();
             if (tid == 0) { sh.dmcount = 0; sh.hlcount = 0; ++sh.rebuilds; }
             BSYNC();
             uint64_t *HL2 = HL + P.hlcap;                                       // ping-pong halves of the window list
@@ -313,18 +344,18 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             for (uint32_t k = tid; k < hn; k += nth) {
                 const uint64_t key = HL[k];
                 const uint32_t c = gtab_find(tab, key, hbits);
-                if (c >= th2) HL2[atomicAdd(&sh.hlcount, 1u)] = key;
+                if (c >= th2) HL2[wg_add(&sh.hlcount, 1u)] = key;
                 if (c == M) {
                     const uint32_t fc = (uint32_t)(key >> abits);
-                    atomicAdd(&cntM[fc], 1u); atomicAdd(&sh.cblk[fc >> 6], 1u);
-                    uint32_t idx = atomicAdd(&sh.dmcount, 1u);
-                    if (idx < P.dmcap) DM[idx] = key; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
+                    wg_add(&cntM[fc], 1u); wg_add(&sh.cblk[fc >> 6], 1u);
+                    uint32_t idx = wg_add(&sh.dmcount, 1u);
+                    if (idx < P.dmcap) DM[idx] = key; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
                 }
             }
-            __threadfence(); BSYNC();
+            PLO_BIG_FENCE(); BSYNC();
             { const uint32_t hn2 = sh.hlcount; for (uint32_t k = tid; k < hn2; k += nth) HL[k] = HL2[k]; }
             need_rebuild = false;
-            __threadfence(); BSYNC();
+            PLO_BIG_FENCE(); BSYNC();
             if (sh.errflag) break;
         }
         PLO_STAMP(0);
@@ -339,7 +370,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                     if (T > 1u) { uint64_t x = 950706376ull * (uint64_t)sh.rng; sh.rng = (uint32_t)(x % 2147483647ull); k = sh.rng % T; }
                     const uint32_t nb = (ncols + 63u) >> 6;
                     for (; blk < nb; ++blk) { const uint32_t q = sh.cblk[blk]; if (k < run + q) break; run += q; }
-                    if (blk >= nb) { atomicMax(&sh.errflag, (uint32_t)BERR_SEL); blk = 0; }
+                    if (blk >= nb) { wg_max(&sh.errflag, (uint32_t)BERR_SEL); blk = 0; }
                     sh.sel_n = 0; sh.sel_over = 0;
                 }
                 blk = (uint32_t)__shfl((int)blk, 0);
@@ -350,7 +381,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 const uint64_t kk = (((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k >> 32), 0)) << 32 | (uint32_t)__shfl((int)(uint32_t)k, 0))
                                     - (((uint64_t)(uint32_t)__shfl((int)(uint32_t)(run >> 32), 0)) << 32 | (uint32_t)__shfl((int)(uint32_t)run, 0));
                 const uint64_t hm = __ballot(kk < (uint64_t)incl);
-                if (!hm) { if (lane == 0) atomicMax(&sh.errflag, (uint32_t)BERR_SEL); }
+                if (!hm) { if (lane == 0) wg_max(&sh.errflag, (uint32_t)BERR_SEL); }
                 else if (lane == (uint32_t)__builtin_ctzll(hm)) { sh.a = c; sh.kprime = kk - (uint64_t)(incl - q); }
             }
             BSYNC();
@@ -360,7 +391,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             for (uint32_t k = tid; k < dn; k += nth) {
                 const uint64_t key = DM[k];
                 if ((uint32_t)(key >> abits) == a && gtab_find(tab, key, hbits) == M) {
-                    uint32_t idx = atomicAdd(&sh.sel_n, 1u);
+                    uint32_t idx = wg_add(&sh.sel_n, 1u);
                     if (idx < PLO_BIG_SELCAP) sh.sel[idx] = key; else sh.sel_over = 1u;
                 }
             }
@@ -377,7 +408,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                         const uint64_t key = DM[k];
                         if ((uint32_t)(key >> abits) == a && key <= mid && gtab_find(tab, key, hbits) == M) ++c;
                     }
-                    if (c) atomicAdd(&sh.sel_n, c);
+                    if (c) wg_add(&sh.sel_n, c);
                     BSYNC();
                     const uint32_t tot = sh.sel_n;
                     BSYNC();
@@ -391,7 +422,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                     for (uint32_t y = 0; y < sn; ++y) rank += (sh.sel[y] < mine) ? 1u : 0u;
                     if ((uint64_t)rank == sh.kprime) sh.selkey = mine;
                 }
-                if (tid == 0 && (uint64_t)sn <= sh.kprime) atomicMax(&sh.errflag, (uint32_t)BERR_SEL);
+                if (tid == 0 && (uint64_t)sn <= sh.kprime) wg_max(&sh.errflag, (uint32_t)BERR_SEL);
             }
             BSYNC();
             if (sh.errflag) break;
@@ -400,7 +431,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         PLO_STAMP(1);
         const uint32_t r = (uint32_t)(key & ((1ull << rb) - 1ull)), b = (uint32_t)(key >> rb) & ((1u << P.bb) - 1u), a = (uint32_t)(key >> abits);
         const uint32_t lm = ncols;
-        if (lm + 1u >= P.NCmax) { if (tid == 0) atomicMax(&sh.errflag, (uint32_t)BERR_COLS); BSYNC(); break; }
+        if (lm + 1u >= P.NCmax) { if (tid == 0) wg_max(&sh.errflag, (uint32_t)BERR_COLS); BSYNC(); break; }
         // ---- RemOneCSE :60-194
         const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
@@ -419,18 +450,21 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (pb < 0) continue;
                 const uint32_t va = val[base + pa], vb = val[base + pb];
                 if (vb != bmul(r, va, p, mu, mers)) continue;
-                const uint32_t idx = atomicAdd(&sh.naff, 1u);
+                const uint32_t idx = wg_add(&sh.naff, 1u);
                 const uint32_t ia = inv[base + pa], ib = inv[base + pb];
                 uint32_t *rec = aff + 8u * idx;                             // record: row, positions and values of the two entries
                 rec[0] = i; rec[1] = (uint32_t)pa; rec[2] = (uint32_t)pb; rec[3] = va; rec[4] = ia; rec[5] = vb; rec[6] = ib;
                 if (idx == 0) sh.invr = bmul(va, ib, p, mu, mers);               // 1/r
             }
         }
-        __threadfence(); BSYNC();
+        PLO_BIG_FENCE(); BSYNC();
         const uint32_t naff = sh.naff;
         PLO_STAMP(2);
-        if (naff != M) { if (tid == 0) atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); BSYNC(); break; }   // frequency must equal the row count
-        // sweep 1: retire the old pairs of the affected rows (:115-118)
+        if (naff != M) { if (tid == 0) wg_max(&sh.errflag, (uint32_t)BERR_FREQ); BSYNC(); break; }   // frequency must equal the row count
+        // sweep 1: retire the old pairs of the affected rows (:115-118).  In every affected row v_b = r v_a, so the two
+        // pairs an entry (c, v) forms with a and with b are functions of (c, x), x = v_a/v (c < a) or v/v_a (c > a): the
+        // pair with a has ratio x, the pair with b has ratio r x (c < a), r/x (a < c < b) or x/r (b < c).  One LDS entry
+        // per (c, x) therefore carries both retirements; the flush derives the two table keys.
         for (uint32_t q = wave; q < naff; q += nwaves) {
             const uint32_t *rec = aff + 8u * q;
             const uint32_t i = rec[0], base = P.rs[i], L = len[i];
@@ -439,41 +473,54 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             for (uint32_t z = lane; z < L; z += 64u) {
                 if ((int)z == pa || (int)z == pb) continue;
                 const uint32_t c = col[base + z], v = val[base + z], iv = inv[base + z];
-                const uint64_t k1 = c < a ? BKEY(c, a, bmul(va, iv, p, mu, mers)) : BKEY(a, c, bmul(v, ia, p, mu, mers));
+                const uint32_t x = c < a ? bmul(va, iv, p, mu, mers) : bmul(v, ia, p, mu, mers);
+                if (agg_add(agg, aggbits, ((uint64_t)c << rb) | x)) continue;
+#ifdef PLO_BIG_PROFILE
+                wg_add(&sh.fb1, 1u);
+#endif
+                const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x);
                 const uint64_t k2 = c < b ? BKEY(c, b, bmul(vb, iv, p, mu, mers)) : BKEY(b, c, bmul(v, ib, p, mu, mers));
-                if (!agg_add(agg, aggbits, k1)) {
-                    uint32_t o1 = gtab_dec(tab, k1, hbits);
-                    if (!o1) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-                    atomicSub(&hist[o1], 1u); if (o1 > 1u) atomicAdd(&hist[o1 - 1u], 1u);
-                    if (o1 == M) { atomicSub(&cntM[c < a ? c : a], 1u); atomicSub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
-                }
-                if (!agg_add(agg, aggbits, k2)) {
-                    uint32_t o2 = gtab_dec(tab, k2, hbits);
-                    if (!o2) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-                    atomicSub(&hist[o2], 1u); if (o2 > 1u) atomicAdd(&hist[o2 - 1u], 1u);
-                    if (o2 == M) { atomicSub(&cntM[c < b ? c : b], 1u); atomicSub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
-                }
-            }
-            if (lane == 0 && !agg_add(agg, aggbits, key)) {
-                uint32_t o = gtab_dec(tab, key, hbits);
-                if (!o) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
-                else { atomicSub(&hist[o], 1u); if (o > 1u) atomicAdd(&hist[o - 1u], 1u); if (o == M) { atomicSub(&cntM[a], 1u); atomicSub(&sh.cblk[a >> 6], 1u); } }
+                uint32_t o1 = gtab_dec(tab, k1, hbits);
+                if (!o1) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
+                if (o1 == M) { wg_sub(&cntM[c < a ? c : a], 1u); wg_sub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
+                uint32_t o2 = gtab_dec(tab, k2, hbits);
+                if (!o2) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                wg_sub(&hist[o2], 1u); if (o2 > 1u) wg_add(&hist[o2 - 1u], 1u);
+                if (o2 == M) { wg_sub(&cntM[c < b ? c : b], 1u); wg_sub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
             }
         }
         BSYNC();
+#ifdef PLO_BIG_PROFILE
+        if (tid == 0) { const int cl = M >= 256u ? 0 : M >= 64u ? 1 : M >= 16u ? 2 : 3; sh.tb1[cl] += wall_clock64() - tstamp; ++sh.nb[cl]; }
+#endif
         PLO_STAMP(3);
-        // flush the summed retirements: one global atomic per distinct triple
-        for (uint32_t s = tid; s < (1u << aggbits); s += nth) {
-            const uint64_t v = agg[s];
-            if (v == PLO_GEMPTY) continue;
-            agg[s] = PLO_GEMPTY;
-            const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
-            const uint32_t o = gtab_subn(tab, k, d, hbits);
-            if (o < d) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-            atomicSub(&hist[o], 1u); if (o > d) atomicAdd(&hist[o - d], 1u);
-            if (o == M) { atomicSub(&cntM[(uint32_t)(k >> abits)], 1u); atomicSub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
+        // flush the summed retirements: one global atomic per distinct triple; the triple itself loses all its M instances
+        {
+            const uint32_t invr = sh.invr;
+            auto retire = [&](uint64_t k, uint32_t d) {
+                const uint32_t o = gtab_subn(tab, k, d, hbits);
+                if (o < d) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
+                wg_sub(&hist[o], 1u); if (o > d) wg_add(&hist[o - d], 1u);
+                if (o == M) { wg_sub(&cntM[(uint32_t)(k >> abits)], 1u); wg_sub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
+            };
+            if (tid == 0) retire(key, M);
+            for (uint32_t s = tid; s < (1u << aggbits); s += nth) {
+                const uint64_t v = agg[s];
+                if (v == PLO_GEMPTY) continue;
+                agg[s] = PLO_GEMPTY;
+                const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+                const uint32_t c = (uint32_t)(k >> rb), x = (uint32_t)(k & ((1ull << rb) - 1ull));
+#ifdef PLO_BIG_PROFILE
+                wg_add(&sh.fl1, 1u);
+#endif
+                const uint32_t y = (c > a && c < b) ? binv(x, p, mu, mers) : x;
+                const uint32_t x2 = bmul(y, c < b ? r : invr, p, mu, mers);
+                retire(c < a ? BKEY(c, a, x) : BKEY(a, c, x), d);
+                retire(c < b ? BKEY(c, b, x2) : BKEY(b, c, x2), d);
+            }
         }
-        __threadfence(); BSYNC();
+        PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(4);
         if (sh.errflag) break;
         // sweep 2: rewrite the rows, insert the pairs with the new column (:96-110, :132-142)
@@ -493,16 +540,19 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                     col[np] = c; val[np] = v; inv[np] = iv;
                     const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu, mers));
                     if (agg_add(agg, aggbits, nk)) continue;
+#ifdef PLO_BIG_PROFILE
+                    wg_add(&sh.fb2, 1u);
+#endif
                     const uint32_t nc = gtab_inc(tab, nk, hbits);
-                    if (!nc) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-                    if (nc > P.maxf0) { atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
-                    if (nc > 1u) atomicSub(&hist[nc - 1u], 1u);
-                    atomicAdd(&hist[nc], 1u);
-                    if (nc == sh.theta) { uint32_t idx = atomicAdd(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = nk; else sh.hlbad = 1u; }
+                    if (!nc) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                    if (nc > P.maxf0) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
+                    if (nc > 1u) wg_sub(&hist[nc - 1u], 1u);
+                    wg_add(&hist[nc], 1u);
+                    if (nc == sh.theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = nk; else sh.hlbad = 1u; }
                     if (nc == M) {
-                        atomicAdd(&cntM[c], 1u); atomicAdd(&sh.cblk[c >> 6], 1u);
-                        uint32_t idx = atomicAdd(&sh.dmcount, 1u);
-                        if (idx < P.dmcap) DM[idx] = nk; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
+                        wg_add(&cntM[c], 1u); wg_add(&sh.cblk[c >> 6], 1u);
+                        uint32_t idx = wg_add(&sh.dmcount, 1u);
+                        if (idx < P.dmcap) DM[idx] = nk; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -510,12 +560,15 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             if (lane == 0) {
                 col[base + L - 2u] = lm; val[base + L - 2u] = coeff; inv[base + L - 2u] = icoeff;
                 len[i] = L - 1u;
-                if (ua) atomicSub(&ucount[a], 1u);
-                if (ub) atomicSub(&ucount[b], 1u);
-                if (babsone(coeff, p)) atomicAdd(&ucount[lm], 1u);
+                if (ua) wg_sub(&ucount[a], 1u);
+                if (ub) wg_sub(&ucount[b], 1u);
+                if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
             }
         }
         BSYNC();
+#ifdef PLO_BIG_PROFILE
+        if (tid == 0) { const int cl = M >= 256u ? 0 : M >= 64u ? 1 : M >= 16u ? 2 : 3; sh.tb2[cl] += wall_clock64() - tstamp; }
+#endif
         PLO_STAMP(5);
         // flush the summed insertions
         for (uint32_t s = tid; s < (1u << aggbits); s += nth) {
@@ -524,16 +577,19 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             agg[s] = PLO_GEMPTY;
             const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
             const uint32_t o = gtab_addn(tab, k, d, hbits);
-            if (o == 0xFFFFFFFFu) { atomicMax(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+#ifdef PLO_BIG_PROFILE
+            wg_add(&sh.fl2, 1u);
+#endif
+            if (o == 0xFFFFFFFFu) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
             const uint32_t nc = o + d;
-            if (nc > P.maxf0 || nc > M) { atomicMax(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
-            if (o > 0u) atomicSub(&hist[o], 1u);
-            atomicAdd(&hist[nc], 1u);
-            if (o < sh.theta && nc >= sh.theta) { uint32_t idx = atomicAdd(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = k; else sh.hlbad = 1u; }
+            if (nc > P.maxf0 || nc > M) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
+            if (o > 0u) wg_sub(&hist[o], 1u);
+            wg_add(&hist[nc], 1u);
+            if (o < sh.theta && nc >= sh.theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = k; else sh.hlbad = 1u; }
             if (nc == M) {
-                atomicAdd(&cntM[(uint32_t)(k >> abits)], 1u); atomicAdd(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u);
-                uint32_t idx = atomicAdd(&sh.dmcount, 1u);
-                if (idx < P.dmcap) DM[idx] = k; else atomicMax(&sh.errflag, (uint32_t)BERR_DM);
+                wg_add(&cntM[(uint32_t)(k >> abits)], 1u); wg_add(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u);
+                uint32_t idx = wg_add(&sh.dmcount, 1u);
+                if (idx < P.dmcap) DM[idx] = k; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
             }
         }
         PLO_STAMP(6);
@@ -552,13 +608,13 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (hit) sh.part[0] = 1u;
                 BSYNC();
                 if (tid == 0 && !sh.part[0]) {
-                    if (nm >= P.multcap) atomicMax(&sh.errflag, (uint32_t)BERR_MULT);
+                    if (nm >= P.multcap) wg_max(&sh.errflag, (uint32_t)BERR_MULT);
                     else { multc[nm] = l1; multv[nm] = asgs; sh.nmult = nm + 1u; ++sh.nbmul; }
                 }
             }
         }
         if (tid == 0) { ++sh.nbadd; ++sh.steps; sh.ncols = lm + 1u; }      // :292, :190-191
-        __threadfence(); BSYNC();
+        PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(7);
     }
     BSYNC();
@@ -593,7 +649,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
     if (P.unit) {                                                      // all +-1: len-1 additions per row (:576)
         uint32_t acc = 0;
         for (uint32_t i = tid; i < m; i += nth) { uint32_t L = len[i]; acc += L > 1u ? L - 1u : 0u; }
-        if (acc) atomicAdd(&sh.acc0, acc);
+        if (acc) wg_add(&sh.acc0, acc);
         BSYNC();
         return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | sh.nbmul;
     }
@@ -601,7 +657,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
     {
         uint32_t acc = 0;
         for (uint32_t i = tid; i < m; i += nth) acc += len[i];
-        if (acc) atomicAdd(&sh.acc0, acc);
+        if (acc) wg_add(&sh.acc0, acc);
         BSYNC();
     }
     const uint32_t live = sh.acc0 + sh.nmult;
@@ -610,29 +666,29 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
     for (uint64_t s = tid; s < (1ull << hb); s += nth) tab[s] = PLO_GEMPTY;
     BSYNC();
     if (tid == 0) sh.acc0 = 0;
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     for (uint32_t k = tid; k < sh.nmult; k += nth)
-        if (!gtab_flag(tab, ((uint64_t)multc[k] << rb) | multv[k], PLO_PGFLAG, hb)) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
-    __threadfence(); BSYNC();
+        if (!gtab_flag(tab, ((uint64_t)multc[k] << rb) | multv[k], PLO_PGFLAG, hb)) wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
+    PLO_BIG_FENCE(); BSYNC();
     // A1 occurrences of (j,e)
     for (uint32_t i = wave; i < m; i += nwaves) {
         const uint32_t base = P.rs[i], L = len[i];
         for (uint32_t z = lane; z < L; z += 64u) {
             const uint32_t e = babs(val[base + z], p);
-            if (!babsone(e, p)) if (!gtab_add(tab, ((uint64_t)col[base + z] << rb) | e, 1u, hb)) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
+            if (!babsone(e, p)) if (!gtab_add(tab, ((uint64_t)col[base + z] << rb) | e, 1u, hb)) wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
         }
     }
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     // A2 one multiplication per repeated (j,e) not yet in multiples (:335-352)
     {
         uint32_t cnt = 0;
         for (uint64_t s = tid; s < (1ull << hb); s += nth) {
             uint64_t v = gload64(&tab[s]);
-            if (v != PLO_GEMPTY && ((uint32_t)v & PLO_PGCNT) >= 2u && !((uint32_t)v & PLO_PGFLAG)) { ++cnt; atomicOr((unsigned long long *)&tab[s], (unsigned long long)PLO_PGFLAG); }
+            if (v != PLO_GEMPTY && ((uint32_t)v & PLO_PGCNT) >= 2u && !((uint32_t)v & PLO_PGFLAG)) { ++cnt; wg_or((unsigned long long *)&tab[s], (unsigned long long)PLO_PGFLAG); }
         }
-        if (cnt) atomicAdd(&sh.acc1, cnt);
+        if (cnt) wg_add(&sh.acc1, cnt);
     }
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     if (tid == 0) { sh.nbmul += sh.acc1; sh.acc1 = 0; }
     // A3 repeated entries become +-1 entries of a fresh column (:358-368)
     for (uint32_t i = wave; i < m; i += nwaves) {
@@ -645,7 +701,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
             }
         }
     }
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     // B FactorOutRows on every row (:375-420): |v| values of the row in per-wave LDS scratch
     {
         uint32_t *sc = scratch + (size_t)wave * P.scr_stride;             // per-wave scratch, stride = longest input row
@@ -677,29 +733,29 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
             if (lane == 0) len[i] = kept;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
-        if (addacc) atomicAdd(&sh.acc0, addacc);
+        if (addacc) wg_add(&sh.acc0, addacc);
     }
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     if (tid == 0) { sh.nbadd += sh.acc0; sh.acc0 = 0; }
     // C Triangle (:427-507).  Columns with >= 2 non +-1 entries, ascending; rows of each in ascending order.
     for (uint32_t c = tid; c < ncols0; c += nth) tcnt[c] = 0u;
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     for (uint32_t i = wave; i < m; i += nwaves) {
         const uint32_t base = P.rs[i], L = len[i];
-        for (uint32_t z = lane; z < L; z += 64u) { const uint32_t c = col[base + z]; if (c != PLO_BFRESH && !babsone(val[base + z], p)) atomicAdd(&tcnt[c], 1u); }
+        for (uint32_t z = lane; z < L; z += 64u) { const uint32_t c = col[base + z]; if (c != PLO_BFRESH && !babsone(val[base + z], p)) wg_add(&tcnt[c], 1u); }
     }
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     if (tid == 0) {                                                        // ordered compaction (a few thousand columns)
         uint32_t nc2 = 0, off = 0;
         for (uint32_t c = 0; c < ncols0; ++c) { const uint32_t k = gload32(&tcnt[c]); if (k >= 2u) { cols2[nc2] = c; tptr2[nc2] = off; off += k; ++nc2; } }
         tptr2[nc2] = off; sh.naff = nc2;
     }
-    __threadfence(); BSYNC();
+    PLO_BIG_FENCE(); BSYNC();
     const uint32_t nc2 = sh.naff;
     if (nc2) {
         // fill the row lists (binary search of the column in cols2), then sort each list
         for (uint32_t c = tid; c < ncols0; c += nth) tcnt[c] = 0u;
-        __threadfence(); BSYNC();
+        PLO_BIG_FENCE(); BSYNC();
         for (uint32_t i = wave; i < m; i += nwaves) {
             const uint32_t base = P.rs[i], L = len[i];
             for (uint32_t z = lane; z < L; z += 64u) {
@@ -707,20 +763,20 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
                 if (c == PLO_BFRESH || babsone(val[base + z], p)) continue;
                 uint32_t lo = 0, hi = nc2;
                 while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cols2[mid] < c) lo = mid + 1; else hi = mid; }
-                if (lo < nc2 && cols2[lo] == c) tlist[tptr2[lo] + atomicAdd(&tcnt[c], 1u)] = i;
+                if (lo < nc2 && cols2[lo] == c) tlist[tptr2[lo] + wg_add(&tcnt[c], 1u)] = i;
             }
         }
-        __threadfence(); BSYNC();
+        PLO_BIG_FENCE(); BSYNC();
         for (uint32_t x = tid; x < nc2; x += nth) {                         // insertion sort, lists are short
             uint32_t *l = tlist + tptr2[x]; const uint32_t k = tptr2[x + 1] - tptr2[x];
             for (uint32_t u = 1; u < k; ++u) { uint32_t t = l[u], w = u; while (w > 0 && l[w - 1] > t) { l[w] = l[w - 1]; --w; } l[w] = t; }
         }
-        __threadfence(); BSYNC();
+        PLO_BIG_FENCE(); BSYNC();
         if (wave == 0) {
             uint32_t mulacc = 0, addacc = 0;
             for (uint32_t x = 0; x < nc2; ++x) {
                 const uint32_t j = cols2[x], k = tptr2[x + 1] - tptr2[x];
-                if (k > 64u) { if (lane == 0) atomicMax(&sh.errflag, (uint32_t)BERR_PGEN); break; }
+                if (k > 64u) { if (lane == 0) wg_max(&sh.errflag, (uint32_t)BERR_PGEN); break; }
                 const uint32_t row = lane < k ? tlist[tptr2[x] + lane] : 0xFFFFFFFFu;
                 bool found = false;
                 for (;;) {
@@ -754,7 +810,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
                     found = true;                                           // :453-498
                     const uint32_t v1 = (uint32_t)__shfl((int)vj, it), iv1 = (uint32_t)__shfl((int)ivj, it);
                     ++mulacc;
-                    if (lane == 0) if (!gtab_flag(tab, ((uint64_t)j << rb) | v1, PLO_PGFLAG, hb)) atomicMax(&sh.errflag, (uint32_t)BERR_TABLE);
+                    if (lane == 0) if (!gtab_flag(tab, ((uint64_t)j << rb) | v1, PLO_PGFLAG, hb)) wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
                     if ((int)lane == it) {
                         const uint32_t base = P.rs[row], L = len[row];
                         for (uint32_t z = 0; z < L; ++z) if (col[base + z] == j) { col[base + z] = PLO_BFRESH; val[base + z] = 1u; inv[base + z] = 1u; break; }
@@ -781,7 +837,7 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
             }
             if (lane == 0) { sh.nbmul += mulacc; sh.nbadd += addacc; }
         }
-        __threadfence(); BSYNC();
+        PLO_BIG_FENCE(); BSYNC();
     }
     // D output rows (:547-604)
     {
@@ -797,8 +853,8 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
                 }
             }
         }
-        if (addacc) atomicAdd(&sh.acc0, addacc);
-        if (mulacc) atomicAdd(&sh.acc1, mulacc);
+        if (addacc) wg_add(&sh.acc0, addacc);
+        if (mulacc) wg_add(&sh.acc1, mulacc);
     }
     BSYNC();
     if (sh.errflag) { if (tid == 0) atomicMax(errw, sh.errflag); return 0; }
@@ -832,7 +888,12 @@ __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, Big
             const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
-            if (J.stats) { J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull); }   // phase times in us
+            if (J.stats) { J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull);
+#ifdef PLO_BIG_PROFILE
+                for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }
+                J.stats[28] = sh.fb1; J.stats[29] = sh.fb2; J.stats[30] = sh.fl1; J.stats[31] = sh.fl2;
+#endif
+            }   // phase times in us
             // 64-bit cost word: the op-counts of config 5 do not fit 16 bits
             uint64_t ck;
             switch (J.cost_mode) { case 1: ck = ((uint64_t)a << 20) | mu_; break; case 2: ck = (uint64_t)(a + mu_) << 20; break; default: ck = ((uint64_t)(a + mu_) << 20) | a; }
