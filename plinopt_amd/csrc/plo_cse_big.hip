@@ -206,21 +206,43 @@ __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint3
 // (x21 on config 5); the duplicates are summed here and each distinct triple costs one global atomic.
 // key48<<16 | count16, open addressing, at most 16 probes; `false` = no room, the caller goes to HBM directly.
 #define PLO_AGG_PROBES 16u
-__device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_t key) {
+#define PLO_AGG_LIST (PLO_BIG_SELCAP * 4u)     // slot list (u16) kept in the tie-selection buffer, idle during the sweeps
+__device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_t key, uint32_t *aggn, uint16_t *agglist) {
     volatile uint64_t *va = agg;
     const uint32_t mask = (1u << aggbits) - 1u;
     uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - aggbits));
+    uint32_t claimed = 0xFFFFFFFFu; bool done = false;
+    // two slots per trip (both LDS reads in flight together): the wave pays the longest probe sequence of its lanes
     for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
-        uint64_t v = va[s];
-        if ((v >> PLO_GVB) == key) { wg_add((unsigned long long *)&agg[s], 1ull); return true; }
-        if (v == PLO_GEMPTY) {
-            uint64_t old = wg_cas((unsigned long long *)&agg[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | 1ull));
-            if (old == v) return true;
+        const uint32_t s1 = (s + 1u) & mask;
+        const uint64_t v0 = va[s], v1 = va[s1];
+        if ((v0 >> PLO_GVB) == key) { wg_add((unsigned long long *)&agg[s], 1ull); done = true; break; }
+        if (v0 == PLO_GEMPTY) {
+            const uint64_t old = wg_cas((unsigned long long *)&agg[s], (unsigned long long)v0, (unsigned long long)((key << PLO_GVB) | 1ull));
+            if (old == v0) { claimed = s; done = true; break; }
             continue;                      // somebody took the slot: look at it again
         }
-        s = (s + 1u) & mask; ++pr;
+        if ((v1 >> PLO_GVB) == key) { wg_add((unsigned long long *)&agg[s1], 1ull); done = true; break; }
+        if (v1 == PLO_GEMPTY) {
+            const uint64_t old = wg_cas((unsigned long long *)&agg[s1], (unsigned long long)v1, (unsigned long long)((key << PLO_GVB) | 1ull));
+            if (old == v1) { claimed = s1; done = true; break; }
+            continue;
+        }
+        s = (s + 2u) & mask; pr += 2u;
     }
-    return false;
+    // new entries: remember their slots (the flush walks the entries, not the table); one counter update per wave
+    const unsigned long long cm = __builtin_amdgcn_ballot_w64(claimed != 0xFFFFFFFFu);
+    if (cm) {
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(cm);
+        uint32_t base = 0;
+        if (lane == leader) base = wg_add(aggn, (uint32_t)__builtin_popcountll(cm));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+        if (claimed != 0xFFFFFFFFu) {
+            const uint32_t idx = base + (uint32_t)__builtin_popcountll(cm & ((1ull << lane) - 1ull));
+            if (idx < PLO_AGG_LIST) agglist[idx] = (uint16_t)claimed;
+        }
+    }
+    return done;
 }
 
 // position of column c in row [base, base+L) (sorted by column), or -1
@@ -232,7 +254,7 @@ __device__ __forceinline__ int row_find(const uint32_t *col, uint32_t base, uint
 
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
-    uint32_t a, b, r; uint64_t kprime; uint64_t selkey;
+    uint32_t a, b, r, aggn, aggn2; uint64_t kprime; uint64_t selkey;
     uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
 #ifdef PLO_BIG_PROFILE
@@ -256,6 +278,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
     uint32_t *len   = (uint32_t *)(ws + P.o_len), *ucount = (uint32_t *)(ws + P.o_ucount), *cntM = (uint32_t *)(ws + P.o_cntM);
     uint64_t *DM    = (uint64_t *)(ws + P.o_dm), *HL = (uint64_t *)(ws + P.o_hl);
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
+    uint16_t *agglist = (uint16_t *)sh.sel;       // slots claimed in the aggregation table by the running sweep
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
     const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
     const uint64_t mu = P.mu, cap = 1ull << P.hbits;
@@ -435,7 +458,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         // ---- RemOneCSE :60-194
         const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
-        if (tid == 0) sh.naff = 0;
+        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.aggn2 = 0; }
         BSYNC();
         {   // rows holding the triple: walk the shorter row list of the two columns
             const uint32_t *la, *lb; uint32_t na, nb;
@@ -452,8 +475,9 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (vb != bmul(r, va, p, mu, mers)) continue;
                 const uint32_t idx = wg_add(&sh.naff, 1u);
                 const uint32_t ia = inv[base + pa], ib = inv[base + pb];
-                uint32_t *rec = aff + 8u * idx;                             // record: row, positions and values of the two entries
-                rec[0] = i; rec[1] = (uint32_t)pa; rec[2] = (uint32_t)pb; rec[3] = va; rec[4] = ia; rec[5] = vb; rec[6] = ib;
+                uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each) and values/inverses of the two entries, row start and length
+                *(uint4 *)rec = make_uint4(i, (uint32_t)pa | ((uint32_t)pb << 16), va, ia);
+                *(uint4 *)(rec + 4) = make_uint4(vb, ib, base, L);
                 if (idx == 0) sh.invr = bmul(va, ib, p, mu, mers);               // 1/r
             }
         }
@@ -465,29 +489,40 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         // pairs an entry (c, v) forms with a and with b are functions of (c, x), x = v_a/v (c < a) or v/v_a (c > a): the
         // pair with a has ratio x, the pair with b has ratio r x (c < a), r/x (a < c < b) or x/r (b < c).  One LDS entry
         // per (c, x) therefore carries both retirements; the flush derives the two table keys.
-        for (uint32_t q = wave; q < naff; q += nwaves) {
-            const uint32_t *rec = aff + 8u * q;
-            const uint32_t i = rec[0], base = P.rs[i], L = len[i];
-            const int pa = (int)rec[1], pb = (int)rec[2];
-            const uint32_t va = rec[3], ia = rec[4], vb = rec[5], ib = rec[6];
-            for (uint32_t z = lane; z < L; z += 64u) {
-                if ((int)z == pa || (int)z == pb) continue;
-                const uint32_t c = col[base + z], v = val[base + z], iv = inv[base + z];
+        {
+            auto retire_entry = [&](uint32_t c, uint32_t v, uint32_t iv, uint32_t va, uint32_t ia, uint32_t vb, uint32_t ib) {
                 const uint32_t x = c < a ? bmul(va, iv, p, mu, mers) : bmul(v, ia, p, mu, mers);
-                if (agg_add(agg, aggbits, ((uint64_t)c << rb) | x)) continue;
+                if (agg_add(agg, aggbits, ((uint64_t)c << rb) | x, &sh.aggn, agglist)) return;
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fb1, 1u);
 #endif
                 const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x);
                 const uint64_t k2 = c < b ? BKEY(c, b, bmul(vb, iv, p, mu, mers)) : BKEY(b, c, bmul(v, ib, p, mu, mers));
                 uint32_t o1 = gtab_dec(tab, k1, hbits);
-                if (!o1) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                if (!o1) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
                 wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
                 if (o1 == M) { wg_sub(&cntM[c < a ? c : a], 1u); wg_sub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
                 uint32_t o2 = gtab_dec(tab, k2, hbits);
-                if (!o2) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                if (!o2) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
                 wg_sub(&hist[o2], 1u); if (o2 > 1u) wg_add(&hist[o2 - 1u], 1u);
                 if (o2 == M) { wg_sub(&cntM[c < b ? c : b], 1u); wg_sub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
+            };
+            // two rows per wave and trip: both records, then the first 64 entries of both rows, are in flight together
+            for (uint32_t q = wave; q < naff; q += 2u * nwaves) {
+                const uint32_t q2 = q + nwaves < naff ? q + nwaves : q;
+                const uint4 A0 = *(const uint4 *)(aff + 8u * q), A1 = *(const uint4 *)(aff + 8u * q + 4u);
+                const uint4 B0 = *(const uint4 *)(aff + 8u * q2), B1 = *(const uint4 *)(aff + 8u * q2 + 4u);
+                const uint32_t baseA = A1.z, LA = A1.w, baseB = B1.z, LB = q2 != q ? B1.w : 0u;
+                uint32_t cA = 0, vA = 0, iA = 0, cB = 0, vB = 0, iB = 0;
+                const uint32_t paA = A0.y & 0xFFFFu, pbA = A0.y >> 16, paB = B0.y & 0xFFFFu, pbB = B0.y >> 16;
+                if (lane < LA) { cA = col[baseA + lane]; vA = val[baseA + lane]; iA = inv[baseA + lane]; }
+                if (lane < LB) { cB = col[baseB + lane]; vB = val[baseB + lane]; iB = inv[baseB + lane]; }
+                if (lane < LA && lane != paA && lane != pbA) retire_entry(cA, vA, iA, A0.z, A0.w, A1.x, A1.y);
+                if (lane < LB && lane != paB && lane != pbB) retire_entry(cB, vB, iB, B0.z, B0.w, B1.x, B1.y);
+                for (uint32_t z = lane + 64u; z < LA; z += 64u)
+                    if (z != paA && z != pbA) retire_entry(col[baseA + z], val[baseA + z], inv[baseA + z], A0.z, A0.w, A1.x, A1.y);
+                for (uint32_t z = lane + 64u; z < LB; z += 64u)
+                    if (z != paB && z != pbB) retire_entry(col[baseB + z], val[baseB + z], inv[baseB + z], B0.z, B0.w, B1.x, B1.y);
             }
         }
         BSYNC();
@@ -505,7 +540,9 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (o == M) { wg_sub(&cntM[(uint32_t)(k >> abits)], 1u); wg_sub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
             };
             if (tid == 0) retire(key, M);
-            for (uint32_t s = tid; s < (1u << aggbits); s += nth) {
+            const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
+            for (uint32_t e = tid; e < nslot; e += nth) {
+                const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
                 const uint64_t v = agg[s];
                 if (v == PLO_GEMPTY) continue;
                 agg[s] = PLO_GEMPTY;
@@ -524,45 +561,59 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         PLO_STAMP(4);
         if (sh.errflag) break;
         // sweep 2: rewrite the rows, insert the pairs with the new column (:96-110, :132-142)
-        for (uint32_t q = wave; q < naff; q += nwaves) {
-            const uint32_t *rec = aff + 8u * q;
-            const uint32_t i = rec[0], base = P.rs[i], L = len[i];
-            const int pa = (int)rec[1], pb = (int)rec[2];
-            const uint32_t coeff = (l0 == a) ? rec[3] : rec[5], icoeff = (l0 == a) ? rec[4] : rec[6];
-            const bool ua = babsone(rec[3], p), ub = babsone(rec[5], p);
-            for (uint32_t z0 = 0; z0 < L; z0 += 64u) {
-                const uint32_t z = z0 + lane; const bool have = z < L;
-                uint32_t c = 0, v = 0, iv = 0;
-                if (have) { c = col[base + z]; v = val[base + z]; iv = inv[base + z]; }
-                __builtin_amdgcn_wave_barrier();
-                if (have && (int)z != pa && (int)z != pb) {
-                    const uint32_t np = base + z - ((int)z > pa ? 1u : 0u) - ((int)z > pb ? 1u : 0u);
-                    col[np] = c; val[np] = v; inv[np] = iv;
-                    const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu, mers));
-                    if (agg_add(agg, aggbits, nk)) continue;
+        {
+            auto insert_entry = [&](uint32_t c, uint32_t iv, uint32_t coeff) {
+                const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu, mers));
+                if (agg_add(agg, aggbits, nk, &sh.aggn2, agglist)) return;
 #ifdef PLO_BIG_PROFILE
-                    wg_add(&sh.fb2, 1u);
+                wg_add(&sh.fb2, 1u);
 #endif
-                    const uint32_t nc = gtab_inc(tab, nk, hbits);
-                    if (!nc) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-                    if (nc > P.maxf0) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
-                    if (nc > 1u) wg_sub(&hist[nc - 1u], 1u);
-                    wg_add(&hist[nc], 1u);
-                    if (nc == sh.theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = nk; else sh.hlbad = 1u; }
-                    if (nc == M) {
-                        wg_add(&cntM[c], 1u); wg_add(&sh.cblk[c >> 6], 1u);
-                        uint32_t idx = wg_add(&sh.dmcount, 1u);
-                        if (idx < P.dmcap) DM[idx] = nk; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
-                    }
+                const uint32_t nc = gtab_inc(tab, nk, hbits);
+                if (!nc) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
+                if (nc > P.maxf0) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); return; }
+                if (nc > 1u) wg_sub(&hist[nc - 1u], 1u);
+                wg_add(&hist[nc], 1u);
+                if (nc == sh.theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = nk; else sh.hlbad = 1u; }
+                if (nc == M) {
+                    wg_add(&cntM[c], 1u); wg_add(&sh.cblk[c >> 6], 1u);
+                    uint32_t idx = wg_add(&sh.dmcount, 1u);
+                    if (idx < P.dmcap) DM[idx] = nk; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
                 }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (lane == 0) {
-                col[base + L - 2u] = lm; val[base + L - 2u] = coeff; inv[base + L - 2u] = icoeff;
-                len[i] = L - 1u;
-                if (ua) wg_sub(&ucount[a], 1u);
-                if (ub) wg_sub(&ucount[b], 1u);
-                if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
+            };
+            // one row: entries shift left over the two removed positions (first chunk preloaded by the caller), the new
+            // column's entry goes last; all loads of a chunk complete before its stores
+            auto rewrite_row = [&](const uint4 R0, const uint4 R1, uint32_t c, uint32_t v, uint32_t iv) {
+                const uint32_t i = R0.x, pa = R0.y & 0xFFFFu, pb = R0.y >> 16, base = R1.z, L = R1.w;
+                const uint32_t coeff = (l0 == a) ? R0.z : R1.x, icoeff = (l0 == a) ? R0.w : R1.y;
+                for (uint32_t z0 = 0; z0 < L; z0 += 64u) {
+                    const uint32_t z = z0 + lane; const bool have = z < L;
+                    if (z0 && have) { c = col[base + z]; v = val[base + z]; iv = inv[base + z]; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (have && z != pa && z != pb) {
+                        const uint32_t np = base + z - (z > pa ? 1u : 0u) - (z > pb ? 1u : 0u);
+                        col[np] = c; val[np] = v; inv[np] = iv;
+                        insert_entry(c, iv, coeff);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0) {
+                    col[base + L - 2u] = lm; val[base + L - 2u] = coeff; inv[base + L - 2u] = icoeff;
+                    len[i] = L - 1u;
+                    if (babsone(R0.z, p)) wg_sub(&ucount[a], 1u);
+                    if (babsone(R1.x, p)) wg_sub(&ucount[b], 1u);
+                    if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
+                }
+            };
+            for (uint32_t q = wave; q < naff; q += 2u * nwaves) {
+                const uint32_t q2 = q + nwaves;
+                const uint4 A0 = *(const uint4 *)(aff + 8u * q), A1 = *(const uint4 *)(aff + 8u * q + 4u);
+                uint4 B0 = A0, B1 = A1;
+                if (q2 < naff) { B0 = *(const uint4 *)(aff + 8u * q2); B1 = *(const uint4 *)(aff + 8u * q2 + 4u); }
+                uint32_t cA = 0, vA = 0, iA = 0, cB = 0, vB = 0, iB = 0;
+                if (lane < A1.w) { cA = col[A1.z + lane]; vA = val[A1.z + lane]; iA = inv[A1.z + lane]; }
+                if (q2 < naff && lane < B1.w) { cB = col[B1.z + lane]; vB = val[B1.z + lane]; iB = inv[B1.z + lane]; }
+                rewrite_row(A0, A1, cA, vA, iA);
+                if (q2 < naff) rewrite_row(B0, B1, cB, vB, iB);
             }
         }
         BSYNC();
@@ -571,7 +622,9 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
 #endif
         PLO_STAMP(5);
         // flush the summed insertions
-        for (uint32_t s = tid; s < (1u << aggbits); s += nth) {
+        const uint32_t nent2 = sh.aggn2, nslot2 = nent2 <= PLO_AGG_LIST ? nent2 : (1u << aggbits);
+        for (uint32_t e = tid; e < nslot2; e += nth) {
+            const uint32_t s = nent2 <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
             const uint64_t v = agg[s];
             if (v == PLO_GEMPTY) continue;
             agg[s] = PLO_GEMPTY;
