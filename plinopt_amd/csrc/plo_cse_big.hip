@@ -208,14 +208,13 @@ __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint3
 #define PLO_AGG_PROBES 16u
 #define PLO_AGG_LIST (PLO_BIG_SELCAP * 4u)     // slot list (u16) kept in the tie-selection buffer, idle during the sweeps
 __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_t key, uint32_t *aggn, uint16_t *agglist) {
-    volatile uint64_t *va = agg;
     const uint32_t mask = (1u << aggbits) - 1u;
     uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - aggbits));
     uint32_t claimed = 0xFFFFFFFFu; bool done = false;
     // two slots per trip (both LDS reads in flight together): the wave pays the longest probe sequence of its lanes
     for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
         const uint32_t s1 = (s + 1u) & mask;
-        const uint64_t v0 = va[s], v1 = va[s1];
+        const uint64_t v0 = __hip_atomic_load(&agg[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), v1 = __hip_atomic_load(&agg[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_read_b64 (a volatile read would be a flat load)
         if ((v0 >> PLO_GVB) == key) { wg_add((unsigned long long *)&agg[s], 1ull); done = true; break; }
         if (v0 == PLO_GEMPTY) {
             const uint64_t old = wg_cas((unsigned long long *)&agg[s], (unsigned long long)v0, (unsigned long long)((key << PLO_GVB) | 1ull));

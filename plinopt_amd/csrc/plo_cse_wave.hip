@@ -118,12 +118,15 @@ __device__ __forceinline__ uint32_t tab_hash(uint64_t key, uint32_t hbits) {
     return (x * 0x9E3779B1u) >> (32u - hbits);
 }
 
+// relaxed atomic read of a table slot: a `volatile` read of an LDS pointer is not address-space inferred and becomes a
+// flat_load sc0 sc1 (measured in the ISA); this one compiles to ds_read_b64
+__device__ __forceinline__ uint64_t lds_ld64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // count[key] -= 1 ; the key must be live
 __device__ __forceinline__ bool tab_dec(uint64_t *tab, uint64_t key, uint32_t cap, uint32_t hbits) {
-    volatile uint64_t *vt = tab;
     uint32_t s = tab_hash(key, hbits);
     for (uint32_t pr = 0; pr < cap; ++pr) {
-        uint64_t v = vt[s];
+        uint64_t v = lds_ld64(&tab[s]);
         if ((v >> PLO_VB) == key) { atomicAdd((unsigned long long *)&tab[s], ~0ull); return true; }
         s = (s + 1u) & (cap - 1u);
     }
@@ -133,10 +136,9 @@ __device__ __forceinline__ bool tab_dec(uint64_t *tab, uint64_t key, uint32_t ca
 // Only called when no decrement is in flight (see the two sweeps below), so a
 // key can never end up in two slots.
 __device__ __forceinline__ bool tab_inc(uint64_t *tab, uint64_t key, uint32_t cap, uint32_t hbits) {
-    volatile uint64_t *vt = tab;
     uint32_t s = tab_hash(key, hbits);
     for (uint32_t pr = 0; pr < 2u * cap + 64u; ++pr) {
-        uint64_t v = vt[s];
+        uint64_t v = lds_ld64(&tab[s]);
         if ((v >> PLO_VB) == key) { atomicAdd((unsigned long long *)&tab[s], 1ull); return true; }
         if ((v & PLO_VMASK) == 0ull) {
             uint64_t nv = (key << PLO_VB) | 1ull;
@@ -153,10 +155,9 @@ __device__ __forceinline__ bool tab_inc(uint64_t *tab, uint64_t key, uint32_t ca
 // (column, |coefficient|) multiset: low 16 bits = occurrences, bit 16 = "a
 // multiplier r := t_col * |coefficient| already exists" (`multiples`).
 __device__ __forceinline__ bool tab_add(uint64_t *tab, uint64_t key, uint32_t incv, uint32_t cap, uint32_t hbits) {
-    volatile uint64_t *vt = tab;
     uint32_t s = tab_hash(key, hbits);
     for (uint32_t pr = 0; pr < 2u * cap + 64u; ++pr) {
-        uint64_t v = vt[s];
+        uint64_t v = lds_ld64(&tab[s]);
         if (v == PLO_EMPTY) {
             uint64_t nv = (key << PLO_VB) | incv;
             uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)nv);
@@ -170,10 +171,9 @@ __device__ __forceinline__ bool tab_add(uint64_t *tab, uint64_t key, uint32_t in
 }
 // set a flag bit on the key's value (insert the key if absent); idempotent, unlike an add
 __device__ __forceinline__ bool tab_flag(uint64_t *tab, uint64_t key, uint32_t flag, uint32_t cap, uint32_t hbits) {
-    volatile uint64_t *vt = tab;
     uint32_t s = tab_hash(key, hbits);
     for (uint32_t pr = 0; pr < 2u * cap + 64u; ++pr) {
-        uint64_t v = vt[s];
+        uint64_t v = lds_ld64(&tab[s]);
         if (v == PLO_EMPTY) {
             uint64_t old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_VB) | flag));
             if (old == v) return true;
