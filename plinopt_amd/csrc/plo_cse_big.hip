@@ -87,8 +87,8 @@ __device__ __forceinline__ uint32_t bmul(uint32_t a, uint32_t b, uint32_t p, uin
         return (uint32_t)(x >= p ? x - p : x);
     }
     uint64_t q = __umul64hi(x, mu);
-    uint64_t r = x - q * p;
-    while (r >= p) r -= p;
+    uint64_t r = x - q * p;                       // Barrett: at most 2p too large
+    r -= r >= p ? p : 0ull; r -= r >= p ? p : 0ull;
     return (uint32_t)r;
 }
 // 1/x mod p (x != 0): x^(p-2)
@@ -209,23 +209,20 @@ __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint3
 #define PLO_AGG_LIST (PLO_BIG_SELCAP * 4u)     // slot list (u16) kept in the tie-selection buffer, idle during the sweeps
 __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_t key, uint32_t *aggn, uint16_t *agglist) {
     const uint32_t mask = (1u << aggbits) - 1u;
-    uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - aggbits));
+    uint32_t s = ((((uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32u - aggbits));   // keys are (column, ratio): 32 bits on config 5
     uint32_t claimed = 0xFFFFFFFFu; bool done = false;
     // two slots per trip (both LDS reads in flight together): the wave pays the longest probe sequence of its lanes
     for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
         const uint32_t s1 = (s + 1u) & mask;
         const uint64_t v0 = __hip_atomic_load(&agg[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), v1 = __hip_atomic_load(&agg[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_read_b64 (a volatile read would be a flat load)
-        if ((v0 >> PLO_GVB) == key) { wg_add((unsigned long long *)&agg[s], 1ull); done = true; break; }
-        if (v0 == PLO_GEMPTY) {
-            const uint64_t old = wg_cas((unsigned long long *)&agg[s], (unsigned long long)v0, (unsigned long long)((key << PLO_GVB) | 1ull));
-            if (old == v0) { claimed = s; done = true; break; }
-            continue;                      // somebody took the slot: look at it again
-        }
-        if ((v1 >> PLO_GVB) == key) { wg_add((unsigned long long *)&agg[s1], 1ull); done = true; break; }
-        if (v1 == PLO_GEMPTY) {
-            const uint64_t old = wg_cas((unsigned long long *)&agg[s1], (unsigned long long)v1, (unsigned long long)((key << PLO_GVB) | 1ull));
-            if (old == v1) { claimed = s1; done = true; break; }
-            continue;
+        const bool hit0 = (v0 >> PLO_GVB) == key, emp0 = v0 == PLO_GEMPTY, first = hit0 || emp0;
+        const bool hit = hit0 || (!emp0 && (v1 >> PLO_GVB) == key), emp = emp0 || (!hit && v1 == PLO_GEMPTY);
+        const uint32_t t = first ? s : s1;
+        if (hit) { wg_add((unsigned long long *)&agg[t], 1ull); done = true; break; }
+        if (emp) {
+            const uint64_t old = wg_cas((unsigned long long *)&agg[t], (unsigned long long)PLO_GEMPTY, (unsigned long long)((key << PLO_GVB) | 1ull));
+            if (old == PLO_GEMPTY) { claimed = t; done = true; break; }
+            continue;                      // somebody took the slot: look at both again
         }
         s = (s + 2u) & mask; pr += 2u;
     }
@@ -490,7 +487,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         // per (c, x) therefore carries both retirements; the flush derives the two table keys.
         {
             auto retire_entry = [&](uint32_t c, uint32_t v, uint32_t iv, uint32_t va, uint32_t ia, uint32_t vb, uint32_t ib) {
-                const uint32_t x = c < a ? bmul(va, iv, p, mu, mers) : bmul(v, ia, p, mu, mers);
+                const uint32_t x = bmul(c < a ? va : v, c < a ? iv : ia, p, mu, mers);        // one product, operands selected (no divergent branch)
                 if (agg_add(agg, aggbits, ((uint64_t)c << rb) | x, &sh.aggn, agglist)) return;
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fb1, 1u);
@@ -562,8 +559,9 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         // sweep 2: rewrite the rows, insert the pairs with the new column (:96-110, :132-142)
         {
             auto insert_entry = [&](uint32_t c, uint32_t iv, uint32_t coeff) {
-                const uint64_t nk = BKEY(c, lm, bmul(coeff, iv, p, mu, mers));
-                if (agg_add(agg, aggbits, nk, &sh.aggn2, agglist)) return;
+                const uint32_t x = bmul(coeff, iv, p, mu, mers);
+                if (agg_add(agg, aggbits, ((uint64_t)c << rb) | x, &sh.aggn2, agglist)) return;   // the new column is implied
+                const uint64_t nk = BKEY(c, lm, x);
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fb2, 1u);
 #endif
@@ -627,7 +625,8 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             const uint64_t v = agg[s];
             if (v == PLO_GEMPTY) continue;
             agg[s] = PLO_GEMPTY;
-            const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+            const uint64_t kc = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+            const uint64_t k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
             const uint32_t o = gtab_addn(tab, k, d, hbits);
 #ifdef PLO_BIG_PROFILE
             wg_add(&sh.fl2, 1u);
