@@ -30,7 +30,9 @@
 
 namespace plo {
 
+#ifndef PLO_BIG_THREADS
 #define PLO_BIG_THREADS 512
+#endif
 #define PLO_BIG_SELCAP 512u
 #define PLO_GVB 16u
 #define PLO_GVMASK 0xFFFFull
@@ -206,6 +208,12 @@ __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint3
 // (x21 on config 5); the duplicates are summed here and each distinct triple costs one global atomic.
 // key48<<16 | count16, open addressing, at most 16 probes; `false` = no room, the caller goes to HBM directly.
 #define PLO_AGG_PROBES 16u
+#ifdef PLO_BIG_PROFILE
+__device__ unsigned long long g_prof[16];      // thread 0 of every workgroup, sweep 1: cycles per stage (racy sums; profile only)
+#define PROF_T(k_) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t__ = clock64(); if (tid == 0) g_prof[k_] += t__ - tp; tp = t__; } while (0)
+#else
+#define PROF_T(k_) do { } while (0)
+#endif
 #define PLO_AGG_LIST (PLO_BIG_SELCAP * 4u)     // slot list (u16) kept in the tie-selection buffer, idle during the sweeps
 __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_t key, uint32_t *aggn, uint16_t *agglist) {
     const uint32_t mask = (1u << aggbits) - 1u;
@@ -506,6 +514,9 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             // two rows per wave and trip: both records, then the first 64 entries of both rows, are in flight together
             for (uint32_t q = wave; q < naff; q += 2u * nwaves) {
                 const uint32_t q2 = q + nwaves < naff ? q + nwaves : q;
+#ifdef PLO_BIG_PROFILE
+                unsigned long long tp = clock64();
+#endif
                 const uint4 A0 = *(const uint4 *)(aff + 8u * q), A1 = *(const uint4 *)(aff + 8u * q + 4u);
                 const uint4 B0 = *(const uint4 *)(aff + 8u * q2), B1 = *(const uint4 *)(aff + 8u * q2 + 4u);
                 const uint32_t baseA = A1.z, LA = A1.w, baseB = B1.z, LB = q2 != q ? B1.w : 0u;
@@ -513,12 +524,17 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 const uint32_t paA = A0.y & 0xFFFFu, pbA = A0.y >> 16, paB = B0.y & 0xFFFFu, pbB = B0.y >> 16;
                 if (lane < LA) { cA = col[baseA + lane]; vA = val[baseA + lane]; iA = inv[baseA + lane]; }
                 if (lane < LB) { cB = col[baseB + lane]; vB = val[baseB + lane]; iB = inv[baseB + lane]; }
-                if (lane < LA && lane != paA && lane != pbA) retire_entry(cA, vA, iA, A0.z, A0.w, A1.x, A1.y);
-                if (lane < LB && lane != paB && lane != pbB) retire_entry(cB, vB, iB, B0.z, B0.w, B1.x, B1.y);
-                for (uint32_t z = lane + 64u; z < LA; z += 64u)
-                    if (z != paA && z != pbA) retire_entry(col[baseA + z], val[baseA + z], inv[baseA + z], A0.z, A0.w, A1.x, A1.y);
-                for (uint32_t z = lane + 64u; z < LB; z += 64u)
-                    if (z != paB && z != pbB) retire_entry(col[baseB + z], val[baseB + z], inv[baseB + z], B0.z, B0.w, B1.x, B1.y);
+                const uint32_t Lmax = LA > LB ? LA : LB;
+                for (uint32_t z0 = 0; z0 < Lmax; z0 += 64u) {
+                    // the next 64 entries of both rows are requested before this chunk is worked on
+                    const uint32_t z = z0 + lane, zn = z + 64u;
+                    uint32_t ncA = 0, nvA = 0, niA = 0, ncB = 0, nvB = 0, niB = 0;
+                    if (zn < LA) { ncA = col[baseA + zn]; nvA = val[baseA + zn]; niA = inv[baseA + zn]; }
+                    if (zn < LB) { ncB = col[baseB + zn]; nvB = val[baseB + zn]; niB = inv[baseB + zn]; }
+                    if (z < LA && z != paA && z != pbA) retire_entry(cA, vA, iA, A0.z, A0.w, A1.x, A1.y);
+                    if (z < LB && z != paB && z != pbB) retire_entry(cB, vB, iB, B0.z, B0.w, B1.x, B1.y);
+                    cA = ncA; vA = nvA; iA = niA; cB = ncB; vB = nvB; iB = niB;
+                }
             }
         }
         BSYNC();
@@ -583,8 +599,9 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 const uint32_t i = R0.x, pa = R0.y & 0xFFFFu, pb = R0.y >> 16, base = R1.z, L = R1.w;
                 const uint32_t coeff = (l0 == a) ? R0.z : R1.x, icoeff = (l0 == a) ? R0.w : R1.y;
                 for (uint32_t z0 = 0; z0 < L; z0 += 64u) {
-                    const uint32_t z = z0 + lane; const bool have = z < L;
-                    if (z0 && have) { c = col[base + z]; v = val[base + z]; iv = inv[base + z]; }
+                    const uint32_t z = z0 + lane, zn = z + 64u; const bool have = z < L;
+                    uint32_t nc = 0, nv = 0, niv = 0;                 // the next chunk is read before this one is stored: the stores
+                    if (zn < L) { nc = col[base + zn]; nv = val[base + zn]; niv = inv[base + zn]; }   // reach back at most two positions
                     __builtin_amdgcn_wave_barrier();
                     if (have && z != pa && z != pb) {
                         const uint32_t np = base + z - (z > pa ? 1u : 0u) - (z > pb ? 1u : 0u);
@@ -592,6 +609,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                         insert_entry(c, iv, coeff);
                     }
                     __builtin_amdgcn_wave_barrier();
+                    c = nc; v = nv; iv = niv;
                 }
                 if (lane == 0) {
                     col[base + L - 2u] = lm; val[base + L - 2u] = coeff; inv[base + L - 2u] = icoeff;
