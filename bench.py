@@ -23,9 +23,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
     # name: (fixture file, modulus, default per-GPU batch, description)
-    "32x32x32": ("32x32x32_15096_L.slp", 131071, 512,
+    "32x32x32": ("32x32x32_15096_L.slp", 131071, 1024,
                  "bin/optimizer -q 131071 -D data/32x32x32_15096_L.sms (BASELINE configs[4], the metric's config): "
-                 "matrix regenerated from the stored SLP (reference Makefile:79-80), 512 random restarts per GPU per step (2 resident workgroups per CU)"),
+                 "matrix regenerated from the stored SLP (reference Makefile:79-80), 1024 random restarts per GPU per step (one workgroup per restart, 2 resident per CU)"),
     "winograd": ("2x2x2_7_Winograd_L.sms", 131071, 1000000,
                  "bin/optimizer -q 131071 -D data/2x2x2_7_Winograd_L.sms, 10^6 random restarts per step (BASELINE configs[1])"),
     "4x4x4_L": ("4x4x4_49_156_L.sms", 131071, 200000,
@@ -190,7 +190,7 @@ def main():
     if args.workload == "cob":
         return bench_cob(args)
     if args.steps is None:
-        args.steps = 3 if args.workload == "32x32x32" else 20       # one config-5 step is ~5.5 s of GPU time
+        args.steps = 3 if args.workload == "32x32x32" else 20       # one config-5 step is ~3 s of GPU time
     if args.warmup is None:
         args.warmup = 1 if args.workload == "32x32x32" else 3
     import torch
@@ -293,8 +293,9 @@ def main():
         except Exception:
             pass
         if plan.is_hbm:
-            out["roofline"]["note"] = ("candidate state (64 MB pair table + rows) is HBM-resident; waves wait on dependent LDS/HBM "
-                                       "accesses 86 % of their cycles, HBM traffic is 0.6 TB/s: latency-bound, not bandwidth-bound (DESIGN.md)")
+            out["roofline"]["note"] = ("candidate state (16 MB pair table + rows + lists, 165 MB workspace) is HBM-resident; waves wait 79 % of "
+                                       "their cycles on dependent LDS/HBM accesses, measured HBM traffic is 2.3 TB/s (rocprofv3 PMC, profiles/r01g_*): "
+                                       "latency-bound, not bandwidth-bound (DESIGN.md 6)")
             out["kernel"]["family"] = "plo::cse_big_kernel (one workgroup per candidate)"
             out["roofline"]["kernel"] = "plo::cse_big_kernel"
         if not args.no_cpu_baseline and world == 1:
