@@ -87,6 +87,20 @@ void plo_oracle_naive_ops(uint32_t m, const uint32_t *rowptr,
                           const uint32_t *val, uint32_t p,
                           uint32_t *adds, uint32_t *muls);
 
+/* ---- trilplacer (plo_tril_oracle.c): in-place trilinear programs, plinopt_inplace.inl:400-502, :732-929.
+ * A (m x nA), B (m x nB), T = transpose of the product matrix (m x nT): CSR, columns sorted per row, rational values
+ * num/den (den == NULL: integers).  One candidate = one restart of SearchTriLinearAlgorithm :837-924 = row permutation
+ * + coherent row negations from the seed's stream, then the oriented (variant 0) and the unoriented (variant 1) program;
+ * ops6 = {ADD,SCA,MUL} of variant 0 then of variant 1.  seed == ~0 is the unpermuted oriented program of :829.
+ * Returns 0, -1 bad dimensions, -3 rational overflow. */
+#define PLO_TRIL_ARGS(x_) uint32_t n##x_, const uint32_t *rp##x_, const uint32_t *col##x_, const int64_t *num##x_, const int64_t *den##x_
+int plo_oracle_tril_cost_many(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T),
+                              const uint64_t *seeds, uint64_t seed0, uint64_t nseeds, uint32_t *ops6, int nthreads);
+int plo_oracle_tril_program(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T),
+                            uint64_t seed, int variant, uint32_t *ops6, char **text);
+int plo_oracle_tril_search(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T),
+                           uint64_t seed0, uint64_t nseeds, uint32_t *best_ops3, uint64_t *best_seed, uint32_t *best_variant);
+
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);
 

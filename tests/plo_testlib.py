@@ -272,6 +272,11 @@ def oracle():
         L.plo_oracle_cob_search.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
                                             ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), u64p, u32p]
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        mat = [ctypes.c_uint32, u32p, u32p, i64p, i64p]
+        L.plo_oracle_tril_cost_many.argtypes = [ctypes.c_uint32] + mat * 3 + [u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, ctypes.c_int]
+        L.plo_oracle_tril_program.argtypes = [ctypes.c_uint32] + mat * 3 + [ctypes.c_uint64, ctypes.c_int, u32p, ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_oracle_tril_search.argtypes = [ctypes.c_uint32] + mat * 3 + [ctypes.c_uint64, ctypes.c_uint64, u32p, u64p, u32p]
         L.plo_oracle_naive_ops.argtypes = [ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p, u32p]
         L.plo_oracle_naive_ops.restype = None
         L.plo_oracle_free.argtypes = [ctypes.c_void_p]
@@ -378,3 +383,125 @@ def oracle_cob_search(n, m, TM, Cand, row, off, coeffs, p, w0=-1, w1=-1):
                                         ctypes.byref(zv), ctypes.byref(zw), ctypes.byref(idx), ctypes.byref(fnd))
     assert rc == 0
     return zv.value, zw.value, idx.value, fnd.value
+
+
+# ----------------------------------------------------------------------------- trilplacer
+TRIL_BASE_SEED = (1 << 64) - 1
+
+
+def csr_rational(m, n, ent):
+    """CSR with rational values: (rowptr, col, num, den), columns sorted per row."""
+    rows = [[] for _ in range(m)]
+    for (i, j), v in ent.items():
+        rows[i].append((j, v))
+    rp, col, num, den = [0], [], [], []
+    for r in rows:
+        r.sort()
+        for j, v in r:
+            col.append(j); num.append(v.numerator); den.append(v.denominator)
+        rp.append(len(col))
+    return rp, col, num, den
+
+
+class OracleTril:
+    """The three matrices of an in-place trilinear search handed to the oracle: A, B (m x .) and T = C^T (m x .)."""
+
+    def __init__(self, A, B, C):
+        (ma, na, ea), (mb, nb, eb), (mc, nc, ec) = A, B, C
+        et = {(j, i): v for (i, j), v in ec.items()}
+        self.m = ma
+        self.dims = (na, nb, mc)
+        self.ent = (ea, eb, et)
+        self.csr = [csr_rational(ma, na, ea), csr_rational(mb, nb, eb), csr_rational(nc, mc, et)]
+        assert ma == mb == nc
+
+    @classmethod
+    def from_sms(cls, pa, pb, pc):
+        return cls(read_sms(pa), read_sms(pb), read_sms(pc))
+
+    def _args(self):
+        out = [ctypes.c_uint32(self.m)]
+        self._keep = []
+        for n, (rp, col, num, den) in zip(self.dims, self.csr):
+            a = (_arr(rp), _arr(col), _arr(num, ctypes.c_int64), _arr(den, ctypes.c_int64))
+            self._keep.append(a)
+            out += [ctypes.c_uint32(n), a[0], a[1], a[2], a[3]]
+        return out
+
+    def cost_many(self, seeds=None, seed0=0, nseeds=0):
+        """-> list of ((ADD,SCA,MUL) oriented, (ADD,SCA,MUL) unoriented)"""
+        if seeds is not None:
+            nseeds = len(seeds); sp = _arr(seeds, ctypes.c_uint64)
+        else:
+            sp = None
+        ops = (ctypes.c_uint32 * (6 * max(nseeds, 1)))()
+        rc = oracle().plo_oracle_tril_cost_many(*self._args(), sp, seed0, nseeds, ops, 1)
+        assert rc == 0, rc
+        return [(tuple(ops[6 * k:6 * k + 3]), tuple(ops[6 * k + 3:6 * k + 6])) for k in range(nseeds)]
+
+    def program(self, seed, variant):
+        ops = (ctypes.c_uint32 * 6)()
+        txt = ctypes.c_void_p()
+        rc = oracle().plo_oracle_tril_program(*self._args(), seed, variant, ops, ctypes.byref(txt))
+        assert rc == 0, rc
+        text = ctypes.string_at(txt).decode()
+        oracle().plo_oracle_free(txt)
+        return tuple(ops[3 * variant:3 * variant + 3]), text
+
+    def search(self, seed0, nseeds):
+        best = (ctypes.c_uint32 * 3)(); bs = ctypes.c_uint64(); bv = ctypes.c_uint32()
+        rc = oracle().plo_oracle_tril_search(*self._args(), seed0, nseeds, best, ctypes.byref(bs), ctypes.byref(bv))
+        assert rc == 0, rc
+        return tuple(best), bs.value, bv.value
+
+
+_INPL_LINE = re.compile(r"^([a-z])(\d+):=(.*?);")
+
+
+def run_inplace_program(text, a, b, c):
+    """Independent interpreter of a trilplacer program (the reference checks these with Maple, -DINPLACE_CHECKER):
+    executes `x:=x op y[*v|/d];`, `x:=-x;`, `x:=x*v;`, `x:=x/d;` and `c:=c +- a * b;` on Fractions, in place.
+    Returns the operation counts (ADD, SCA, MUL) seen."""
+    env = {"a": a, "b": b, "c": c}
+    nadd = nsca = nmul = 0
+
+    def operand(tok):
+        tok = tok.strip()
+        mm = re.match(r"^([a-z])(\d+)(?:([*/])(-?\d+(?:/\d+)?))?$", tok)
+        assert mm, tok
+        v = env[mm.group(1)][int(mm.group(2))]
+        sca = 0
+        if mm.group(3):
+            f = Fraction(mm.group(4)); sca = 1
+            v = v * f if mm.group(3) == "*" else v / f
+        return v, sca, (mm.group(1), int(mm.group(2)))
+
+    for line in text.splitlines():
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        mm = _INPL_LINE.match(line)
+        assert mm, line
+        var, idx, rhs = mm.group(1), int(mm.group(2)), mm.group(3).strip()
+        if " * " in rhs:                                    # AXPY: c:=c +/- a * b
+            mq = re.match(r"^([a-z])(\d+) ([+-]) ([a-z])(\d+) \* ([a-z])(\d+)$", rhs)
+            assert mq and mq.group(1) == var and int(mq.group(2)) == idx, line
+            prod = env[mq.group(4)][int(mq.group(5))] * env[mq.group(6)][int(mq.group(7))]
+            env[var][idx] += prod if mq.group(3) == "+" else -prod
+            nmul += 1
+            continue
+        neg = rhs.startswith("-")
+        body = rhs[1:] if neg else rhs
+        mq = re.match(r"^([a-z]\d+)([+-])(.*)$", body)
+        if mq and not neg:                                   # ADD: x:=x+y*v
+            v0, s0, who = operand(mq.group(1))
+            assert who == (var, idx) and s0 == 0, line
+            v1, s1, _ = operand(mq.group(3))
+            env[var][idx] = v0 + v1 if mq.group(2) == "+" else v0 - v1
+            nadd += 1; nsca += s1
+        else:                                                # SCA: x:=[-]x[*v|/d]
+            v0, s0, who = operand(body)
+            assert who == (var, idx), line
+            env[var][idx] = -v0 if neg else v0
+            nsca += 1
+    return nadd, nsca, nmul
