@@ -127,6 +127,24 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
                    const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
                    plo_cob_best_t *out, plo_stats_t *stats);
 
+/* ---- In-place trilinear search: replaces the body of the restart loop of SearchTriLinearAlgorithm
+ * (include/plinopt_inplace.inl:837-924; driver src/trilplacer.cpp:150-152).  A (m x nA), B (m x nB) and T = transpose of
+ * the product matrix (m x nT), integer CSR with columns sorted per row.  One candidate (seed) = row permutation +
+ * coherent row negations drawn from the seed's stream, then the oriented (variant 0) and the unoriented (variant 1)
+ * in-place program of TriLinearProgram :732-806; cost = (ADD, SCA) lexicographic as :893-897, ties to the smaller
+ * (seed, variant).  seed == PLO_TRIL_BASE_SEED is the unpermuted oriented program of :829.  The device path takes
+ * matrices with entries +-1, no empty row and rows of at most 64 entries (PLO_E_UNSUPPORTED otherwise: such inputs
+ * stay on the host).  The host replays the winning (seed, variant) to print the program. */
+#define PLO_TRIL_BASE_SEED 0xFFFFFFFFFFFFFFFFull
+typedef struct { uint32_t m, n; const uint32_t *rowptr; const uint32_t *col; const int32_t *val; } plo_icsr_t;
+typedef struct { uint32_t add, sca, mul; uint32_t variant; uint64_t seed; } plo_tril_best_t;
+typedef struct plo_tril_plan plo_tril_plan_t;
+int  plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, plo_tril_plan_t **plan);
+void plo_tril_plan_destroy(plo_tril_plan_t *plan);
+/* ops6[6k..6k+5] = ADD,SCA,MUL of variant 0 then of variant 1 for candidate k (seeds[k], or seed0+k when seeds==NULL) */
+int  plo_tril_cost_many(plo_tril_plan_t *plan, const uint64_t *seeds, uint64_t seed0, uint64_t n, uint32_t *ops6, plo_stats_t *stats);
+int  plo_tril_search(plo_tril_plan_t *plan, uint64_t seed0, uint64_t nseeds, plo_tril_best_t *best, plo_stats_t *stats);
+
 /* Pack / unpack the (cost, seed) word used by the grid reduction and by the
  * single 8-byte MIN all-reduce across ranks (the `#pragma omp critical`
  * best-so-far of include/plinopt_optimize.inl:1214-1237).  seed_off is the

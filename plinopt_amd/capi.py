@@ -22,6 +22,7 @@ EXPORTS = [
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many",
     "plo_cob_search",
+    "plo_tril_plan_create", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
     "plo_pack_cost",
 ]
 
@@ -50,6 +51,14 @@ class Stats(ctypes.Structure):
 
 class CobBest(ctypes.Structure):
     _fields_ = [("zeros_v", ctypes.c_int32), ("zeros_w", ctypes.c_int32), ("index", ctypes.c_uint64), ("found", ctypes.c_uint32)]
+
+
+class ICSR(ctypes.Structure):
+    _fields_ = [("m", ctypes.c_uint32), ("n", ctypes.c_uint32), ("rowptr", u32p), ("col", u32p), ("val", ctypes.POINTER(ctypes.c_int32))]
+
+
+class TrilBest(ctypes.Structure):
+    _fields_ = [("add", ctypes.c_uint32), ("sca", ctypes.c_uint32), ("mul", ctypes.c_uint32), ("variant", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
 
 
 class PloError(RuntimeError):
@@ -99,6 +108,11 @@ def lib():
         L.plo_cob_search.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.POINTER(CobBest), ctypes.POINTER(Stats)]
+        L.plo_tril_plan_create.argtypes = [ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_tril_plan_destroy.argtypes = [ctypes.c_void_p]
+        L.plo_tril_plan_destroy.restype = None
+        L.plo_tril_cost_many.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, ctypes.POINTER(Stats)]
+        L.plo_tril_search.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(TrilBest), ctypes.POINTER(Stats)]
         L.plo_pack_cost.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
         L.plo_pack_cost.restype = ctypes.c_uint64
         _lib = L

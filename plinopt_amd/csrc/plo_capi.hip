@@ -11,6 +11,7 @@
 #include "plo_cse_wave.hip"
 #include "plo_cse_big.hip"
 #include "plo_cob.hip"
+#include "plo_tril.hip"
 #include "../../include/plinopt_hip.h"
 
 #include <algorithm>
@@ -824,6 +825,143 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     else { out->zeros_v = w0; out->zeros_w = w1; out->index = 0; }
     st->kernel_ms = ms; st->launches = 1; st->candidates = total; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)(use_tab ? lds_tab : lds); st->waves_per_wg = 4;
     st->algo_bytes = 16ull * m + 8;                       // the 4 x m block of TM, once, plus the result word
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PLO_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------- trilplacer
+struct plo_tril_plan {
+    plo::TrilPlan P{};
+    void *d_img = nullptr; uint32_t *d_err = nullptr; unsigned long long *d_best = nullptr;
+    uint32_t waves_per_wg = 4, lds_bytes = 0, blocks_per_cu = 1;
+    uint64_t algo_bytes = 0;
+};
+
+namespace {
+int tril_launch(plo_tril_plan *pl, plo::TrilJob J, plo_stats_t *st) {
+    HIPCHK(hipMemsetAsync(pl->d_err, 0, sizeof(uint32_t), g_stream));
+    J.err = pl->d_err;
+    const uint64_t need = (J.ncand + pl->waves_per_wg - 1) / pl->waves_per_wg;
+    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g_cus * pl->blocks_per_cu, need));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g_stream));
+    hipLaunchKernelGGL(plo::tril_kernel, dim3((uint32_t)grid), dim3(64 * pl->waves_per_wg), pl->lds_bytes, g_stream, pl->P, J);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, g_stream)); HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = pl->waves_per_wg; st->algo_bytes = pl->algo_bytes; st->candidates += J.ncand; }
+    if (err) return fail(err == plo::TERR_CAP ? PLO_E_INTERNAL : PLO_E_UNSUPPORTED, "device (trilplacer): error " + std::to_string(err));
+    return PLO_OK;
+}
+} // namespace
+
+extern "C" {
+
+int plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, plo_tril_plan_t **plan)
+{
+    if (g_device < 0) return fail(PLO_E_HIP, "plo_init was not called (or found no HIP device)");
+    if (!A || !B || !T || !plan) return fail(PLO_E_ARG, "null argument");
+    const plo_icsr_t *Ms[3] = {A, B, T};
+    if (A->m == 0 || A->m != B->m || A->m != T->m) return fail(PLO_E_ARG, "A, B and T (transposed product matrix) need the same number of rows");
+    if (A->m > 65535u) return fail(PLO_E_CAPACITY, "more than 65535 rows");
+    uint32_t cap = 0; size_t bytes = 0; uint64_t algo = 8;
+    for (const plo_icsr_t *M : Ms) {
+        if (!M->rowptr || !M->col || !M->val || M->n == 0 || M->n > 65535u) return fail(PLO_E_ARG, "bad matrix");
+        const uint32_t nnz = M->rowptr[M->m];
+        if (nnz > 65535u) return fail(PLO_E_CAPACITY, "more than 65535 non-zeros");
+        for (uint32_t i = 0; i < M->m; ++i) {
+            const uint32_t len = M->rowptr[i + 1] - M->rowptr[i];
+            if (len == 0) return fail(PLO_E_UNSUPPORTED, "empty row: host path only");
+            if (len > 64) return fail(PLO_E_UNSUPPORTED, "row with more than 64 entries: host path only");
+            for (uint32_t e = M->rowptr[i]; e < M->rowptr[i + 1]; ++e) {
+                if (M->val[e] != 1 && M->val[e] != -1) return fail(PLO_E_UNSUPPORTED, "entry other than +-1: host path only");
+                if (M->col[e] >= M->n || (e > M->rowptr[i] && M->col[e] <= M->col[e - 1])) return fail(PLO_E_ARG, "columns must be sorted and in range");
+            }
+        }
+        cap = std::max(cap, 2u * nnz + 3u * M->m);
+        bytes += round_up((M->m + 1) * 2, 16) + round_up(nnz * 2, 16) + round_up(nnz, 16);
+        algo += 2ull * (M->m + 1) + 3ull * nnz;                 // the CSR image of the three matrices, once per candidate
+    }
+    cap = round_up(cap + 2, 64);
+    plo_tril_plan *pl = new plo_tril_plan();
+    std::vector<uint8_t> img(bytes, 0);
+    if (hipMalloc(&pl->d_img, bytes) != hipSuccess) { delete pl; return fail(PLO_E_HIP, "hipMalloc"); }
+    size_t off = 0;
+    for (int w = 0; w < 3; ++w) {
+        const plo_icsr_t *M = Ms[w]; const uint32_t nnz = M->rowptr[M->m];
+        plo::TrilMat &D = pl->P.M[w];
+        D.m = M->m; D.n = M->n; D.nnz = nnz;
+        uint16_t *rp = (uint16_t *)(img.data() + off); D.rp = (const uint16_t *)((uint8_t *)pl->d_img + off); off += round_up((M->m + 1) * 2, 16);
+        uint16_t *cl = (uint16_t *)(img.data() + off); D.col = (const uint16_t *)((uint8_t *)pl->d_img + off); off += round_up(nnz * 2, 16);
+        int8_t *vl = (int8_t *)(img.data() + off); D.val = (const int8_t *)((uint8_t *)pl->d_img + off); off += round_up(nnz, 16);
+        for (uint32_t i = 0; i <= M->m; ++i) rp[i] = (uint16_t)M->rowptr[i];
+        for (uint32_t e = 0; e < nnz; ++e) { cl[e] = (uint16_t)M->col[e]; vl[e] = (int8_t)M->val[e]; }
+    }
+    pl->P.cap = cap;
+    pl->P.lds_per_wave = round_up(7u * cap + 2u * ((A->m + 1u) & ~1u) + A->m, 16);
+    pl->algo_bytes = algo;
+    pl->waves_per_wg = 4;
+    pl->lds_bytes = pl->P.lds_per_wave * pl->waves_per_wg;
+    if (pl->lds_bytes > 64u * 1024u) { pl->waves_per_wg = 1; pl->lds_bytes = pl->P.lds_per_wave; }
+    if (pl->lds_bytes > g_lds_max) { (void)hipFree(pl->d_img); delete pl; return fail(PLO_E_CAPACITY, "program does not fit LDS"); }
+    pl->blocks_per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32u / pl->waves_per_wg, (uint32_t)(g_lds_max / pl->lds_bytes)));
+    if (hipMemcpy(pl->d_img, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMalloc((void **)&pl->d_err, 4) != hipSuccess ||
+        hipMalloc((void **)&pl->d_best, 8) != hipSuccess || hipFuncSetAttribute((const void *)plo::tril_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes) != hipSuccess) {
+        plo_tril_plan_destroy(pl); return fail(PLO_E_HIP, "device setup of the trilplacer plan failed");
+    }
+    *plan = pl;
+    return PLO_OK;
+}
+
+void plo_tril_plan_destroy(plo_tril_plan_t *pl)
+{
+    if (!pl) return;
+    if (pl->d_img) (void)hipFree(pl->d_img);
+    if (pl->d_err) (void)hipFree(pl->d_err);
+    if (pl->d_best) (void)hipFree(pl->d_best);
+    delete pl;
+}
+
+int plo_tril_cost_many(plo_tril_plan_t *pl, const uint64_t *seeds, uint64_t seed0, uint64_t n, uint32_t *ops6, plo_stats_t *stats)
+{
+    if (!pl || !ops6) return fail(PLO_E_ARG, "null argument");
+    if (n >= (1ull << 31)) return fail(PLO_E_ARG, "at most 2^31-1 candidates per call");
+    plo_stats_t local{}; plo_stats_t *st = stats ? stats : &local; *st = plo_stats_t{};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n == 0) return PLO_OK;
+    uint32_t *d_ops = nullptr; uint64_t *d_seeds = nullptr;
+    HIPCHK(hipMalloc((void **)&d_ops, n * 6 * sizeof(uint32_t)));
+    if (seeds) { HIPCHK(hipMalloc((void **)&d_seeds, n * 8)); HIPCHK(hipMemcpy(d_seeds, seeds, n * 8, hipMemcpyHostToDevice)); }
+    plo::TrilJob J{}; J.seed0 = seed0; J.seeds = d_seeds; J.ncand = n; J.ops = d_ops; J.best = nullptr;
+    int rc = tril_launch(pl, J, st);
+    if (rc == PLO_OK && hipMemcpy(ops6, d_ops, n * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PLO_E_HIP, "copy back");
+    (void)hipFree(d_ops); if (d_seeds) (void)hipFree(d_seeds);
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int plo_tril_search(plo_tril_plan_t *pl, uint64_t seed0, uint64_t nseeds, plo_tril_best_t *best, plo_stats_t *stats)
+{
+    if (!pl || !best) return fail(PLO_E_ARG, "null argument");
+    if (nseeds == 0 || nseeds >= (1ull << 31)) return fail(PLO_E_ARG, "1 .. 2^31-1 candidates per call");
+    plo_stats_t local{}; plo_stats_t *st = stats ? stats : &local; *st = plo_stats_t{};
+    const auto t0 = std::chrono::steady_clock::now();
+    const unsigned long long init = ~0ull;
+    HIPCHK(hipMemcpy(pl->d_best, &init, 8, hipMemcpyHostToDevice));
+    plo::TrilJob J{}; J.seed0 = seed0; J.seeds = nullptr; J.ncand = nseeds; J.ops = nullptr; J.best = pl->d_best;
+    int rc = tril_launch(pl, J, st);
+    if (rc != PLO_OK) return rc;
+    unsigned long long w = 0;
+    HIPCHK(hipMemcpy(&w, pl->d_best, 8, hipMemcpyDeviceToHost));
+    if (w == init) return fail(PLO_E_INTERNAL, "no candidate reported");
+    best->add = (uint32_t)(w >> 48); best->sca = (uint32_t)(w >> 32) & 0xFFFFu; best->mul = pl->P.M[0].m;
+    best->variant = (uint32_t)(w & 1ull); best->seed = seed0 + ((w & 0xFFFFFFFFull) >> 1);
     st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PLO_OK;
 }

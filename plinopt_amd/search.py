@@ -129,3 +129,52 @@ def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1):
     capi.check(L.plo_cob_search(n, m, arr(TM), arr(Cand), row, offsetblock, arr(coeffs), len(coeffs), p, w0, w1,
                                 ctypes.byref(b), ctypes.byref(st)))
     return (b.zeros_v, b.zeros_w, b.index, b.found), st.as_dict()
+
+
+TRIL_BASE_SEED = (1 << 64) - 1
+
+
+class TrilPlan:
+    """Mirror of the restart loop of `SearchTriLinearAlgorithm` (reference include/plinopt_inplace.inl:812-929):
+    A, B and T (= transpose of the product matrix) as integer CSR triples (rowptr, col, val) with m rows each.
+    `cost_many` returns, per seed, ((ADD,SCA,MUL) oriented, (ADD,SCA,MUL) unoriented); `search` the best
+    (ADD, SCA, MUL, seed, variant) under the reference's order (:893-897), ties to the smaller (seed, variant)."""
+
+    def __init__(self, m, mats, device=None):
+        L = capi.lib()
+        if device is not None:
+            capi.check(L.plo_init(device))
+        self._keep = []
+        cs = []
+        for (n, rowptr, col, val) in mats:
+            a = ((ctypes.c_uint32 * len(rowptr))(*rowptr), (ctypes.c_uint32 * max(len(col), 1))(*col), (ctypes.c_int32 * max(len(val), 1))(*val))
+            self._keep.append(a)
+            cs.append(capi.ICSR(m, n, a[0], a[1], a[2]))
+        self._h = ctypes.c_void_p()
+        capi.check(L.plo_tril_plan_create(ctypes.byref(cs[0]), ctypes.byref(cs[1]), ctypes.byref(cs[2]), ctypes.byref(self._h)))
+        self.last_stats = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                capi.lib().plo_tril_plan_destroy(self._h); self._h = None
+        except Exception:
+            pass
+
+    def cost_many(self, seeds=None, seed0=0, n=0):
+        L = capi.lib()
+        if seeds is not None:
+            n = len(seeds); sp = (ctypes.c_uint64 * max(n, 1))(*seeds)
+        else:
+            sp = None
+        ops = (ctypes.c_uint32 * (6 * max(n, 1)))()
+        st = capi.Stats()
+        capi.check(L.plo_tril_cost_many(self._h, sp, seed0, n, ops, ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return [(tuple(ops[6 * k:6 * k + 3]), tuple(ops[6 * k + 3:6 * k + 6])) for k in range(n)]
+
+    def search(self, seed0, nseeds):
+        b, st = capi.TrilBest(), capi.Stats()
+        capi.check(capi.lib().plo_tril_search(self._h, seed0, nseeds, ctypes.byref(b), ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return (b.add, b.sca, b.mul), b.seed, b.variant

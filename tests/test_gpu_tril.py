@@ -1,0 +1,63 @@
+"""GPU parity of the trilplacer search (plo_tril_* of include/plinopt_hip.h) against oracle/plo_tril_oracle.c:
+(ADD, SCA, MUL) of both variants for every seed, bit-exact, and the same argmin."""
+import glob
+import os
+
+import pytest
+
+from plo_testlib import DATA, TRIL_BASE_SEED, OracleTril, read_sms
+
+pytestmark = pytest.mark.gpu
+
+
+def unit_triples():
+    out = []
+    for l in sorted(glob.glob(os.path.join(DATA, "*_L.sms"))):
+        r, p = l[:-6] + "_R.sms", l[:-6] + "_P.sms"
+        if not (os.path.exists(r) and os.path.exists(p)):
+            continue
+        try:
+            mats = [read_sms(f) for f in (l, r, p)]
+        except ValueError:
+            continue
+        if all(abs(v) == 1 for _, _, e in mats for v in e.values()) and mats[2][0] <= 64 and mats[0][1] <= 64 and mats[1][1] <= 64:
+            rows_ok = all(len({i for (i, j) in e}) == m for m, n, e in mats[:2]) and len({j for (i, j) in mats[2][2]}) == mats[2][1]
+            if rows_ok:
+                out.append(os.path.basename(l)[:-6])
+    return out
+
+
+UNIT = unit_triples()
+
+
+def plans(name):
+    from plinopt_amd import TrilPlan
+    O = OracleTril.from_sms(*(os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")))
+    mats = [(n, rp, col, [int(x) for x in num]) for n, (rp, col, num, den) in zip(O.dims, O.csr)]
+    return O, TrilPlan(O.m, mats)
+
+
+def test_unit_fixtures_present():
+    assert "4x4x4_49_156" in UNIT and "2x2x2_7_Winograd" in UNIT and len(UNIT) >= 5
+
+
+@pytest.mark.parametrize("name", UNIT)
+def test_cost_many_bit_exact(hip, name):
+    O, G = plans(name)
+    n = 48 if O.m > 30 else 96
+    seeds = [TRIL_BASE_SEED, 0, 1, 2**40 + 7] + list(range(1000, 1000 + n))
+    assert G.cost_many(seeds=seeds) == O.cost_many(seeds=seeds)
+
+
+def test_search_same_argmin(hip):
+    O, G = plans("4x4x4_49_156")
+    assert G.search(5000, 300) == O.search(5000, 300)
+    O, G = plans("2x2x2_7_Winograd")
+    assert G.search(0, 2000) == O.search(0, 2000)
+
+
+def test_non_unit_inputs_are_refused(hip):
+    from plinopt_amd import TrilPlan, capi
+    with pytest.raises(capi.PloError) as e:
+        TrilPlan(2, [(2, [0, 1, 2], [0, 1], [1, 2]), (2, [0, 1, 2], [0, 1], [1, 1]), (2, [0, 1, 2], [0, 1], [1, 1])])
+    assert e.value.code == capi.PLO_E_UNSUPPORTED
