@@ -30,6 +30,9 @@ WORKLOADS = {
                  "bin/optimizer -q 131071 -D data/2x2x2_7_Winograd_L.sms, 10^6 random restarts per step (BASELINE configs[1])"),
     "4x4x4_L": ("4x4x4_49_156_L.sms", 131071, 200000,
                 "bin/optimizer -q 131071 -D data/4x4x4_49_156_L.sms, 2*10^5 random restarts per step"),
+    "tril": ("4x4x4_49_156", 0, 200000,
+             "bin/trilplacer data/4x4x4_49_156_{L,R,P}.sms -O N (BASELINE configs[3]): 2*10^5 restarts per step, each = one row permutation "
+             "+ coherent negations, oriented and unoriented in-place program"),
     "4x4x4_P": ("4x4x4_49_156_P.sms", 131071, 100000,
                 "bin/optimizer -q 131071 -D data/4x4x4_49_156_P.sms, 10^5 random restarts per step"),
     "cyclic": ("cyclic.sms", 131071, 500000, "bin/optimizer -q 131071 -D data/cyclic.sms"),
@@ -177,6 +180,56 @@ def bench_cob(args):
     print(json.dumps(out))
 
 
+def bench_tril(args):
+    """configs[3]: the restart loop of SearchTriLinearAlgorithm (plinopt_inplace.inl:837-924) on the GPU."""
+    import torch
+    from plinopt_amd import capi, TrilPlan
+    from plo_testlib import DATA, OracleTril
+    name, _, batch, desc = WORKLOADS["tril"]
+    if args.batch:
+        batch = args.batch
+    torch.cuda.set_device(0)
+    capi.check(capi.lib().plo_init(0))
+    O = OracleTril.from_sms(*(os.path.join(DATA, name + x) for x in ("_L.sms", "_R.sms", "_P.sms")))
+    G = TrilPlan(O.m, [(n, rp, col, [int(x) for x in num]) for n, (rp, col, num, den) in zip(O.dims, O.csr)])
+    steps = args.steps if args.steps is not None else 10
+    warm = args.warmup if args.warmup is not None else 2
+    for k in range(warm):
+        G.search(k * batch, batch)
+    torch.cuda.synchronize()
+    kms = 0.0
+    best = None
+    t0 = time.perf_counter()
+    for k in range(steps):
+        r = G.search((warm + k) * batch, batch)
+        kms += G.last_stats["kernel_ms"]
+        key = (r[0][0], r[0][1], r[1], r[2])
+        best = key if best is None or key < best else best
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = G.last_stats
+    per = kms / steps
+    algo = st["algo_bytes"] * batch
+    out = {"metric": "candidate in-place programs/sec", "value": batch * steps / dt, "unit": "candidates/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16",
+           "data": "synthetic seeds over the reference's own data/%s_{L,R,P}.sms" % name,
+           "config": {"workload": desc, "matrices": name, "per_gpu_batch": batch, "rows": O.m, "dims": list(O.dims)},
+           "best": {"add": best[0], "sca": best[1], "seed": best[2], "variant": best[3]},
+           "roofline": {"bound": "hbm", "achieved": algo / (per * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "plo::tril_kernel", "kernel_ms_per_launch": per, "algo_bytes_per_candidate": st["algo_bytes"],
+                        "note": "atom lists are LDS-resident (one wavefront per candidate); HBM sees the three CSR images (L2-resident) and one "
+                                "result word per workgroup: the limiter is LDS latency of dependent scans, not HBM"},
+           "kernel": {"lds_bytes": st["lds_bytes"], "waves_per_wg": st["waves_per_wg"], "grid": st["grid"]}}
+    if not args.no_cpu_baseline:
+        n = 2000
+        t0 = time.perf_counter()
+        ob = O.search(0, n)
+        d = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / d, "unit": "candidates/s", "cores": 1, "kind": "port",
+                               "sample": "%d seeds of the same matrices through oracle/plo_tril_oracle.c, single thread, %.1f s; best %s" % (n, d, list(ob))}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +242,8 @@ def main():
 
     if args.workload == "cob":
         return bench_cob(args)
+    if args.workload == "tril":
+        return bench_tril(args)
     if args.steps is None:
         args.steps = 3 if args.workload == "32x32x32" else 20       # one config-5 step is ~3 s of GPU time
     if args.warmup is None:

@@ -856,6 +856,9 @@ int tril_launch(plo_tril_plan *pl, plo::TrilJob J, plo_stats_t *st) {
     uint32_t err = 0;
     HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = pl->waves_per_wg; st->algo_bytes = pl->algo_bytes; st->candidates += J.ncand; }
+#ifdef PLO_TRIL_PROFILE
+    { unsigned long long gp[8] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_tprof), sizeof gp) == hipSuccess && gp[5]) fprintf(stderr, "# tril profile (wave 0 of every workgroup, %llu candidates): cycles per candidate: perm %.0f build %.0f pushvariables %.0f simplify %.0f; fixpoint trips %.1f\n", gp[5], (double)gp[0] / gp[5], (double)gp[1] / gp[5], (double)gp[2] / gp[5], (double)gp[3] / gp[5], (double)gp[4] / gp[5]); }
+#endif
     if (err) return fail(err == plo::TERR_CAP ? PLO_E_INTERNAL : PLO_E_UNSUPPORTED, "device (trilplacer): error " + std::to_string(err));
     return PLO_OK;
 }

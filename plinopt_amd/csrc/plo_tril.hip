@@ -38,8 +38,17 @@ struct TrilJob {
 enum { TERR_CAP = 21, TERR_ROW = 22 };
 enum { T_BAR = 0, T_ADD = 1, T_SUB = 2, T_MUL = 3, T_DIV = 4 };
 
+#ifndef PLO_TRIL_LOCKSTEPS
+#define PLO_TRIL_LOCKSTEPS 6u
+#endif
 #define TW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+#ifdef PLO_TRIL_PROFILE
+__device__ unsigned long long g_tprof[8];   // lane 0 of wave 0 of every workgroup: cycles in perm, build, pushvariables, simplify; calls
+#define TP_ADD(k_, t0_) do { if (threadIdx.x == 0) g_tprof[k_] += clock64() - (t0_); } while (0)
+#else
+#define TP_ADD(k_, t0_) do { } while (0)
+#endif
 struct TrilProg { uint16_t *src; int16_t *des; int16_t *val; uint8_t *ope; uint32_t n; };
 
 __device__ __forceinline__ uint32_t t_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
@@ -97,19 +106,40 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
         int is = 0, id = 0, iv = 0; uint32_t io = 0;
         if (act) { is = P.src[p]; id = P.des[p]; iv = P.val[p]; io = P.ope[p]; act = io != T_BAR; }
         uint32_t k = p + 1u, q = 0; int res = act ? 0 : 2;       // 0 walking, 1 merge found, 2 stopped
-        while (__builtin_amdgcn_ballot_w64(res == 0)) {
+        // what stops the walk of atom (is,id,io) at atom kk: a merge (sameops + cumulate) or a dependency (:284-307)
+        auto merges = [&](int s_, int d_, uint32_t o_, uint32_t kk) {
+            const uint32_t no = P.ope[kk];
+            return (int)P.src[kk] == s_ && (int)P.des[kk] == d_ && ((t_as(o_) && t_as(no)) || (t_md(o_) && t_md(no)));
+        };
+        auto breaks = [&](int s_, int d_, uint32_t o_, uint32_t kk) {
+            const int ns = P.src[kk], nd = P.des[kk]; const uint32_t no = P.ope[kk];
+            bool brk = (s_ == ns) && (no == T_BAR || (t_as(o_) && t_md(no)) || (t_md(o_) && t_as(no)));
+            brk |= transposed ? (d_ == ns) : (d_ == ns && no != T_BAR);
+            brk |= (s_ == nd);
+            return brk;
+        };
+        // most walks end within a few atoms: a few lock-step steps, one atom per lane ...
+        for (uint32_t step = 0; step < PLO_TRIL_LOCKSTEPS && __builtin_amdgcn_ballot_w64(res == 0); ++step) {
             if (res == 0) {
                 if (k >= n) res = 2;
-                else {
-                    const int ns = P.src[k], nd = P.des[k]; const uint32_t no = P.ope[k];
-                    if (ns == is && nd == id && ((t_as(io) && t_as(no)) || (t_md(io) && t_md(no)))) { res = 1; q = k; }   // sameops + cumulate
-                    else {
-                        bool brk = (is == ns) && (no == T_BAR || (t_as(io) && t_md(no)) || (t_md(io) && t_as(no)));
-                        brk |= transposed ? (id == ns) : (id == ns && no != T_BAR);
-                        brk |= (is == nd);
-                        if (brk) res = 2; else ++k;
-                    }
-                }
+                else if (merges(is, id, io, k)) { res = 1; q = k; }
+                else if (breaks(is, id, io, k)) res = 2;
+                else ++k;
+            }
+        }
+        // ... and each long walk that is still open before the first merge found so far is finished by the whole wave
+        {
+            const unsigned long long ok1 = __builtin_amdgcn_ballot_w64(res == 1);
+            unsigned long long und = __builtin_amdgcn_ballot_w64(res == 0);
+            if (ok1) und &= (1ull << __builtin_ctzll(ok1)) - 1ull;
+            while (und) {
+                const int L = __builtin_ctzll(und); und &= und - 1ull;
+                const int bs = __builtin_amdgcn_readlane(is, L), bd = __builtin_amdgcn_readlane(id, L);
+                const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)io, L), bk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
+                const uint32_t e = t_find(bk, n, lane, [&](uint32_t kk) { return merges(bs, bd, bo, kk) || breaks(bs, bd, bo, kk); });
+                const bool mg = e < n && merges(bs, bd, bo, e);
+                if ((int)lane == L) { if (mg) { res = 1; q = e; } else res = 2; }
+                if (mg) break;
             }
         }
         const unsigned long long ok = __builtin_amdgcn_ballot_w64(res == 1);
@@ -163,6 +193,7 @@ __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane) {
 __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, bool transposed,
                          bool oriented, uint32_t &rng, uint32_t lane, uint32_t ops[3], uint32_t cap, uint32_t *errw) {
     P.n = 0;
+    const unsigned long long tb0 = clock64(); (void)tb0;
     uint32_t preci = M.n;
     for (uint32_t l = 0; l < M.m; ++l) {
         const uint32_t r = perm[l], b = M.rp[r], len = (uint32_t)M.rp[r + 1u] - b;
@@ -211,8 +242,18 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
         TW_SYNC();
     }
     // no '*1' atoms exist for +-1 inputs (:481-482); fixpoint :488-494
+    TP_ADD(1, tb0);
     bool simp;
-    do { if (transposed) t_pushvariables(P, M.n, lane); simp = t_simplify(P, transposed, lane); } while (simp);
+    do {
+        unsigned long long t1 = clock64();
+        if (transposed) t_pushvariables(P, M.n, lane);
+        TP_ADD(2, t1); t1 = clock64();
+        simp = t_simplify(P, transposed, lane);
+        TP_ADD(3, t1);
+#ifdef PLO_TRIL_PROFILE
+        if (threadIdx.x == 0) g_tprof[4] += 1;
+#endif
+    } while (simp);
     uint32_t a = 0, s = 0, mu = 0;                                                                    // :133-144
     for (uint32_t k = lane; k < P.n; k += 64u) {
         const uint32_t o = P.ope[k]; const int v = P.val[k];
@@ -238,6 +279,7 @@ __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
     const uint64_t stride = (uint64_t)gridDim.x * nw;
     for (uint64_t cnd = (uint64_t)blockIdx.x * nw + wave; cnd < J.ncand; cnd += stride) {
         const uint64_t seed = J.seeds ? J.seeds[cnd] : J.seed0 + cnd;
+        const unsigned long long tc0 = clock64(); (void)tc0;
         uint32_t rng = 1u + (uint32_t)(t_splitmix(seed) % 2147483646ull);
         const bool basec = seed == ~0ull;
         for (uint32_t k = lane; k < m; k += 64u) { perm[k] = (uint16_t)k; sgn[k] = 0; }
@@ -251,6 +293,10 @@ __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
             rng = t_uni(rng);
             TW_SYNC();
         }
+        TP_ADD(0, tc0);
+#ifdef PLO_TRIL_PROFILE
+        if (threadIdx.x == 0) g_tprof[5] += 1;
+#endif
         uint32_t tot[6] = {0, 0, 0, 0, 0, 0};
         for (uint32_t variant = 0; variant < 2u; ++variant) {
             if (basec && variant == 1u) { tot[3] = tot[0]; tot[4] = tot[1]; tot[5] = tot[2]; break; }
