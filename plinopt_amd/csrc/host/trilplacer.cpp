@@ -1,0 +1,135 @@
+// ==========================================================================
+// bin/trilplacer -- in-place trilinear programs (reference src/trilplacer.cpp:60-190):
+//   trilplacer L.sms R.sms P.sms [-O #] [--seed s] [--gpu 0|1]
+// stdout = the program (a_i, b_j restored, c_k += the bilinear map), clog = '#' statistics
+// ("ADD / SCA / AXPY" as the reference :170-180).  The restart loop of
+// SearchTriLinearAlgorithm (include/plinopt_inplace.inl:837-924) runs on the GPU through
+// plo_tril_search of libplinopt_hip.so when the three matrices are +-1 matrices without
+// empty rows; the winner is replayed on the host to print it.  Other inputs, or --gpu 0,
+// use the host loop (OpenMP).  -e (double expansion) is not built.
+// ==========================================================================
+#include "plo_inplace.hpp"
+#include "../../../include/plinopt_hip.h"
+#include <dlfcn.h>
+#include <libgen.h>
+#include <unistd.h>
+#include <chrono>
+#include <fstream>
+#include <omp.h>
+#include <tuple>
+
+using namespace plo;
+
+namespace {
+struct HipTril {
+    void *h = nullptr;
+    decltype(&plo_init) init = nullptr; decltype(&plo_last_error) last_error = nullptr;
+    decltype(&plo_tril_plan_create) create = nullptr; decltype(&plo_tril_plan_destroy) destroy = nullptr; decltype(&plo_tril_search) search = nullptr;
+    bool load() {
+        std::vector<std::string> cand;
+        if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
+        char buf[4096]; ssize_t k = readlink("/proc/self/exe", buf, sizeof buf - 1);
+        if (k > 0) { buf[k] = 0; std::string d = dirname(buf); cand.push_back(d + "/../plinopt_amd/libplinopt_hip.so"); cand.push_back(d + "/libplinopt_hip.so"); }
+        cand.emplace_back("libplinopt_hip.so");
+        for (auto &c : cand) { h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
+        init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
+        create = (decltype(create))dlsym(h, "plo_tril_plan_create"); destroy = (decltype(destroy))dlsym(h, "plo_tril_plan_destroy");
+        search = (decltype(search))dlsym(h, "plo_tril_search");
+        return init && last_error && create && destroy && search;
+    }
+};
+
+bool better(const Tricount &l, const Tricount &r) { return l[0] < r[0] || (l[0] == r[0] && l[1] < r[1]); }   // :893-897
+
+struct ICsr { std::vector<uint32_t> rp{0}, col; std::vector<int32_t> val; bool unit = true, full = true; };
+ICsr icsr(const QMat &M) {
+    ICsr c;
+    for (const auto &row : M.rows) {
+        if (row.empty() || row.size() > 64) c.full = false;
+        for (const auto &e : row) { c.col.push_back((uint32_t)e.first); if (!(e.second.d == 1 && (e.second.n == 1 || e.second.n == -1))) c.unit = false; c.val.push_back((int32_t)e.second.n); }
+        c.rp.push_back((uint32_t)c.col.size());
+    }
+    return c;
+}
+} // namespace
+
+int main(int argc, char **argv) {
+    size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; std::vector<std::string> files;
+    for (int i = 1; i < argc; ++i) {
+        std::string a(argv[i]);
+        if (a == "-h") { std::clog << "Usage: " << argv[0] << " L.sms R.sms P.sms [-O #] [--seed s] [--gpu 0|1]\n"; return 0; }
+        else if (a == "-O" && i + 1 < argc) loops = (size_t)atoll(argv[++i]);
+        else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
+        else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (a == "-e") { std::cerr << "# \033[1;31mERROR: -e (double expansion) is not built\033[0m\n"; return 2; }
+        else files.push_back(a);
+    }
+    if (files.size() != 3) { std::cerr << "# \033[1;31mERROR: three matrices needed (L R P)\033[0m\n"; return -1; }
+    try {
+        QMat M[3];
+        for (int k = 0; k < 3; ++k) { std::ifstream in(files[(size_t)k]); if (!in) { std::cerr << "# \033[1;31mERROR: cannot read " << files[(size_t)k] << "\033[0m\n"; return -1; } M[k] = read_sms(in); }
+        const QMat &A = M[0], &B = M[1]; QMat T = transpose(M[2]);
+        if (A.rowdim() != B.rowdim() || A.rowdim() != T.rowdim()) { std::cerr << "Incorrect dimensions\n"; return 1; }
+        const auto t0 = std::chrono::steady_clock::now();
+        TrilCandidate basec = tril_candidate(A, B, T, ~0ull, 0);
+        Tricount best = basec.ops[0]; uint64_t bseed = ~0ull; int bvar = 0;
+        std::clog << "# Oriented number of operations: " << best[0] << '|' << best[1] << '|' << best[2] << std::endl;
+        bool on_gpu = false; double kms = 0;
+        if (loops > 0) {
+            ICsr ca = icsr(A), cb = icsr(B), ct = icsr(T);
+            if (gpu && ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full) {
+                HipTril L;
+                if (!L.load()) return 2;                                  // no silent fallback: --gpu 0 selects the host loop
+                if (L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m\n"; return 2; }
+                plo_icsr_t a{(uint32_t)A.rowdim(), (uint32_t)A.coldim(), ca.rp.data(), ca.col.data(), ca.val.data()};
+                plo_icsr_t b{(uint32_t)B.rowdim(), (uint32_t)B.coldim(), cb.rp.data(), cb.col.data(), cb.val.data()};
+                plo_icsr_t t{(uint32_t)T.rowdim(), (uint32_t)T.coldim(), ct.rp.data(), ct.col.data(), ct.val.data()};
+                plo_tril_plan_t *plan = nullptr;
+                if (L.create(&a, &b, &t, &plan) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m\n"; return 2; }
+                plo_tril_best_t r{}; plo_stats_t st{};
+                if (L.search(plan, seed0, loops, &r, &st) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m\n"; L.destroy(plan); return 2; }
+                L.destroy(plan);
+                on_gpu = true; kms = st.kernel_ms;
+                const Tricount g{r.add, r.sca, r.mul};
+                if (better(g, best)) { best = g; bseed = r.seed; bvar = (int)r.variant; }
+            } else {
+                if (gpu) std::clog << "# matrices are not +-1 without empty rows: host search" << std::endl;
+                // best of the loop under (ADD, SCA, seed, variant), then strictly better than the unpermuted program
+                using Key = std::tuple<size_t, size_t, uint64_t, int>;
+                Key lb{~(size_t)0, ~(size_t)0, 0, 0};
+                #pragma omp parallel
+                {
+                    Key tb = lb;
+                    #pragma omp for schedule(dynamic, 16)
+                    for (long long k = 0; k < (long long)loops; ++k) {
+                        TrilCandidate c = tril_candidate(A, B, T, seed0 + (uint64_t)k, -1);
+                        for (int v = 0; v < 2; ++v) tb = std::min(tb, Key{c.ops[v][0], c.ops[v][1], seed0 + (uint64_t)k, v});
+                    }
+                    #pragma omp critical
+                    lb = std::min(lb, tb);
+                }
+                const Tricount g{std::get<0>(lb), std::get<1>(lb), A.rowdim()};
+                if (better(g, best)) { best = g; bseed = std::get<2>(lb); bvar = std::get<3>(lb); }
+            }
+        }
+        // replay of the winner for the text
+        std::string text;
+        if (bseed == ~0ull) text = basec.text[0];
+        else {
+            TrilCandidate w = tril_candidate(A, B, T, bseed, bvar);
+            if (w.ops[bvar] != best) { std::cerr << "# \033[1;31mERROR: replay of seed " << bseed << " gives " << w.ops[bvar][0] << '|' << w.ops[bvar][1] << ", search said " << best[0] << '|' << best[1] << "\033[0m\n"; return 3; }
+            text = w.text[bvar];
+            std::clog << "# Found " << (bvar ? "unoriented" : "oriented") << " [seed " << bseed << "], operations: " << best[0] << '|' << best[1] << '|' << best[2] << std::endl;
+        }
+        std::cout << text << std::flush;
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::clog << std::string(40, '#') << std::endl;
+        std::clog << "# \033[1;32m" << best[0] << "\tADD\033[0m\n# \033[1;32m" << best[1] << "\tSCA\033[0m\n# \033[1;32m" << best[2] << "\tAXPY\033[0m\n";
+        std::clog << std::string(40, '#') << std::endl;
+        std::clog << "# " << loops << " restarts on " << (on_gpu ? "GPU" : "host") << " in " << dt << " s";
+        if (on_gpu) std::clog << " (kernel " << kms << " ms)";
+        std::clog << std::endl;
+    } catch (const std::exception &e) { std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m\n"; return 4; }
+    return 0;
+}

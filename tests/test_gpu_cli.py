@@ -67,3 +67,24 @@ def test_lu_method_on_gpu_equals_host_search(name):
     assert out == out0
     rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2, err2
+
+
+def test_trilplacer_cli_on_gpu():
+    """bin/trilplacer: restart loop on the GPU (plo_tril_search), winner replayed on the host; the program runs in
+    place and the reported (ADD, SCA) are those of the oracle's argmin over the same seeds."""
+    import random
+    from plo_testlib import TRIL_BASE_SEED, OracleTril
+    from test_tril_oracle import check_program
+    name = "4x4x4_49_156"
+    files = [os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")]
+    T = OracleTril.from_sms(*files)
+    n = 400
+    r = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-O", str(n), "--seed", "1000"] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "restarts on GPU" in r.stderr
+    ops, seed, var = T.search(1000, n)
+    (base, _), = T.cost_many(seeds=[TRIL_BASE_SEED])
+    want = ops if (ops[0], ops[1]) < (base[0], base[1]) else base
+    got = tuple(int(x) for x in re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", r.stderr))
+    assert got == want, (got, want, r.stderr)
+    check_program(T, r.stdout, want, random.Random(5))

@@ -193,3 +193,29 @@ def test_sparsifier_finds_the_known_sparse_basis_of_winograd():
     """Winograd's L matrix (14 non-zeros) has an alternative basis with 10 (data/2x2x2_7_DPS-accurate-ALT_L.sms)."""
     rc, out, err = run([SPS, "-c", "4", "-S", os.path.join(DATA, "2x2x2_7_Winograd_L.sms")])
     assert rc == 0 and re.search(r"with (\d+) non-zeroes", err).group(1) == "10"
+
+
+# ----------------------------------------------------------------------------- trilplacer (host loop)
+TRIL_CASES = ["2x2x2_7_Winograd", "4x4x4_49_156", "1o1o2_3_Karatsuba", "2x2x2_7_DPS-accurate"]
+
+
+@pytest.mark.parametrize("name", TRIL_CASES)
+def test_trilplacer_host_search_equals_oracle_and_program_runs_in_place(name):
+    """bin/trilplacer --gpu 0: the host restart loop picks the oracle's argmin, and the printed program, run by the
+    independent in-place interpreter, adds the bilinear map to c and restores a and b."""
+    import random
+    from plo_testlib import TRIL_BASE_SEED, OracleTril
+    from test_tril_oracle import check_program
+    files = [os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")]
+    if not all(os.path.exists(f) for f in files):
+        pytest.skip("fixture triple absent")
+    T = OracleTril.from_sms(*files)
+    n = 60
+    r = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "--gpu", "0", "-O", str(n), "--seed", "7"] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ops, seed, var = T.search(7, n)
+    (base, _), = T.cost_many(seeds=[TRIL_BASE_SEED])
+    want = ops if (ops[0], ops[1]) < (base[0], base[1]) else base
+    got = tuple(int(x) for x in re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", r.stderr))
+    assert got == want, (got, want, r.stderr)
+    check_program(T, r.stdout, want, random.Random(11))
