@@ -9,7 +9,7 @@
 // winning seed to print the program.
 //
 // One wavefront per candidate.  The atom list of the program being built lives in
-// LDS as four arrays (src u16, des i16, val i16, ope u8); the control flow is wave
+// LDS, one 8-byte word per atom (src, des, val, ope); the control flow is wave
 // uniform and the lanes share the scans:
 //   simplify  (:243-311)  64 atoms at a time, every lane walks the atoms after its
 //                         own one until it meets a mergeable atom or a dependency;
@@ -39,7 +39,7 @@ enum { TERR_CAP = 21, TERR_ROW = 22 };
 enum { T_BAR = 0, T_ADD = 1, T_SUB = 2, T_MUL = 3, T_DIV = 4 };
 
 #ifndef PLO_TRIL_LOCKSTEPS
-#define PLO_TRIL_LOCKSTEPS 6u
+#define PLO_TRIL_LOCKSTEPS 20u
 #endif
 #define TW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -49,7 +49,15 @@ __device__ unsigned long long g_tprof[8];   // lane 0 of wave 0 of every workgro
 #else
 #define TP_ADD(k_, t0_) do { } while (0)
 #endif
-struct TrilProg { uint16_t *src; int16_t *des; int16_t *val; uint8_t *ope; uint32_t n; };
+// one atom = one 8-byte word: src | des<<16 | val<<32 | ope<<48 (des, val signed 16 bits)
+struct TrilProg { uint64_t *at; uint32_t n; };
+__device__ __forceinline__ uint64_t ta_make(uint32_t src, int des, int val, uint32_t ope) {
+    return (uint64_t)(src & 0xFFFFu) | ((uint64_t)((uint32_t)des & 0xFFFFu) << 16) | ((uint64_t)((uint32_t)val & 0xFFFFu) << 32) | ((uint64_t)ope << 48);
+}
+__device__ __forceinline__ int ta_src(uint64_t a) { return (int)(a & 0xFFFFull); }
+__device__ __forceinline__ int ta_des(uint64_t a) { return (int)(int16_t)(uint16_t)(a >> 16); }
+__device__ __forceinline__ int ta_val(uint64_t a) { return (int)(int16_t)(uint16_t)(a >> 32); }
+__device__ __forceinline__ uint32_t ta_ope(uint64_t a) { return (uint32_t)(a >> 48) & 0xFFu; }
 
 __device__ __forceinline__ uint32_t t_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t t_rng(uint32_t &s) { s = (uint32_t)((950706376ull * (uint64_t)s) % 2147483647ull); return s; }
@@ -59,72 +67,69 @@ __device__ __forceinline__ uint64_t t_splitmix(uint64_t x) {
 __device__ __forceinline__ bool t_as(uint32_t o) { return o == T_ADD || o == T_SUB; }
 __device__ __forceinline__ bool t_md(uint32_t o) { return o == T_MUL || o == T_DIV; }
 
-// remove atoms [k, k+1): everything behind moves one slot down (64 at a time, lowest chunk first: a chunk's reads are
-// complete before its writes, and it reads the first element of the next chunk before that chunk is written)
-__device__ __forceinline__ void t_erase(TrilProg &P, uint32_t k, uint32_t lane) {
-    for (uint32_t b = k; b + 1u < P.n; b += 64u) {
-        const uint32_t d = b + lane; const bool on = d + 1u < P.n;
-        uint16_t s = 0; int16_t e = 0, v = 0; uint8_t o = 0;
-        if (on) { s = P.src[d + 1u]; e = P.des[d + 1u]; v = P.val[d + 1u]; o = P.ope[d + 1u]; }
+// [lo, hi) moves one slot down onto [lo-1, hi-1) (64 at a time, lowest chunk first: a chunk's reads are complete
+// before its writes, and it reads the first element of the next chunk before that chunk is written)
+__device__ __forceinline__ void t_shift_down(TrilProg &P, uint32_t lo, uint32_t hi, uint32_t lane) {
+    for (uint32_t b = lo; b < hi; b += 64u) {
+        const uint32_t d = b + lane; const bool on = d < hi;
+        uint64_t a = 0;
+        if (on) a = P.at[d];
         TW_SYNC();
-        if (on) { P.src[d] = s; P.des[d] = e; P.val[d] = v; P.ope[d] = o; }
+        if (on) P.at[d - 1u] = a;
         TW_SYNC();
     }
-    --P.n;
 }
+__device__ __forceinline__ void t_erase(TrilProg &P, uint32_t k, uint32_t lane) { t_shift_down(P, k + 1u, P.n, lane); --P.n; }
 // std::rotate(f, f+1, e): atom f goes to e-1, [f+1, e) moves one slot down
 __device__ __forceinline__ void t_rotate(TrilProg &P, uint32_t f, uint32_t e, uint32_t lane) {
-    const uint16_t fs = P.src[f]; const int16_t fd = P.des[f], fv = P.val[f]; const uint8_t fo = P.ope[f];
+    const uint64_t fa = P.at[f];
     TW_SYNC();
-    for (uint32_t b = f; b + 1u < e; b += 64u) {
-        const uint32_t d = b + lane; const bool on = d + 1u < e;
-        uint16_t s = 0; int16_t x = 0, v = 0; uint8_t o = 0;
-        if (on) { s = P.src[d + 1u]; x = P.des[d + 1u]; v = P.val[d + 1u]; o = P.ope[d + 1u]; }
-        TW_SYNC();
-        if (on) { P.src[d] = s; P.des[d] = x; P.val[d] = v; P.ope[d] = o; }
-        TW_SYNC();
-    }
-    if (lane == 0) { P.src[e - 1u] = fs; P.des[e - 1u] = fd; P.val[e - 1u] = fv; P.ope[e - 1u] = fo; }
+    t_shift_down(P, f + 1u, e, lane);
+    if (lane == 0) P.at[e - 1u] = fa;
     TW_SYNC();
 }
 
-// first k in [start, n) with pred(k), or n
-template <class F> __device__ __forceinline__ uint32_t t_find(uint32_t start, uint32_t n, uint32_t lane, F pred) {
+// first k in [start, n) with pred(atom k), or n
+template <class F> __device__ __forceinline__ uint32_t t_find(const TrilProg &P, uint32_t start, uint32_t n, uint32_t lane, F pred) {
     for (uint32_t b = start; b < n; b += 64u) {
         const uint32_t k = b + lane;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(k < n && pred(k));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(k < n && pred(P.at[k < n ? k : start]));
         if (m) return b + (uint32_t)__builtin_ctzll(m);
     }
     return n;
+}
+
+// what stops the walk of atom `it` at atom `nx`: a merge (sameops + cumulate, :266-282) or a dependency (:284-307)
+__device__ __forceinline__ bool t_merges(uint64_t it, uint64_t nx) {
+    const uint32_t io = ta_ope(it), no = ta_ope(nx);
+    return (uint32_t)it == (uint32_t)nx && ((t_as(io) && t_as(no)) || (t_md(io) && t_md(no)));       // same src and des, compatible operations
+}
+__device__ __forceinline__ bool t_breaks(uint64_t it, uint64_t nx, bool transposed) {
+    const int is = ta_src(it), id = ta_des(it), ns = ta_src(nx), nd = ta_des(nx); const uint32_t io = ta_ope(it), no = ta_ope(nx);
+    bool brk = (is == ns) && (no == T_BAR || (t_as(io) && t_md(no)) || (t_md(io) && t_as(no)));
+    brk |= transposed ? (id == ns) : (id == ns && no != T_BAR);
+    brk |= (is == nd);
+    return brk;
 }
 
 // :243-311.  true = one merge applied.
 __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
     for (uint32_t base = 0; base < P.n; base += 64u) {
         const uint32_t p = base + lane, n = P.n;
+        uint64_t it = 0;
         bool act = p < n;
-        int is = 0, id = 0, iv = 0; uint32_t io = 0;
-        if (act) { is = P.src[p]; id = P.des[p]; iv = P.val[p]; io = P.ope[p]; act = io != T_BAR; }
+        if (act) { it = P.at[p]; act = ta_ope(it) != T_BAR; }
         uint32_t k = p + 1u, q = 0; int res = act ? 0 : 2;       // 0 walking, 1 merge found, 2 stopped
-        // what stops the walk of atom (is,id,io) at atom kk: a merge (sameops + cumulate) or a dependency (:284-307)
-        auto merges = [&](int s_, int d_, uint32_t o_, uint32_t kk) {
-            const uint32_t no = P.ope[kk];
-            return (int)P.src[kk] == s_ && (int)P.des[kk] == d_ && ((t_as(o_) && t_as(no)) || (t_md(o_) && t_md(no)));
-        };
-        auto breaks = [&](int s_, int d_, uint32_t o_, uint32_t kk) {
-            const int ns = P.src[kk], nd = P.des[kk]; const uint32_t no = P.ope[kk];
-            bool brk = (s_ == ns) && (no == T_BAR || (t_as(o_) && t_md(no)) || (t_md(o_) && t_as(no)));
-            brk |= transposed ? (d_ == ns) : (d_ == ns && no != T_BAR);
-            brk |= (s_ == nd);
-            return brk;
-        };
         // most walks end within a few atoms: a few lock-step steps, one atom per lane ...
         for (uint32_t step = 0; step < PLO_TRIL_LOCKSTEPS && __builtin_amdgcn_ballot_w64(res == 0); ++step) {
             if (res == 0) {
                 if (k >= n) res = 2;
-                else if (merges(is, id, io, k)) { res = 1; q = k; }
-                else if (breaks(is, id, io, k)) res = 2;
-                else ++k;
+                else {
+                    const uint64_t nx = P.at[k];
+                    if (t_merges(it, nx)) { res = 1; q = k; }
+                    else if (t_breaks(it, nx, transposed)) res = 2;
+                    else ++k;
+                }
             }
         }
         // ... and each long walk that is still open before the first merge found so far is finished by the whole wave
@@ -134,10 +139,10 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
             if (ok1) und &= (1ull << __builtin_ctzll(ok1)) - 1ull;
             while (und) {
                 const int L = __builtin_ctzll(und); und &= und - 1ull;
-                const int bs = __builtin_amdgcn_readlane(is, L), bd = __builtin_amdgcn_readlane(id, L);
-                const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)io, L), bk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
-                const uint32_t e = t_find(bk, n, lane, [&](uint32_t kk) { return merges(bs, bd, bo, kk) || breaks(bs, bd, bo, kk); });
-                const bool mg = e < n && merges(bs, bd, bo, e);
+                const uint64_t bit = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(it >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)it, L);
+                const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
+                const uint32_t e = t_find(P, bk, n, lane, [&](uint64_t nx) { return t_merges(bit, nx) || t_breaks(bit, nx, transposed); });
+                const bool mg = e < n && t_merges(bit, P.at[e < n ? e : 0u]);
                 if ((int)lane == L) { if (mg) { res = 1; q = e; } else res = 2; }
                 if (mg) break;
             }
@@ -146,8 +151,8 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
         if (ok) {
             const int L = __builtin_ctzll(ok);
             const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)p, L), qq = (uint32_t)__builtin_amdgcn_readlane((int)q, L);
-            const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)io, L); const int v1 = __builtin_amdgcn_readlane(iv, L);
-            const uint32_t o2 = P.ope[qq]; const int v2 = P.val[qq];
+            const uint64_t a1 = P.at[pp], a2 = P.at[qq];
+            const uint32_t o1 = ta_ope(a1), o2 = ta_ope(a2); const int v1 = ta_val(a1), v2 = ta_val(a2);
             uint32_t o = o1; int v; bool noop;
             if (t_as(o1)) {                                   // :96-107
                 v = (o1 == o2) ? v1 + v2 : v1 - v2;
@@ -159,7 +164,7 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
             TW_SYNC();
             t_erase(P, qq, lane);
             if (noop) t_erase(P, pp, lane);
-            else if (lane == 0) { P.ope[pp] = (uint8_t)o; P.val[pp] = (int16_t)v; }
+            else if (lane == 0) P.at[pp] = ta_make((uint32_t)ta_src(a1), ta_des(a1), v, o);
             TW_SYNC();
             return true;
         }
@@ -173,16 +178,18 @@ __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane) {
         uint32_t pos = 0;
         for (;;) {
             const uint32_t n = P.n;
-            const uint32_t f = t_find(pos, n, lane, [&](uint32_t k) { return P.ope[k] != T_BAR && P.src[k] == i; });
+            const uint32_t f = t_find(P, pos, n, lane, [&](uint64_t a) { return ta_ope(a) != T_BAR && ta_src(a) == (int)i; });
             if (f >= n) break;
-            const uint32_t fo = P.ope[f]; const int fd = P.des[f];
+            const uint64_t fa = P.at[f];
+            const uint32_t fo = ta_ope(fa); const int fd = ta_des(fa);
             uint32_t e;
-            if (t_as(fo)) e = t_find(f + 1u, n, lane, [&](uint32_t k) { const int s = P.src[k]; return fd == s || (s == (int)i && (fd == (int)P.des[k] || t_md(P.ope[k]))); });
-            else e = t_find(f + 1u, n, lane, [&](uint32_t k) { return (int)P.des[k] == (int)i || P.src[k] == i; });
+            if (t_as(fo)) e = t_find(P, f + 1u, n, lane, [&](uint64_t a) { const int s = ta_src(a); return fd == s || (s == (int)i && (fd == ta_des(a) || t_md(ta_ope(a)))); });
+            else e = t_find(P, f + 1u, n, lane, [&](uint64_t a) { return ta_des(a) == (int)i || ta_src(a) == (int)i; });
             if (e >= n) { if (f + 1u != n) t_rotate(P, f, n, lane); break; }      // can be moved to the end (:381-391)
+            const uint64_t ea = P.at[e];
             bool rot;
-            if (t_as(fo)) rot = !(fd == (int)P.src[e]) && fd == (int)P.des[e];
-            else rot = !((int)P.des[e] == (int)i) && t_md(P.ope[e]);
+            if (t_as(fo)) rot = !(fd == ta_src(ea)) && fd == ta_des(ea);
+            else rot = !(ta_des(ea) == (int)i) && t_md(ta_ope(ea));
             if (rot && f + 1u != e) t_rotate(P, f, e, lane);
             pos = e + 1u;
         }
@@ -225,17 +232,17 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
             const uint32_t rk = lane - (lane > ai ? 1u : 0u);
             const uint32_t p1 = base + scale + rk, p2 = bar + 1u + rk;
             if (transposed) {                                                                          // :424-427, :444-447
-                P.src[p1] = (uint16_t)c; P.des[p1] = (int16_t)i; P.val[p1] = (int16_t)v; P.ope[p1] = (uint8_t)(av == -1 ? T_ADD : T_SUB);
-                P.src[p2] = (uint16_t)c; P.des[p2] = (int16_t)i; P.val[p2] = (int16_t)v; P.ope[p2] = (uint8_t)(av == -1 ? T_SUB : T_ADD);
+                P.at[p1] = ta_make((uint32_t)c, i, v, av == -1 ? T_ADD : T_SUB);
+                P.at[p2] = ta_make((uint32_t)c, i, v, av == -1 ? T_SUB : T_ADD);
             } else {                                                                                   // :428-431, :448-451
-                P.src[p1] = (uint16_t)i; P.des[p1] = (int16_t)c; P.val[p1] = (int16_t)v; P.ope[p1] = T_ADD;
-                P.src[p2] = (uint16_t)i; P.des[p2] = (int16_t)c; P.val[p2] = (int16_t)v; P.ope[p2] = T_SUB;
+                P.at[p1] = ta_make((uint32_t)i, c, v, T_ADD);
+                P.at[p2] = ta_make((uint32_t)i, c, v, T_SUB);
             }
         }
         if (lane == ai) {
-            if (scale) { P.src[base] = (uint16_t)i; P.des[base] = -1; P.val[base] = (int16_t)av; P.ope[base] = T_MUL; }
-            P.src[bar] = (uint16_t)i; P.des[bar] = -1; P.val[bar] = (int16_t)av; P.ope[bar] = T_BAR;
-            if (scale) { const uint32_t u = bar + len; P.src[u] = (uint16_t)i; P.des[u] = -1; P.val[u] = (int16_t)av; P.ope[u] = T_DIV; }
+            if (scale) P.at[base] = ta_make((uint32_t)i, -1, av, T_MUL);
+            P.at[bar] = ta_make((uint32_t)i, -1, av, T_BAR);
+            if (scale) P.at[bar + len] = ta_make((uint32_t)i, -1, av, T_DIV);
         }
         P.n = base + 2u * scale + 2u * (len - 1u) + 1u;
         if (len > 1u) preci = (uint32_t)i;
@@ -256,7 +263,7 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
     } while (simp);
     uint32_t a = 0, s = 0, mu = 0;                                                                    // :133-144
     for (uint32_t k = lane; k < P.n; k += 64u) {
-        const uint32_t o = P.ope[k]; const int v = P.val[k];
+        const uint64_t at = P.at[k]; const uint32_t o = ta_ope(at); const int v = ta_val(at);
         if (t_as(o)) { ++a; if (v != 1 && v != -1) ++s; }
         if (t_md(o)) ++s;
         if (o == T_BAR) ++mu;
@@ -272,9 +279,9 @@ __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
     uint8_t *reg = tdyn + (size_t)wave * P.lds_per_wave;
     const uint32_t cap = P.cap, m = P.M[0].m;
     TrilProg G;
-    G.src = (uint16_t *)reg; G.des = (int16_t *)(reg + 2u * cap); G.val = (int16_t *)(reg + 4u * cap); G.ope = reg + 6u * cap; G.n = 0;
-    uint16_t *perm = (uint16_t *)(reg + 7u * cap);
-    uint8_t *sgn = reg + 7u * cap + 2u * ((m + 1u) & ~1u);
+    G.at = (uint64_t *)reg; G.n = 0;
+    uint16_t *perm = (uint16_t *)(reg + 8u * cap);
+    uint8_t *sgn = reg + 8u * cap + 2u * ((m + 1u) & ~1u);
     unsigned long long best = ~0ull;
     const uint64_t stride = (uint64_t)gridDim.x * nw;
     for (uint64_t cnd = (uint64_t)blockIdx.x * nw + wave; cnd < J.ncand; cnd += stride) {

@@ -12,5 +12,5 @@ for db in sorted(glob.glob(sys.argv[1] + "/**/*.db", recursive=True)):
     except sqlite3.Error as e:
         print(db, "unreadable:", e); continue
     for k, c, n, s in rows:
-        if "big" in k:
+        if "plo::" in k:
             print("%s,%s,%s,%d,%.6g" % (db.split("/")[-3] if db.count("/") > 2 else db, k.split("(")[0], c, n, s))
