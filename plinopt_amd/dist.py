@@ -80,3 +80,18 @@ def allreduce_best(local, seed0, cost_mode=capi.COST_SUM_THEN_ADD, group=None, d
     if multi:
         dist.all_reduce(ts, op=dist.ReduceOp.MIN, group=group)
     return seed0 + int(ts.item()), best_c
+
+
+def allreduce_tril_best(local, seed0, group=None, device=None):
+    """Same single MIN all-reduce for the in-place trilinear search (`SearchTriLinearAlgorithm`'s critical sections,
+    include/plinopt_inplace.inl:891-921): local = ((ADD, SCA, MUL), seed, variant) or None; order (ADD, SCA, seed, variant).
+    Returns (seed, variant, word) or (None, None, INF)."""
+    pseudo = None
+    if local is not None:
+        (add, sca, _mul), seed, variant = local
+        pseudo = (add, sca, seed0 + (((seed - seed0) << 1) | variant))
+    s, w = allreduce_best(pseudo, seed0, capi.COST_ADD_THEN_MUL, group=group, device=device)
+    if s is None:
+        return None, None, INF
+    off = s - seed0
+    return seed0 + (off >> 1), off & 1, w

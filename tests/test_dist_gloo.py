@@ -35,6 +35,14 @@ s, cnt = shard_range(5, 1, rank, world)
 local = M.search(s, cnt) if cnt else None
 seed, word = allreduce_best(local, 5, 0)
 assert seed == 5
+# the trilplacer restart loop shards the same way: order (ADD, SCA, seed, variant)
+from plinopt_amd.dist import allreduce_tril_best
+from plo_testlib import OracleTril
+T = OracleTril.from_sms(*(os.path.join(DATA, "4x4x4_49_156" + x) for x in ("_L.sms", "_R.sms", "_P.sms")))
+s, cnt = shard_range(40, 151, rank, world)
+seed, variant, word = allreduce_tril_best(T.search(s, cnt) if cnt else None, 40)
+exp = T.search(40, 151)
+assert (seed, variant) == (exp[1], exp[2]), (seed, variant, exp)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
