@@ -70,3 +70,18 @@ def test_config5_cli_end_to_end(hip, l32):
     assert [a, mu] == G["costs"][str(seed)] and seed == 6
     chk = subprocess.run([CHK, "-q", str(P), "-M", sms], input=r.stdout, capture_output=True, text=True, timeout=300)
     assert chk.returncode == 0 and "SUCCESS" in chk.stderr and ("%d,%d" % (a, mu)) in chk.stderr, chk.stderr
+
+
+def test_config5_under_full_load_is_reproducible(hip, l32):
+    """640 candidates = every CU holds two workgroups (plus a second round): the costs do not depend on what else runs
+    on the compute unit (workgroup-scope atomics on a shared L2), and seeds 1..8 still equal the golden values."""
+    from plinopt_amd import CSEPlan
+    _, m, n, rp, c, v = l32
+    G = json.load(open(os.path.join(GOLDEN, "config5_costs.json")))
+    plan = CSEPlan(m, n, rp, c, v, P)
+    a1, m1 = plan.cost_many(seed0=1, n=640)
+    a2, m2 = plan.cost_many(seed0=1, n=640)
+    assert (a1, m1) == (a2, m2)
+    for k in range(8):
+        assert [a1[k], m1[k]] == G["costs"][str(k + 1)], k + 1
+    assert len(set(zip(a1, m1))) > 100          # the restarts do explore different programs
