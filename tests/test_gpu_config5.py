@@ -74,7 +74,7 @@ def test_config5_cli_end_to_end(hip, l32):
 
 def test_config5_under_full_load_is_reproducible(hip, l32):
     """640 candidates = every CU holds two workgroups (plus a second round): the costs do not depend on what else runs
-    on the compute unit (workgroup-scope atomics on a shared L2), and seeds 1..8 still equal the golden values."""
+    on the compute unit (workgroup-scope atomics on a shared L2), and seeds 1..40 still equal the golden values."""
     from plinopt_amd import CSEPlan
     _, m, n, rp, c, v = l32
     G = json.load(open(os.path.join(GOLDEN, "config5_costs.json")))
@@ -82,6 +82,6 @@ def test_config5_under_full_load_is_reproducible(hip, l32):
     a1, m1 = plan.cost_many(seed0=1, n=640)
     a2, m2 = plan.cost_many(seed0=1, n=640)
     assert (a1, m1) == (a2, m2)
-    for k in range(8):
+    for k in range(len(G["costs"])):             # 40 seeds walked by the host engine, each program verified
         assert [a1[k], m1[k]] == G["costs"][str(k + 1)], k + 1
-    assert len(set(zip(a1, m1))) > 100          # the restarts do explore different programs
+    assert len(G["costs"]) >= 40 and len(set(zip(a1, m1))) > 100          # the restarts do explore different programs
