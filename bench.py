@@ -48,8 +48,13 @@ def load_matrix(name):
     fname, p, batch, desc = WORKLOADS[name]
     if fname.endswith(".slp"):
         # data/32x32x32_15096_L.sms is absent upstream; rebuild it from the stored SLP with bin/SLPchecker
+        import fcntl
         import subprocess
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+        host = os.path.join(ROOT, "plinopt_amd", "csrc", "host")
+        with open(os.path.join(host, ".build.lock"), "w") as lk:      # ranks of one node share the tree: build once
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", host])
+            fcntl.flock(lk, fcntl.LOCK_UN)
         out = subprocess.run([os.path.join(ROOT, "bin", "SLPchecker"), "-q", str(p), os.path.join(DATA, fname)],
                              capture_output=True, text=True, check=True).stdout.splitlines()
         m, n = int(out[0].split()[0]), int(out[0].split()[1])
