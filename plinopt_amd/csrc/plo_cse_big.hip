@@ -16,14 +16,24 @@
 //              triples per frequency; cntM[c] counts triples of frequency M whose
 //              first column is c; DM lists the keys that reached M; HL lists keys
 //              with frequency >= theta (a window of levels) so that a level change
-//              re-reads HL instead of the 64 MB table.
+//              re-reads HL instead of the 16 MB table.
 //   tie pick   prefix over cntM -> first column; the few DM keys of that column
 //              are sorted in LDS -> k-th tie in map order (OneSub :244-265).
 //   rows(a)    row lists per column (static transpose for input columns, an
 //              append-only pool for created columns, stale entries filtered);
 //              +-1 counts per column kept incrementally (RemOneCSE :70-77).
-// The work per candidate is ~2.5e8 pair retirements + 1.2e8 pair insertions,
-// each one random 8-byte atomic in a 64 MB table: HBM-latency bound.
+//   aggregate  the rows rewritten by one step retire/create the same triples ~21
+//              times: an LDS table of 2^13 (column, ratio) entries sums them per
+//              sweep; both retirements of an entry (its pair with a and with b)
+//              share one LDS entry because v_b = r v_a in every affected row; the
+//              flush walks a list of claimed slots and does one table atomic per
+//              distinct triple.
+//   scope      a candidate never leaves its workgroup: all atomics, atomic loads
+//              and fences on its workspace are WORKGROUP scope, so the XCD's L2
+//              serves them (agent scope = memory side of the fabric on a part whose
+//              XCD L2s are not coherent with each other: 2.3x slower).
+// The work per candidate is ~2.5e8 pair retirements + 1.2e8 pair insertions; the
+// kernel is bound by the latency of dependent LDS/HBM accesses at 16 waves per CU.
 // ===========================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
