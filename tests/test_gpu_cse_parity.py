@@ -65,3 +65,16 @@ def test_capacity_error_is_loud(hip):
     with pytest.raises(capi.PloError) as e:
         _plan(M)
     assert e.value.code == capi.PLO_E_CAPACITY
+
+
+@pytest.mark.parametrize("name,nseeds", [("2x2x2_7_Winograd_L.sms", 100000), ("cyclic.sms", 30000), ("4x4x4_49_156_L.sms", 12000),
+                                         ("4x4x4_49_156_R.sms", 12000), ("4x4x4_49_156_P.sms", 10000)])
+def test_ten_thousand_seeds_per_baseline_config(hip, name, nseeds):
+    """SURVEY 8c parity definition (A): all cost components equal for >= 10^4 seeds on every BASELINE config
+    that the oracle can walk; (B): the same argmin over the whole range."""
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    plan = _plan(M)
+    ga, gm = plan.cost_many(seed0=10 ** 9, n=nseeds)
+    oa, om = M.cost_many(seed0=10 ** 9, nseeds=nseeds, nthreads=16)
+    assert ga == oa and gm == om
+    assert plan.search(10 ** 9, nseeds) == M.search(10 ** 9, nseeds, nthreads=16)

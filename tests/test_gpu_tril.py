@@ -61,3 +61,11 @@ def test_non_unit_inputs_are_refused(hip):
     with pytest.raises(capi.PloError) as e:
         TrilPlan(2, [(2, [0, 1, 2], [0, 1], [1, 2]), (2, [0, 1, 2], [0, 1], [1, 1]), (2, [0, 1, 2], [0, 1], [1, 1])])
     assert e.value.code == capi.PLO_E_UNSUPPORTED
+
+
+def test_ten_thousand_seeds_on_config4(hip):
+    """BASELINE configs[3] (4x4x4_49_156 L, R, P): 10^4 restarts, all six counts per restart and the argmin."""
+    O, G = plans("4x4x4_49_156")
+    n = 10000
+    assert G.cost_many(seed0=2 * 10 ** 9, n=n) == O.cost_many(seed0=2 * 10 ** 9, nseeds=n)
+    assert G.search(2 * 10 ** 9, n) == O.search(2 * 10 ** 9, n)
