@@ -268,7 +268,7 @@ __device__ __forceinline__ int row_find(const uint32_t *col, uint32_t base, uint
 
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
-    uint32_t a, b, r, aggn, aggn2; uint64_t kprime; uint64_t selkey;
+    uint32_t a, b, r, aggn, nspill; uint64_t kprime; uint64_t selkey;
     uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
 #ifdef PLO_BIG_PROFILE
@@ -293,6 +293,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
     uint64_t *DM    = (uint64_t *)(ws + P.o_dm), *HL = (uint64_t *)(ws + P.o_hl);
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
     uint16_t *agglist = (uint16_t *)sh.sel;       // slots claimed in the aggregation table by the running sweep
+    uint64_t *spill = (uint64_t *)(ws + P.o_tlist); const uint32_t spillcap = (P.nnz + 64u) / 2u;   // new-column pairs of entries that found no room in LDS (ProgramGen's list area is idle here)
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
     const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
     const uint64_t mu = P.mu, cap = 1ull << P.hbits;
@@ -472,7 +473,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         // ---- RemOneCSE :60-194
         const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
-        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.aggn2 = 0; }
+        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; }
         BSYNC();
         {   // rows holding the triple: walk the shorter row list of the two columns
             const uint32_t *la, *lb; uint32_t na, nb;
@@ -499,7 +500,8 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         const uint32_t naff = sh.naff;
         PLO_STAMP(2);
         if (naff != M) { if (tid == 0) wg_max(&sh.errflag, (uint32_t)BERR_FREQ); BSYNC(); break; }   // frequency must equal the row count
-        // sweep 1: retire the old pairs of the affected rows (:115-118).  In every affected row v_b = r v_a, so the two
+        // The sweep over the affected rows: rewrite each row (:96-110) and retire its old pairs (:115-118) in one pass over
+        // its entries.  In every affected row v_b = r v_a, so the two
         // pairs an entry (c, v) forms with a and with b are functions of (c, x), x = v_a/v (c < a) or v/v_a (c > a): the
         // pair with a has ratio x, the pair with b has ratio r x (c < a), r/x (a < c < b) or x/r (b < c).  One LDS entry
         // per (c, x) therefore carries both retirements; the flush derives the two table keys.
@@ -520,6 +522,9 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (!o2) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
                 wg_sub(&hist[o2], 1u); if (o2 > 1u) wg_add(&hist[o2 - 1u], 1u);
                 if (o2 == M) { wg_sub(&cntM[c < b ? c : b], 1u); wg_sub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
+                // its pair with the new column is inserted after all retirements (flush, second pass)
+                const uint32_t idx = wg_add(&sh.nspill, 1u);
+                if (idx < spillcap) spill[idx] = BKEY(c, lm, bmul(l0 == a ? va : vb, iv, p, mu, mers)); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
             };
             // two rows per wave and trip: both records, then the first 64 entries of both rows, are in flight together
             for (uint32_t q = wave; q < naff; q += 2u * nwaves) {
@@ -536,14 +541,39 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 if (lane < LB) { cB = col[baseB + lane]; vB = val[baseB + lane]; iB = inv[baseB + lane]; }
                 const uint32_t Lmax = LA > LB ? LA : LB;
                 for (uint32_t z0 = 0; z0 < Lmax; z0 += 64u) {
-                    // the next 64 entries of both rows are requested before this chunk is worked on
+                    // the next 64 entries of both rows are requested before this chunk is worked on (and before it is
+                    // stored: the stores reach back at most two positions, never into the next chunk)
                     const uint32_t z = z0 + lane, zn = z + 64u;
                     uint32_t ncA = 0, nvA = 0, niA = 0, ncB = 0, nvB = 0, niB = 0;
                     if (zn < LA) { ncA = col[baseA + zn]; nvA = val[baseA + zn]; niA = inv[baseA + zn]; }
                     if (zn < LB) { ncB = col[baseB + zn]; nvB = val[baseB + zn]; niB = inv[baseB + zn]; }
-                    if (z < LA && z != paA && z != pbA) retire_entry(cA, vA, iA, A0.z, A0.w, A1.x, A1.y);
-                    if (z < LB && z != paB && z != pbB) retire_entry(cB, vB, iB, B0.z, B0.w, B1.x, B1.y);
+                    __builtin_amdgcn_wave_barrier();
+                    const bool actA = z < LA && z != paA && z != pbA, actB = z < LB && z != paB && z != pbB;
+                    // the row is rewritten in the same pass (:96-110): entries shift left over the two removed positions
+                    if (actA) { const uint32_t np = baseA + z - (z > paA ? 1u : 0u) - (z > pbA ? 1u : 0u); col[np] = cA; val[np] = vA; inv[np] = iA; }
+                    if (actB) { const uint32_t np = baseB + z - (z > paB ? 1u : 0u) - (z > pbB ? 1u : 0u); col[np] = cB; val[np] = vB; inv[np] = iB; }
+                    if (actA) retire_entry(cA, vA, iA, A0.z, A0.w, A1.x, A1.y);
+                    if (actB) retire_entry(cB, vB, iB, B0.z, B0.w, B1.x, B1.y);
+                    __builtin_amdgcn_wave_barrier();
                     cA = ncA; vA = nvA; iA = niA; cB = ncB; vB = nvB; iB = niB;
+                }
+                if (lane == 0) {                       // the new column's entry goes last
+                    {
+                        const uint32_t coeff = (l0 == a) ? A0.z : A1.x, icoeff = (l0 == a) ? A0.w : A1.y;
+                        col[baseA + LA - 2u] = lm; val[baseA + LA - 2u] = coeff; inv[baseA + LA - 2u] = icoeff;
+                        len[A0.x] = LA - 1u;
+                        if (babsone(A0.z, p)) wg_sub(&ucount[a], 1u);
+                        if (babsone(A1.x, p)) wg_sub(&ucount[b], 1u);
+                        if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
+                    }
+                    if (LB) {
+                        const uint32_t coeff = (l0 == a) ? B0.z : B1.x, icoeff = (l0 == a) ? B0.w : B1.y;
+                        col[baseB + LB - 2u] = lm; val[baseB + LB - 2u] = coeff; inv[baseB + LB - 2u] = icoeff;
+                        len[B0.x] = LB - 1u;
+                        if (babsone(B0.z, p)) wg_sub(&ucount[a], 1u);
+                        if (babsone(B1.x, p)) wg_sub(&ucount[b], 1u);
+                        if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
+                    }
                 }
             }
         }
@@ -552,7 +582,10 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         if (tid == 0) { const int cl = M >= 256u ? 0 : M >= 64u ? 1 : M >= 16u ? 2 : 3; sh.tb1[cl] += wall_clock64() - tstamp; ++sh.nb[cl]; }
 #endif
         PLO_STAMP(3);
-        // flush the summed retirements: one global atomic per distinct triple; the triple itself loses all its M instances
+        // Flush, first pass: the summed retirements, one table atomic per distinct triple; the triple itself loses all its M
+        // instances.  The pair an entry forms with the NEW column has the same multiplicity as its retirements and its
+        // ratio coeff/v_c is a function of (c, x) as well (x or 1/x, times r when coeff = v_b): the entry is rewritten in
+        // place to (c, that ratio) and the second pass inserts it -- the rows are not hashed a second time.
         {
             const uint32_t invr = sh.invr;
             auto retire = [&](uint64_t k, uint32_t d) {
@@ -567,111 +600,62 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
                 const uint64_t v = agg[s];
                 if (v == PLO_GEMPTY) continue;
-                agg[s] = PLO_GEMPTY;
                 const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
                 const uint32_t c = (uint32_t)(k >> rb), x = (uint32_t)(k & ((1ull << rb) - 1ull));
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fl1, 1u);
 #endif
-                const uint32_t y = (c > a && c < b) ? binv(x, p, mu, mers) : x;
-                const uint32_t x2 = bmul(y, c < b ? r : invr, p, mu, mers);
+                const uint32_t y = c > a ? binv(x, p, mu, mers) : x;               // v_a / v_c
+                const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
+                const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
                 retire(c < a ? BKEY(c, a, x) : BKEY(a, c, x), d);
                 retire(c < b ? BKEY(c, b, x2) : BKEY(b, c, x2), d);
+                agg[s] = (((((uint64_t)c) << rb) | (l0 == a ? y : ry)) << PLO_GVB) | d;    // (c, coeff / v_c), same count
             }
         }
         PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(4);
         if (sh.errflag) break;
-        // sweep 2: rewrite the rows, insert the pairs with the new column (:96-110, :132-142)
+        // Flush, second pass: the insertions (:132-142), after every retirement (dead-slot reuse needs that order)
         {
-            auto insert_entry = [&](uint32_t c, uint32_t iv, uint32_t coeff) {
-                const uint32_t x = bmul(coeff, iv, p, mu, mers);
-                if (agg_add(agg, aggbits, ((uint64_t)c << rb) | x, &sh.aggn2, agglist)) return;   // the new column is implied
-                const uint64_t nk = BKEY(c, lm, x);
-#ifdef PLO_BIG_PROFILE
-                wg_add(&sh.fb2, 1u);
-#endif
-                const uint32_t nc = gtab_inc(tab, nk, hbits);
-                if (!nc) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
-                if (nc > P.maxf0) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); return; }
-                if (nc > 1u) wg_sub(&hist[nc - 1u], 1u);
+            auto inserted = [&](uint64_t k, uint32_t o, uint32_t d) {
+                const uint32_t nc = o + d;
+                if (nc > P.maxf0 || nc > M) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); return; }
+                if (o > 0u) wg_sub(&hist[o], 1u);
                 wg_add(&hist[nc], 1u);
-                if (nc == sh.theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = nk; else sh.hlbad = 1u; }
+                if (o < sh.theta && nc >= sh.theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = k; else sh.hlbad = 1u; }
                 if (nc == M) {
-                    wg_add(&cntM[c], 1u); wg_add(&sh.cblk[c >> 6], 1u);
+                    wg_add(&cntM[(uint32_t)(k >> abits)], 1u); wg_add(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u);
                     uint32_t idx = wg_add(&sh.dmcount, 1u);
-                    if (idx < P.dmcap) DM[idx] = nk; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
+                    if (idx < P.dmcap) DM[idx] = k; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
                 }
             };
-            // one row: entries shift left over the two removed positions (first chunk preloaded by the caller), the new
-            // column's entry goes last; all loads of a chunk complete before its stores
-            auto rewrite_row = [&](const uint4 R0, const uint4 R1, uint32_t c, uint32_t v, uint32_t iv) {
-                const uint32_t i = R0.x, pa = R0.y & 0xFFFFu, pb = R0.y >> 16, base = R1.z, L = R1.w;
-                const uint32_t coeff = (l0 == a) ? R0.z : R1.x, icoeff = (l0 == a) ? R0.w : R1.y;
-                for (uint32_t z0 = 0; z0 < L; z0 += 64u) {
-                    const uint32_t z = z0 + lane, zn = z + 64u; const bool have = z < L;
-                    uint32_t nc = 0, nv = 0, niv = 0;                 // the next chunk is read before this one is stored: the stores
-                    if (zn < L) { nc = col[base + zn]; nv = val[base + zn]; niv = inv[base + zn]; }   // reach back at most two positions
-                    __builtin_amdgcn_wave_barrier();
-                    if (have && z != pa && z != pb) {
-                        const uint32_t np = base + z - (z > pa ? 1u : 0u) - (z > pb ? 1u : 0u);
-                        col[np] = c; val[np] = v; inv[np] = iv;
-                        insert_entry(c, iv, coeff);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    c = nc; v = nv; iv = niv;
-                }
-                if (lane == 0) {
-                    col[base + L - 2u] = lm; val[base + L - 2u] = coeff; inv[base + L - 2u] = icoeff;
-                    len[i] = L - 1u;
-                    if (babsone(R0.z, p)) wg_sub(&ucount[a], 1u);
-                    if (babsone(R1.x, p)) wg_sub(&ucount[b], 1u);
-                    if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
-                }
-            };
-            for (uint32_t q = wave; q < naff; q += 2u * nwaves) {
-                const uint32_t q2 = q + nwaves;
-                const uint4 A0 = *(const uint4 *)(aff + 8u * q), A1 = *(const uint4 *)(aff + 8u * q + 4u);
-                uint4 B0 = A0, B1 = A1;
-                if (q2 < naff) { B0 = *(const uint4 *)(aff + 8u * q2); B1 = *(const uint4 *)(aff + 8u * q2 + 4u); }
-                uint32_t cA = 0, vA = 0, iA = 0, cB = 0, vB = 0, iB = 0;
-                if (lane < A1.w) { cA = col[A1.z + lane]; vA = val[A1.z + lane]; iA = inv[A1.z + lane]; }
-                if (q2 < naff && lane < B1.w) { cB = col[B1.z + lane]; vB = val[B1.z + lane]; iB = inv[B1.z + lane]; }
-                rewrite_row(A0, A1, cA, vA, iA);
-                if (q2 < naff) rewrite_row(B0, B1, cB, vB, iB);
+            const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
+            for (uint32_t e = tid; e < nslot; e += nth) {
+                const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
+                const uint64_t v = agg[s];
+                if (v == PLO_GEMPTY) continue;
+                agg[s] = PLO_GEMPTY;
+                const uint64_t kc = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+                const uint64_t k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
+                const uint32_t o = gtab_addn(tab, k, d, hbits);
+#ifdef PLO_BIG_PROFILE
+                wg_add(&sh.fl2, 1u);
+#endif
+                if (o == 0xFFFFFFFFu) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                inserted(k, o, d);
             }
-        }
-        BSYNC();
-#ifdef PLO_BIG_PROFILE
-        if (tid == 0) { const int cl = M >= 256u ? 0 : M >= 64u ? 1 : M >= 16u ? 2 : 3; sh.tb2[cl] += wall_clock64() - tstamp; }
-#endif
-        PLO_STAMP(5);
-        // flush the summed insertions
-        const uint32_t nent2 = sh.aggn2, nslot2 = nent2 <= PLO_AGG_LIST ? nent2 : (1u << aggbits);
-        for (uint32_t e = tid; e < nslot2; e += nth) {
-            const uint32_t s = nent2 <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
-            const uint64_t v = agg[s];
-            if (v == PLO_GEMPTY) continue;
-            agg[s] = PLO_GEMPTY;
-            const uint64_t kc = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
-            const uint64_t k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
-            const uint32_t o = gtab_addn(tab, k, d, hbits);
-#ifdef PLO_BIG_PROFILE
-            wg_add(&sh.fl2, 1u);
-#endif
-            if (o == 0xFFFFFFFFu) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-            const uint32_t nc = o + d;
-            if (nc > P.maxf0 || nc > M) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
-            if (o > 0u) wg_sub(&hist[o], 1u);
-            wg_add(&hist[nc], 1u);
-            if (o < sh.theta && nc >= sh.theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = k; else sh.hlbad = 1u; }
-            if (nc == M) {
-                wg_add(&cntM[(uint32_t)(k >> abits)], 1u); wg_add(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u);
-                uint32_t idx = wg_add(&sh.dmcount, 1u);
-                if (idx < P.dmcap) DM[idx] = k; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
+            const uint32_t nsp = sh.nspill < spillcap ? sh.nspill : spillcap;      // entries that found no room in the LDS table
+            for (uint32_t e = tid; e < nsp; e += nth) {
+                const uint64_t k = spill[e];
+                const uint32_t o = gtab_addn(tab, k, 1u, hbits);
+                if (o == 0xFFFFFFFFu) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                inserted(k, o, 1u);
             }
         }
         PLO_STAMP(6);
+        BSYNC();
+        PLO_STAMP(5);
         // row list of the new column, multiplier reuse (:153-169), counters
         {
             const uint32_t o = ncrptr[lm - n];
