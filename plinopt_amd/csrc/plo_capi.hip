@@ -294,7 +294,7 @@ int build_big_plan(plo_plan *pl)
 int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
 {
     // one workspace slice per resident workgroup
-    uint64_t per_cu = 4;
+    uint64_t per_cu = 2;                  // = the resident workgroups (LDS-limited); more slices only enlarge the footprint
     if (const char *e = getenv("PLO_BIG_WG_PER_CU")) per_cu = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
     uint64_t want = std::min<uint64_t>(J.ncand, (uint64_t)g_cus * per_cu);
     if (const char *e = getenv("PLO_BIG_SLICES")) want = std::min<uint64_t>(want, strtoull(e, nullptr, 10));
@@ -331,6 +331,7 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
             fprintf(stderr, "# big kernel (last candidate): steps %u, full scans %u, level rebuilds %u; phase us: level %u select %u rows %u sweep1 %u flush1 %u sweep2 %u flush2 %u tail %u\n",
                     hs[0], hs[1], hs[2], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11]);
 #ifdef PLO_BIG_PROFILE
+            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[11]) fprintf(stderr, "#   flush 1, thread 0 of every workgroup, cycles per entry (%llu entries): inverse+products %.0f, retire 1 %.0f, retire 2 %.0f\n", gp[11], (double)gp[8] / gp[11], (double)gp[9] / gp[11], (double)gp[10] / gp[11]); }
             fprintf(stderr, "#   steps by rows/step [>=256, 64.., 16.., <16]: %u %u %u %u; sweep1 us %u %u %u %u; sweep2 us %u %u %u %u; fallbacks %u %u; flushed keys %u %u\n",
                     hs[24], hs[25], hs[26], hs[27], hs[16], hs[17], hs[18], hs[19], hs[20], hs[21], hs[22], hs[23], hs[28], hs[29], hs[30], hs[31]);
 #endif
