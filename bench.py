@@ -353,8 +353,8 @@ def main():
         except Exception:
             pass
         if plan.is_hbm:
-            out["roofline"]["note"] = ("candidate state (16 MB pair table + rows + lists, 165 MB workspace) is HBM-resident; waves wait 79 % of "
-                                       "their cycles on dependent LDS/HBM accesses, measured HBM traffic is 2.3 TB/s (rocprofv3 PMC, profiles/r01g_*): "
+            out["roofline"]["note"] = ("candidate state (16 MB pair table + rows + lists, 165 MB workspace) is HBM-resident; waves wait 80 % of "
+                                       "their cycles on dependent LDS/HBM accesses, measured HBM traffic is 2.5 TB/s (rocprofv3 PMC, profiles/r01j_*): "
                                        "latency-bound, not bandwidth-bound (DESIGN.md 6)")
             out["kernel"]["family"] = "plo::cse_big_kernel (one workgroup per candidate)"
             out["roofline"]["kernel"] = "plo::cse_big_kernel"
