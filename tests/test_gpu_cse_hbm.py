@@ -88,3 +88,13 @@ def test_general_matrix_with_many_rows_goes_to_hbm_family(hip):
     assert plan.is_hbm
     assert plan.cost_many(seed0=3, n=12) == tuple(M.cost_many(seed0=3, nseeds=12, nthreads=8))
     assert plan.search(3, 12) == M.search(3, 12, nthreads=8)
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_P.sms", "4x4x4_48_rational_P.sms", "3x4x7_63_rational_R.sms"])
+def test_tiny_aggregation_table_takes_the_spill_path(hip, name, monkeypatch):
+    """A 64-entry LDS aggregation table overflows at almost every step: entries then retire in HBM directly and their
+    pair with the new column waits in the spill list for the flush's second pass.  Same costs as the oracle."""
+    monkeypatch.setenv("PLO_BIG_AGGBITS", "6")
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    plan = _plan(M)
+    assert plan.cost_many(seed0=11, n=150) == tuple(M.cost_many(seed0=11, nseeds=150, nthreads=8))
