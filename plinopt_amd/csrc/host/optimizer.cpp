@@ -155,6 +155,57 @@ template <class F> bool lu_method(const F &f, const SparseMat<typename F::Elt> &
     return true;
 }
 
+// program text of the alternative-factorization method for one seed (include/plinopt_optimize.inl:1142-1153)
+template <class F> std::string ab_text(const F &f, const ABFactors<F> &ab, uint64_t seed, Ops &ops) {
+    std::ostringstream os;
+    input2temps(os, ab.CoB, 'i', 't');                                                                      // :1146
+    CandRng rng(seed);
+    Replay<F> RC(f, ab.CoB, rng, os, 'v', 't', 'r'); Ops bo = RC.optimizer();                               // :1150
+    Replay<F> RA(f, ab.Alt, rng, os, 'o', 'v', 'g'); Ops ao = RA.optimizer();                               // :1153
+    ops = {bo.first + ao.first, bo.second + ao.second};
+    return os.str();
+}
+
+// ABOptimiser :1114-1186 for the inner dimension coldim(M).  Returns false when the method could not run.
+template <class F> bool ab_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
+                                  int verbose, Ops &gops, std::string &gtext, const char *argv0) {
+    if (lM.rowdim() < lM.coldim()) { std::clog << "# -A skipped: fewer rows than columns" << std::endl; return false; }
+    const ABFactors<F> ab = ab_factorize(f, lM, 1 + (loops >> 3), seed0);                                   // :1129-1130
+    uint64_t seed = 0; Ops best; bool have = false;
+    if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+        HipLib L;
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -A: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        std::vector<uint32_t> rp1, c1, v1, rp2, c2, v2;
+        to_csr(ab.CoB, rp1, c1, v1); to_csr(ab.Alt, rp2, c2, v2);
+        plo_csr_t A{(uint32_t)ab.CoB.rowdim(), (uint32_t)ab.CoB.coldim(), rp1.data(), c1.data(), v1.data()};
+        plo_csr_t B{(uint32_t)ab.Alt.rowdim(), (uint32_t)ab.Alt.coldim(), rp2.data(), c2.data(), v2.data()};
+        plo_chain_t *ch = nullptr;
+        int rc = L.chain_create(&A, &B, q, &ch);
+        if (rc != PLO_OK) { std::clog << "# -A skipped: " << L.last_error() << std::endl; return false; }
+        plo_best_t b{}; plo_stats_t st{};
+        rc = L.chain_search(ch, seed0, loops, PLO_COST_SUM_THEN_ADD, &b, &st);
+        L.chain_destroy(ch);
+        if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: -A GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
+        best = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
+        if (verbose > 0) std::clog << "# GPU (A): " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms" << std::endl;
+    }
+    if (!have) {
+#pragma omp parallel for schedule(dynamic)
+        for (long long k = 0; k < (long long)loops; ++k) {
+            Ops ops; (void)ab_text(f, ab, seed0 + (uint64_t)k, ops);
+#pragma omp critical
+            { uint64_t s = seed0 + (uint64_t)k; if (!have || cmp_op_count(ops, best) || (!cmp_op_count(best, ops) && s < seed)) { best = ops; seed = s; have = true; } }
+        }
+    }
+    if (!have) return false;
+    Ops rops; std::string t = ab_text(f, ab, seed, rops);
+    if (rops != best) { std::cerr << "# \033[1;31mERROR: -A replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (verbose > 0) std::clog << "# Found A: (" << ab.Alt.rowdim() << 'x' << ab.Alt.coldim() << 'x' << ab.CoB.coldim() << ' ' << ab.score[0] << '/' << ab.score[2] << ")\t"
+                               << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed << ']' << std::endl;
+    if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                               // :1180-1184
+    return true;
+}
+
 template <class F>
 int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool tryDirect, bool tryKernel, bool tryLU,
         bool tryAB, bool mostCSE, bool allkernels, int verbose, uint32_t q, const char *argv0)
@@ -165,7 +216,10 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
     auto lM = rebind(MQ, f);
     Ops nbops = opsinit; std::string text;
 
-    if (tryAB) std::clog << "# -A (alternative factorization) is not part of this build (SURVEY.md 8f)" << std::endl;
+    if (tryAB) {                                                                      // :1436-1440 (inner dimension = column count)
+        try { ab_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
+        catch (const std::exception &e) { std::clog << "# -A skipped: " << e.what() << std::endl; }
+    }
     if (tryDirect) {
         Ops dops; uint64_t seed = 0; bool have = false;
         bool on_gpu = false;
@@ -236,7 +290,7 @@ int main(int argc, char **argv)
 {
     bool printMaple = false, printPretty = false, mostCSE = false, tryKernel = false, tryLU = false, tryAB = false,
          tryDirect = false, allkernels = false;
-    int verbose = 1, gpu = 1; size_t loops = 100; uint64_t q = 0, seed0 = 0; std::string filename; bool replay_only = false;
+    int verbose = 1, gpu = 1; size_t loops = 100; uint64_t q = 0, seed0 = 0; std::string filename, only; bool replay_only = false;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
         if (a == "-h") {
@@ -245,7 +299,9 @@ int main(int argc, char **argv)
                       << "  -q #: search modulo (default is Rationals, on the host)\n"
                       << "  -O #: randomized search with that many loops (default " << loops << " loops)\n"
                       << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only\n"
-                      << "  --seed #: first candidate seed (default 0)\n";
+                      << "  --seed #: first candidate seed (default 0)\n"
+                      << "  -A: also try the alternative factorization M = Alt.CoB (inner dimension = column count)\n"
+                      << "  --only D|G|A: run exactly that method\n";
             exit(-1);
         } else if (a == "-M") printMaple = true;
         else if (a == "-P") printPretty = true;
@@ -263,9 +319,11 @@ int main(int argc, char **argv)
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
         else if (a == "--engine" && i + 1 < argc) { std::string e(argv[++i]); g_engine = e == "literal" ? 1 : e == "fast" ? 2 : 0; }
         else if (a == "--replay") replay_only = true;    // print the program of candidate --seed, no search
+        else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing
         else filename = a;
     }
-    if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
+    if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = false; }
+    else if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
     (void)printMaple; (void)printPretty;
     try {
         QMat MQ;

@@ -14,6 +14,7 @@
 #define PLO_HOST_HPP
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstdlib>
 #include <fstream>
@@ -603,6 +604,87 @@ template <class F> LUFactors<F> sparse_lu(const F &f, const SparseMat<typename F
         if (usedr[i]) row.emplace_back(pos[i], f.one());
     }
     return R;
+}
+
+// --------------------------------------------------------------------- -A: M = Alt . CoB
+// backSolver / Factorizer (reference include/plinopt_sparsify.inl:756-867, :924-984) for the inner dimension
+// k = coldim(M) (ABOptimiser's first value, plinopt_optimize.inl:1437-1439): a random order of the rows (the build's
+// per-candidate stream; the reference uses LinBox's Permutation::random), the first n independent rows in that order
+// become CoB (n x n, invertible), Alt = M . CoB^{-1} (the chosen rows are unit rows).  Larger inner dimensions need an
+// underdetermined solve whose particular solution is LinBox's (unpinned): not built.
+template <class F> struct ABFactors {
+    SparseMat<typename F::Elt> Alt, CoB;
+    std::array<size_t, 3> score{0, 0, 0};     // nnz(Alt), non +-1 entries of Alt, nnz(CoB): tricOpCount :911-920
+    bool identity = false;
+};
+template <class F> bool ab_backsolve(const F &f, const SparseMat<typename F::Elt> &M, uint64_t seed, ABFactors<F> &out) {
+    using E = typename F::Elt;
+    const size_t m = M.rowdim(), n = M.coldim();
+    std::vector<size_t> ord(m);
+    for (size_t i = 0; i < m; ++i) ord[i] = i;
+    CandRng rng(seed);
+    for (size_t i = m; i > 1; --i) std::swap(ord[i - 1], ord[rng.next() % (uint32_t)i]);
+    // greedy row basis in that order; E keeps the echelon rows together with the combination of basis rows they are
+    std::vector<std::vector<E>> ech, comb; std::vector<size_t> piv, chosen;
+    auto dense_row = [&](size_t r) { std::vector<E> v(n, f.zero()); for (auto &e : M.rows[r]) v[e.first] = e.second; return v; };
+    for (size_t t = 0; t < m && chosen.size() < n; ++t) {
+        std::vector<E> v = dense_row(ord[t]), c(n, f.zero());
+        for (size_t k = 0; k < ech.size(); ++k) {
+            const E x = v[piv[k]];
+            if (f.isZero(x)) continue;
+            for (size_t j = 0; j < n; ++j) v[j] = f.add(v[j], f.neg(f.mul(x, ech[k][j])));
+            for (size_t j = 0; j < n; ++j) c[j] = f.add(c[j], f.neg(f.mul(x, comb[k][j])));
+        }
+        size_t pc = n;
+        for (size_t j = 0; j < n; ++j) if (!f.isZero(v[j])) { pc = j; break; }
+        if (pc == n) continue;                                   // dependent on the rows chosen so far
+        const E iv = f.inv(v[pc]);
+        c[chosen.size()] = f.add(c[chosen.size()], f.one());     // this row itself is basis row number |chosen|
+        for (size_t j = 0; j < n; ++j) { v[j] = f.mul(v[j], iv); c[j] = f.mul(c[j], iv); }
+        ech.push_back(v); comb.push_back(c); piv.push_back(pc); chosen.push_back(ord[t]);
+    }
+    if (chosen.size() < n) return false;                         // rank < n: no square change of basis
+    // x . CoB = row  <=>  reduce the row with the echelon rows, accumulating the combination of basis rows
+    out.CoB = SparseMat<E>(n, n); out.Alt = SparseMat<E>(m, n);
+    for (size_t k = 0; k < n; ++k) out.CoB.rows[k] = M.rows[chosen[k]];
+    for (size_t i = 0; i < m; ++i) {
+        std::vector<E> v = dense_row(i), x(n, f.zero());
+        for (size_t k = 0; k < n; ++k) {
+            const E y = v[piv[k]];
+            if (f.isZero(y)) continue;
+            for (size_t j = 0; j < n; ++j) v[j] = f.add(v[j], f.neg(f.mul(y, ech[k][j])));
+            for (size_t j = 0; j < n; ++j) x[j] = f.add(x[j], f.mul(y, comb[k][j]));
+        }
+        for (size_t j = 0; j < n; ++j) if (!f.isZero(v[j])) return false;      // cannot happen at full column rank
+        for (size_t j = 0; j < n; ++j) if (!f.isZero(x[j])) out.Alt.rows[i].emplace_back(j, x[j]);
+    }
+    size_t nz = 0, nu = 0, nc = 0;
+    for (auto &r : out.Alt.rows) for (auto &e : r) { ++nz; if (!absOne(f, e.second)) ++nu; }
+    for (auto &r : out.CoB.rows) nc += r.size();
+    out.score = {nz, nu, nc};
+    return true;
+}
+// Factorizer :924-984: best of `loops` back-solves (seeds seed0 ...), starting from (Alt, CoB) = (M, identity)
+template <class F> ABFactors<F> ab_factorize(const F &f, const SparseMat<typename F::Elt> &M, size_t loops, uint64_t seed0) {
+    using E = typename F::Elt;
+    const size_t m = M.rowdim(), n = M.coldim();
+    ABFactors<F> best;
+    if (m == n) {                                                // :945-951 identity factorization
+        best.CoB = M; best.Alt = SparseMat<E>(m, n); best.identity = true;
+        for (size_t i = 0; i < m; ++i) best.Alt.rows[i].emplace_back(i, f.one());
+        return best;
+    }
+    best.Alt = M; best.CoB = SparseMat<E>(n, n);
+    for (size_t i = 0; i < n; ++i) best.CoB.rows[i].emplace_back(i, f.one());
+    size_t nz = 0, nu = 0;
+    for (auto &r : M.rows) for (auto &e : r) { ++nz; if (!absOne(f, e.second)) ++nu; }
+    best.score = {nz, nu, n};
+    for (size_t i = 0; i < loops; ++i) {                         // sequential: ties go to the smaller seed
+        ABFactors<F> c;
+        if (m < n || !ab_backsolve(f, M, seed0 + i, c)) continue;
+        if (c.score < best.score) best = c;
+    }
+    return best;
 }
 
 // cmpOpCount, include/plinopt_optimize.h:53-64 (mode 0 default, 1 OPTIMIZE_ADDITIONS, 2 OPTIMIZE_SUMS)

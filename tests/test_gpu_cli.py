@@ -88,3 +88,20 @@ def test_trilplacer_cli_on_gpu():
     got = tuple(int(x) for x in re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", r.stderr))
     assert got == want, (got, want, r.stderr)
     check_program(T, r.stdout, want, random.Random(5))
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms"])
+def test_ab_method_on_gpu_equals_host_search(name):
+    """-A: the factorization M = Alt.CoB is made on the host, the restart loop (Optimizer on CoB, then on Alt, one
+    stream) runs on the GPU through the chained-candidate kernel; same winner and program as the host loop."""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "A", "-O", "3000", path])
+    assert rc == 0, err
+    rc0, out0, err0 = run([OPT, "-q", str(P), "--only", "A", "-O", "3000", "--gpu", "0", path])
+    assert rc0 == 0, err0
+    pat = r"# Found A: \(\d+x\d+x\d+ \d+/\d+\)\t(\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\]"
+    g, g0 = re.search(pat, err), re.search(pat, err0)
+    assert g and g0 and g.groups() == g0.groups(), (err, err0)
+    assert "# GPU (A):" in err and out == out0
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2

@@ -219,3 +219,23 @@ def test_trilplacer_host_search_equals_oracle_and_program_runs_in_place(name):
     got = tuple(int(x) for x in re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", r.stderr))
     assert got == want, (got, want, r.stderr)
     check_program(T, r.stdout, want, random.Random(11))
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "4x4x4_49_156_L.sms", "4x4x4_49_156_R.sms", "3x3x6_40_L.sms",
+                                  "4x4x4_48_rational_L.sms", "2x2x2_7_DPS-accurate_L.sms", "cyclic.sms"])
+@pytest.mark.parametrize("field", ["Q", "p"])
+def test_ab_method_programs_verify(name, field):
+    """-A (ABOptimiser, plinopt_optimize.inl:1114-1186, inner dimension = column count): M = Alt.CoB by the back-solver
+    with a random row order, then Optimizer on CoB and on Alt with one random stream; `--only A` prints that program,
+    which must compute the matrix with exactly the reported operation count."""
+    path = os.path.join(DATA, name)
+    q = ["-q", str(P), "--gpu", "0"] if field == "p" else []
+    rc, out, err = run([OPT, "--only", "A", "-O", "24"] + q + [path])
+    assert rc == 0, err
+    g = re.search(r"# Found A: \((\d+)x(\d+)x(\d+) \d+/\d+\)\t(\d+)\|(\d+) instead of", err)
+    assert g, err
+    rc, _, err2 = run([CHK] + (["-q", str(P)] if field == "p" else []) + ["-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+    m = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
+    final_adds = int(m.group(1)) if m else 0
+    assert int(re.search(r"# \S*?(\d+)\tadditions", err2).group(1)) == final_adds
