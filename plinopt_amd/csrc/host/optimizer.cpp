@@ -206,6 +206,75 @@ template <class F> bool ab_method(const F &f, const SparseMat<typename F::Elt> &
     return true;
 }
 
+// program text of the kernel method for one decomposition and one seed (include/plinopt_optimize.inl:836-872)
+template <class F> std::string kernel_text(const F &f, const KernelDecomp<F> &kd, uint64_t seed, Ops &ops) {
+    std::ostringstream os;
+    input2temps(os, kd.Free, 'i', 't');                                                                    // :836
+    CandRng rng(seed);
+    Replay<F> RF(f, kd.Free, rng, os, 'o', 't', 'r'); Ops fo = RF.optimizer();                             // :841
+    input2temps(os, kd.Dep, 'o', 'v');                                                                     // :859
+    Replay<F> RK(f, kd.Dep, rng, os, 'x', 'v', 'g'); Ops ko = RK.optimizer();                              // :864
+    for (size_t j = 0; j < kd.dep.size(); ++j) os << 'o' << kd.dep[j] << ":=" << 'x' << j << ";\n";       // :871-874
+    ops = {fo.first + ko.first, fo.second + ko.second};
+    return os.str();
+}
+
+// KernelOptimiser :1288-1353 with this build's decomposition rule.  The restarts are spent as blocks of PLO_KERNEL_BLOCK
+// seeds: block d uses the decomposition drawn from its first seed, and every seed of the block is one run of the two
+// Optimizer calls on it (the reference draws a new decomposition for every restart; with a per-restart elimination on
+// the host the GPU would idle).  Returns false when the method could not run.
+#define PLO_KERNEL_BLOCK 256ull
+template <class F> bool kernel_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
+                                      int verbose, Ops &gops, std::string &gtext, const char *argv0) {
+    uint64_t seed = 0, bdec = 0; Ops best; bool have = false; double kms = 0; uint64_t ncand = 0;
+    const uint64_t nblocks = (loops + PLO_KERNEL_BLOCK - 1) / PLO_KERNEL_BLOCK;
+    bool use_gpu = false;
+    HipLib L;
+    if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -K: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        use_gpu = true;
+    }
+    for (uint64_t d = 0; d < nblocks; ++d) {
+        const uint64_t s0 = seed0 + d * PLO_KERNEL_BLOCK, cnt = std::min<uint64_t>(PLO_KERNEL_BLOCK, loops - d * PLO_KERNEL_BLOCK);
+        KernelDecomp<F> kd;
+        if (!kernel_decomp(f, lM, s0, kd)) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }   // :1343-1346
+        Ops bops; uint64_t bs = 0; bool bhave = false;
+        if constexpr (std::is_same<F, ZpField>::value) if (use_gpu) {
+            std::vector<uint32_t> rp1, c1, v1, rp2, c2, v2;
+            to_csr(kd.Free, rp1, c1, v1); to_csr(kd.Dep, rp2, c2, v2);
+            plo_csr_t A{(uint32_t)kd.Free.rowdim(), (uint32_t)kd.Free.coldim(), rp1.data(), c1.data(), v1.data()};
+            plo_csr_t B{(uint32_t)kd.Dep.rowdim(), (uint32_t)kd.Dep.coldim(), rp2.data(), c2.data(), v2.data()};
+            plo_chain_t *ch = nullptr;
+            int rc = L.chain_create(&A, &B, q, &ch);
+            if (rc != PLO_OK) { std::clog << "# -K skipped: " << L.last_error() << std::endl; return false; }
+            plo_best_t b{}; plo_stats_t st{};
+            rc = L.chain_search(ch, s0, cnt, PLO_COST_SUM_THEN_ADD, &b, &st);
+            L.chain_destroy(ch);
+            if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: -K GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
+            bops = {b.adds, b.muls}; bs = b.seed; bhave = true; kms += st.kernel_ms; ncand += st.candidates;
+        }
+        if (!bhave) {
+#pragma omp parallel for schedule(dynamic)
+            for (long long k = 0; k < (long long)cnt; ++k) {
+                Ops ops; (void)kernel_text(f, kd, s0 + (uint64_t)k, ops);
+#pragma omp critical
+                { uint64_t s = s0 + (uint64_t)k; if (!bhave || cmp_op_count(ops, bops) || (!cmp_op_count(bops, ops) && s < bs)) { bops = ops; bs = s; bhave = true; } }
+            }
+        }
+        if (bhave && (!have || cmp_op_count(bops, best))) { best = bops; seed = bs; bdec = s0; have = true; }      // earlier block wins ties
+    }
+    if (!have) return false;
+    KernelDecomp<F> kd;
+    if (!kernel_decomp(f, lM, bdec, kd)) return false;
+    Ops rops; std::string t = kernel_text(f, kd, seed, rops);
+    if (rops != best) { std::cerr << "# \033[1;31mERROR: -K replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (use_gpu && verbose > 0) std::clog << "# GPU (K): " << ncand << " candidates on " << nblocks << " decompositions, kernel " << kms << " ms" << std::endl;
+    if (verbose > 0) std::clog << "# Found K: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed
+                               << "] (rank " << kd.rank << '+' << kd.notindep << ", " << kd.dep.size() << " dependent rows)" << std::endl;
+    if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                              // :1347-1351
+    return true;
+}
+
 template <class F>
 int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool tryDirect, bool tryKernel, bool tryLU,
         bool tryAB, bool mostCSE, bool allkernels, int verbose, uint32_t q, const char *argv0)
@@ -259,7 +328,10 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
             if (cmp_op_count(dops, nbops)) { nbops = dops; text = t; }                 // :1241-1245
         }
     }
-    if (tryKernel && verbose > 1) std::clog << "# -K (kernel method) is not part of this build (SURVEY.md 8f)" << std::endl;
+    if (tryKernel) {                                                                  // :1450-1462 (KFI / -F and -N variants are not built)
+        try { kernel_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
+        catch (const std::exception &e) { std::clog << "# -K skipped: " << e.what() << std::endl; }
+    }
     if (tryLU) {
         try { lu_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
         catch (const std::exception &e) { std::clog << "# -G skipped: " << e.what() << std::endl; }
@@ -295,13 +367,13 @@ int main(int argc, char **argv)
         std::string a(argv[i]);
         if (a == "-h") {
             std::clog << "Usage: " << argv[0] << " [-h|-M|-P|-K|-D|-G|-E|-N|-A|-q #|-O #|--gpu #|--seed #] [stdin|matrixfile.sms]\n"
-                      << "  -D/-K/-G: direct/kernel/LU methods (default is all; this build runs -D and -G)\n"
+                      << "  -D/-K/-G: direct/kernel/LU methods (default is all)\n"
                       << "  -q #: search modulo (default is Rationals, on the host)\n"
                       << "  -O #: randomized search with that many loops (default " << loops << " loops)\n"
                       << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only\n"
                       << "  --seed #: first candidate seed (default 0)\n"
                       << "  -A: also try the alternative factorization M = Alt.CoB (inner dimension = column count)\n"
-                      << "  --only D|G|A: run exactly that method\n";
+                      << "  --only D|K|G|A: run exactly that method\n";
             exit(-1);
         } else if (a == "-M") printMaple = true;
         else if (a == "-P") printPretty = true;
@@ -322,7 +394,7 @@ int main(int argc, char **argv)
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing
         else filename = a;
     }
-    if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = false; }
+    if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = only == "K"; }
     else if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
     (void)printMaple; (void)printPretty;
     try {

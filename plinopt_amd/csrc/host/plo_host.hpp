@@ -687,6 +687,63 @@ template <class F> ABFactors<F> ab_factorize(const F &f, const SparseMat<typenam
     return best;
 }
 
+// --------------------------------------------------------------------- -K: kernel (nullspace) decomposition
+// nullspacedecomp (reference include/plinopt_optimize.inl:689-884) computes a row basis of M through LinBox's
+// InPlaceLinearPivoting and a nullspace basis, none of whose choices are specified in the tree.  This build's rule,
+// from one per-decomposition stream: a random order of the rows (Fisher-Yates, as :705-713 shuffles), the greedy row
+// basis in that order, every other row d as its combination x_d of the basis rows; NotIndep = next() mod nullity of
+// the dependent rows stay in the directly computed part (:789-797, the LAST ones in the order), the others are emptied in
+// `Free` and computed by `Dep` (rows = those dependent rows, columns = rows of M, entries on basis rows only):
+//     o := Free . i ;   x := Dep . o ;   o_{dep[j]} := x_j                    (:836-872)
+template <class F> struct KernelDecomp {
+    SparseMat<typename F::Elt> Free, Dep;
+    std::vector<size_t> dep;                  // row of M computed by row j of Dep
+    size_t rank = 0, notindep = 0;
+};
+template <class F> bool kernel_decomp(const F &f, const SparseMat<typename F::Elt> &M, uint64_t seed, KernelDecomp<F> &out) {
+    using E = typename F::Elt;
+    const size_t m = M.rowdim(), n = M.coldim();
+    std::vector<size_t> ord(m);
+    for (size_t i = 0; i < m; ++i) ord[i] = i;
+    CandRng rng(seed);
+    for (size_t i = m; i > 1; --i) std::swap(ord[i - 1], ord[rng.next() % (uint32_t)i]);
+    std::vector<std::vector<E>> ech, comb; std::vector<size_t> piv, basis, deps;
+    std::vector<std::vector<E>> depx;
+    for (size_t t = 0; t < m; ++t) {
+        std::vector<E> v(n, f.zero()), c(m, f.zero());        // c: combination over basis rows, indexed by basis position
+        for (auto &e : M.rows[ord[t]]) v[e.first] = e.second;
+        for (size_t k = 0; k < ech.size(); ++k) {
+            const E x = v[piv[k]];
+            if (f.isZero(x)) continue;
+            for (size_t j = 0; j < n; ++j) v[j] = f.add(v[j], f.neg(f.mul(x, ech[k][j])));
+            for (size_t j = 0; j < ech.size(); ++j) c[j] = f.add(c[j], f.mul(x, comb[k][j]));
+        }
+        size_t pc = n;
+        for (size_t j = 0; j < n; ++j) if (!f.isZero(v[j])) { pc = j; break; }
+        if (pc == n) { deps.push_back(ord[t]); depx.push_back(c); continue; }      // row = sum_j c[j] * basis row j
+        // new basis row number |basis|: echelon row = (row - sum c_j basis_j) / pivot
+        const E iv = f.inv(v[pc]);
+        std::vector<E> cc(m, f.zero());
+        for (size_t j = 0; j < ech.size(); ++j) cc[j] = f.neg(f.mul(c[j], iv));
+        cc[basis.size()] = iv;
+        for (size_t j = 0; j < n; ++j) v[j] = f.mul(v[j], iv);
+        ech.push_back(v); comb.push_back(cc); piv.push_back(pc); basis.push_back(ord[t]);
+    }
+    if (deps.empty()) return false;                             // zero dimensional kernel (:1304-1309)
+    out.rank = basis.size();
+    out.notindep = rng.next() % (uint32_t)deps.size();          // :792-795
+    const size_t kept = deps.size() - out.notindep;
+    out.Free = M; out.Dep = SparseMat<E>(kept, m); out.dep.assign(deps.begin(), deps.begin() + (long)kept);
+    for (size_t j = 0; j < kept; ++j) {
+        out.Free.rows[deps[j]].clear();
+        std::vector<std::pair<size_t, E>> row;
+        for (size_t b = 0; b < basis.size(); ++b) if (!f.isZero(depx[j][b])) row.emplace_back(basis[b], depx[j][b]);
+        std::sort(row.begin(), row.end(), [](const std::pair<size_t, E> &x, const std::pair<size_t, E> &y) { return x.first < y.first; });
+        out.Dep.rows[j] = row;
+    }
+    return true;
+}
+
 // cmpOpCount, include/plinopt_optimize.h:53-64 (mode 0 default, 1 OPTIMIZE_ADDITIONS, 2 OPTIMIZE_SUMS)
 inline bool cmp_op_count(std::pair<size_t, size_t> a, std::pair<size_t, size_t> b, int mode = 0) {
     if (mode == 1) return a.first < b.first || (a.first == b.first && a.second < b.second);

@@ -239,3 +239,30 @@ def test_ab_method_programs_verify(name, field):
     m = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
     final_adds = int(m.group(1)) if m else 0
     assert int(re.search(r"# \S*?(\d+)\tadditions", err2).group(1)) == final_adds
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "4x4x4_49_156_L.sms", "4x4x4_49_156_R.sms", "3x3x6_40_L.sms",
+                                  "4x4x4_48_rational_L.sms", "2x2x2_7_DPS-accurate_L.sms", "6x3x3_40_DPS-accurate_R.sms"])
+@pytest.mark.parametrize("field", ["Q", "p"])
+def test_kernel_method_programs_verify(name, field):
+    """-K (KernelOptimiser / nullspacedecomp, plinopt_optimize.inl:689-884, :1288-1353) with the build's decomposition rule:
+    a greedy row basis in a random order, the other rows as combinations of the basis outputs, some of them kept direct.
+    `--only K` prints that program, which must compute the matrix with exactly the reported operation count; 600
+    restarts = 3 decompositions."""
+    path = os.path.join(DATA, name)
+    q = ["-q", str(P), "--gpu", "0"] if field == "p" else []
+    rc, out, err = run([OPT, "--only", "K", "-O", "600"] + q + [path])
+    assert rc == 0, err
+    assert re.search(r"# Found K: (\d+)\|(\d+) instead of", err), err
+    rc, _, err2 = run([CHK] + (["-q", str(P)] if field == "p" else []) + ["-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+    m = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
+    final_adds = int(m.group(1)) if m else 0
+    assert int(re.search(r"# \S*?(\d+)\tadditions", err2).group(1)) == final_adds
+
+
+def test_kernel_method_reports_a_zero_dimensional_kernel():
+    rc, out, err = run([OPT, "--only", "K", "-O", "10", "-q", str(P), "--gpu", "0", os.path.join(DATA, "cyclic.sms")])
+    assert rc == 0 and "Zero dimensional kernel" in err
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", os.path.join(DATA, "cyclic.sms")], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2                      # the direct program is printed instead (:1473-1485)
