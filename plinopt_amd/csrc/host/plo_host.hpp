@@ -679,10 +679,14 @@ template <class F> ABFactors<F> ab_factorize(const F &f, const SparseMat<typenam
     size_t nz = 0, nu = 0;
     for (auto &r : M.rows) for (auto &e : r) { ++nz; if (!absOne(f, e.second)) ++nu; }
     best.score = {nz, nu, n};
-    for (size_t i = 0; i < loops; ++i) {                         // sequential: ties go to the smaller seed
+    if (m < n) return best;
+    size_t bi = loops;                                           // ties go to the smaller seed, whatever the thread schedule
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long i = 0; i < (long long)loops; ++i) {
         ABFactors<F> c;
-        if (m < n || !ab_backsolve(f, M, seed0 + i, c)) continue;
-        if (c.score < best.score) best = c;
+        if (!ab_backsolve(f, M, seed0 + (uint64_t)i, c)) continue;
+#pragma omp critical
+        if (c.score < best.score || (c.score == best.score && bi != loops && (size_t)i < bi)) { best = c; bi = (size_t)i; }
     }
     return best;
 }
