@@ -127,6 +127,17 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
                    const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
                    plo_cob_best_t *out, plo_stats_t *stats);
 
+/* ---- -E, the exhaustive CSE tree: RecSub / RecOptimizer (include/plinopt_optimize.inl:889-1013, called by AllCSEOpt
+ * :1252-1281) explore every schedule of pairs of frequency > 1 (not only the maximal ones).  Here a schedule is a
+ * candidate addressed by an index in the mixed radix of its own path: at every step the children (distinct triples of
+ * frequency > 1, in std::map order) are numbered 0..T-1; digit = index mod T, index /= T.  The product of the radices met by
+ * a candidate is returned; the indices first..first+count-1 = 0..N-1 cover the whole tree as soon as N >= *maxprod (the
+ * largest product seen).  Cost = op-count of the program Optimizer would print for that schedule; RecSub's order is
+ * PLO_COST_ADD_THEN_MUL (:958-959).  LDS-resident plans only (PLO_E_UNSUPPORTED otherwise). */
+int plo_cse_enum_cost_many_plan(plo_plan_t *plan, uint64_t first, uint64_t n, uint32_t *adds, uint32_t *muls, uint64_t *prods, plo_stats_t *stats);
+int plo_cse_enum_search_plan(plo_plan_t *plan, uint64_t first, uint64_t count, int cost_mode, plo_best_t *best /* .seed = index */,
+                             uint64_t *maxprod, plo_stats_t *stats);
+
 /* ---- In-place trilinear search: replaces the body of the restart loop of SearchTriLinearAlgorithm
  * (include/plinopt_inplace.inl:837-924; driver src/trilplacer.cpp:150-152).  A (m x nA), B (m x nB) and T = transpose of
  * the product matrix (m x nT), integer CSR with columns sorted per row.  One candidate (seed) = row permutation +

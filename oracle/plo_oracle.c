@@ -138,6 +138,7 @@ static int tv_has(const trivec_t *v, const tri_t *k) {
 
 typedef struct {
     mat_t M; mults_t multiples; uint32_t nbadd, nbmul; uint32_t rng; sink_t out; char ouv, tev, rav;
+    int enumerate; uint64_t rem, prod;      /* RecSub's schedule space walked by index (see plo_oracle_enum_optimizer) */
 } cand_t;
 
 /* RemOneCSE with updateAPM=true, plinopt_optimize.inl:60-194 */
@@ -217,6 +218,10 @@ static int one_sub(cand_t *C, uint32_t *ties_out, int ties_cap, int *nties_out, 
                 if (PairMap.e[k].cnt == maxfrq) MaxCSE[nmax++] = PairMap.e[k].k;
                 if (PairMap.e[k].cnt > maxfrq) { maxfrq = PairMap.e[k].cnt; nmax = 0; MaxCSE[nmax++] = PairMap.e[k].k; }
             }
+            if (C->enumerate && !nties_out) {       /* RecSub :935-937: every pair of frequency > 1 is a child, in map order */
+                nmax = 0;
+                for (int k = 0; k < PairMap.n; k++) if (PairMap.e[k].cnt > 1) MaxCSE[nmax++] = PairMap.e[k].k;
+            }
             if (nties_out) {                       /* test hook: report first tie set and stop */
                 *nties_out = nmax; *maxfrq_out = maxfrq;
                 for (int k = 0; k < nmax && k < ties_cap; k++) { ties_out[3*k] = MaxCSE[k].a; ties_out[3*k+1] = MaxCSE[k].b; ties_out[3*k+2] = MaxCSE[k].r; }
@@ -225,7 +230,12 @@ static int one_sub(cand_t *C, uint32_t *ties_out, int ties_cap, int *nties_out, 
             if (maxfrq <= 1) { ret = goodfreq; break; }                                       /* :255 */
             goodfreq = 1;
             tri_t cse = MaxCSE[0];
-            if (nmax > 1) cse = MaxCSE[plo_oracle_rng_next(&C->rng) % (uint32_t)nmax];       /* :260-265 */
+            if (nmax > 1) {
+                if (C->enumerate) {                 /* next digit of the schedule index, radix = number of children */
+                    cse = MaxCSE[C->rem % (uint64_t)nmax]; C->rem /= (uint64_t)nmax;
+                    C->prod = (C->prod > UINT64_MAX / (uint64_t)nmax) ? UINT64_MAX : C->prod * (uint64_t)nmax;
+                } else cse = MaxCSE[plo_oracle_rng_next(&C->rng) % (uint32_t)nmax];          /* :260-265 */
+            }
             ++C->nbadd;                                                                       /* :292 */
             rem_one_cse(C, &cse, AllPairs, &PairMap);
         }
@@ -578,4 +588,41 @@ int plo_oracle_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* RecSub / RecOptimizer (plinopt_optimize.inl:889-1013) explore every schedule of pairs of frequency > 1.  Here a schedule
+ * is addressed by an index in the mixed radix of its own path: at each step the children (distinct triples of frequency > 1,
+ * map order) are numbered 0..T-1, digit = index mod T, index /= T.  *prod = product of the radices met (saturating): the
+ * enumeration 0..N-1 is exhaustive as soon as N >= max prod over the schedules seen.  Counts are those of the emitted text
+ * (Optimizer-style), cf. the savings-based accounting of :950-951. */
+int plo_oracle_enum_optimizer(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                              uint64_t index, const char letters[4], uint32_t *adds, uint32_t *muls, uint64_t *prod, char **text) {
+    if (p < 2) return -1;
+    cand_t C; cand_load(&C, m, n, rowptr, col, val, p, 0, letters, text != NULL);
+    C.enumerate = 1; C.rem = index; C.prod = 1;
+    if (text) {
+        unsigned char *used = (unsigned char *)calloc(n ? n : 1, 1);
+        for (uint32_t k = 0; k < rowptr[m]; k++) used[col[k]] = 1;
+        for (uint32_t j = 0; j < n; j++) if (used[j]) sk_put(&C.out, "%c%u:=%c%u;\n", letters[1], j, letters[3], j);
+        free(used);
+    }
+    optimizer(&C);
+    *adds = C.nbadd; *muls = C.nbmul; if (prod) *prod = C.prod;
+    if (text) { *text = C.out.s ? C.out.s : (char *)calloc(1, 1); }
+    cand_free(&C);
+    return 0;
+}
+int plo_oracle_enum_cost_many(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                              uint64_t first, uint64_t count, uint32_t *adds, uint32_t *muls, uint64_t *prods, int nthreads) {
+    if (p < 2) return -1;
+    if (nthreads < 1) nthreads = 1;
+    #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
+    for (long long k = 0; k < (long long)count; k++) {
+        cand_t C; cand_load(&C, m, n, rowptr, col, val, p, 0, "otri", 0);
+        C.enumerate = 1; C.rem = first + (uint64_t)k; C.prod = 1;
+        optimizer(&C);
+        adds[k] = C.nbadd; muls[k] = C.nbmul; if (prods) prods[k] = C.prod;
+        cand_free(&C);
+    }
+    return 0;
 }

@@ -87,6 +87,12 @@ void plo_oracle_naive_ops(uint32_t m, const uint32_t *rowptr,
                           const uint32_t *val, uint32_t p,
                           uint32_t *adds, uint32_t *muls);
 
+/* -E: the schedule space of RecSub (plinopt_optimize.inl:889-982) walked by index, see plo_oracle.c */
+int plo_oracle_enum_optimizer(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                              uint64_t index, const char letters[4], uint32_t *adds, uint32_t *muls, uint64_t *prod, char **text);
+int plo_oracle_enum_cost_many(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                              uint64_t first, uint64_t count, uint32_t *adds, uint32_t *muls, uint64_t *prods, int nthreads);
+
 /* ---- trilplacer (plo_tril_oracle.c): in-place trilinear programs, plinopt_inplace.inl:400-502, :732-929.
  * A (m x nA), B (m x nB), T = transpose of the product matrix (m x nT): CSR, columns sorted per row, rational values
  * num/den (den == NULL: integers).  One candidate = one restart of SearchTriLinearAlgorithm :837-924 = row permutation

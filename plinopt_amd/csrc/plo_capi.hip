@@ -653,6 +653,79 @@ int plo_cse_search_plan(plo_plan_t *pl, uint64_t seed0, uint64_t nseeds, int cos
     return PLO_OK;
 }
 
+// -E: the schedule space of RecSub walked by index (PickState in plo_cse_wave.hip).  LDS-resident plans only.
+int plo_cse_enum_cost_many_plan(plo_plan_t *pl, uint64_t first, uint64_t n, uint32_t *adds, uint32_t *muls, uint64_t *prods, plo_stats_t *st)
+{
+    if (!pl || !adds || !muls) return fail(PLO_E_ARG, "null argument");
+    if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
+    if (pl->big) return fail(PLO_E_UNSUPPORTED, "schedule enumeration is for matrices of the LDS-resident kernel (the tree of anything larger cannot be walked)");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    auto t0 = std::chrono::steady_clock::now();
+    if (n == 0) return PLO_OK;
+    if (n > 0xFFFFFFFFull) return fail(PLO_E_ARG, "at most 2^32-1 schedules per call");
+    uint32_t *d_adds = nullptr, *d_muls = nullptr; unsigned long long *d_prods = nullptr;
+    HIPCHK(hipMalloc((void **)&d_adds, n * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&d_muls, n * sizeof(uint32_t)));
+    if (prods) HIPCHK(hipMalloc((void **)&d_prods, n * sizeof(unsigned long long)));
+    plo::WaveJob J{}; J.seed0 = first; J.seeds = nullptr; J.ncand = n; J.adds = d_adds; J.muls = d_muls; J.best = nullptr; J.cost_mode = 0;
+    J.enumerate = 1u; J.prods = d_prods; J.prodmax = nullptr;
+    int rc = run_job(pl, J, st);
+    if (rc == PLO_OK) {
+        hipError_t e1 = hipMemcpy(adds, d_adds, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipError_t e2 = hipMemcpy(muls, d_muls, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipError_t e3 = prods ? hipMemcpy(prods, d_prods, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) : hipSuccess;
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(PLO_E_HIP, "copy back failed");
+    }
+    (void)hipFree(d_adds); (void)hipFree(d_muls); if (d_prods) (void)hipFree(d_prods);
+    st->candidates = n;
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int plo_cse_enum_search_plan(plo_plan_t *pl, uint64_t first, uint64_t count, int cost_mode, plo_best_t *out, uint64_t *maxprod, plo_stats_t *st)
+{
+    if (!pl || !out || !maxprod) return fail(PLO_E_ARG, "null argument");
+    if (cost_mode != PLO_COST_SUM_THEN_ADD && cost_mode != PLO_COST_ADD_THEN_MUL) return fail(PLO_E_ARG, "cost mode 0 or 1");
+    if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
+    if (pl->big) return fail(PLO_E_UNSUPPORTED, "schedule enumeration is for matrices of the LDS-resident kernel (the tree of anything larger cannot be walked)");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    auto t0 = std::chrono::steady_clock::now();
+    out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull; *maxprod = 0;
+    unsigned long long *d_pm = nullptr;
+    HIPCHK(hipMalloc((void **)&d_pm, sizeof(unsigned long long)));
+    HIPCHK(hipMemset(d_pm, 0, sizeof(unsigned long long)));
+    uint64_t bkey = ~0ull, bidx = ~0ull;
+    const uint64_t CH = 0xFFFFFFFFull;
+    int rc = PLO_OK;
+    for (uint64_t done = 0; done < count && rc == PLO_OK;) {
+        const uint64_t cnt = std::min<uint64_t>(CH, count - done);
+        if (hipMemsetAsync(pl->d_best, 0xFF, sizeof(unsigned long long), g_stream) != hipSuccess) { rc = fail(PLO_E_HIP, "memset"); break; }
+        plo::WaveJob J{}; J.seed0 = first + done; J.seeds = nullptr; J.ncand = cnt; J.best = pl->d_best; J.cost_mode = (uint32_t)cost_mode;
+        J.enumerate = 1u; J.prodmax = d_pm;
+        rc = run_job(pl, J, st);
+        if (rc != PLO_OK) break;
+        unsigned long long w = 0;
+        if (hipMemcpy(&w, pl->d_best, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(PLO_E_HIP, "copy back"); break; }
+        const uint64_t key = w >> 32, ix = first + done + (w & 0xFFFFFFFFull);
+        if (key < bkey || (key == bkey && ix < bidx)) { bkey = key; bidx = ix; }
+        done += cnt;
+    }
+    unsigned long long pm = 0;
+    if (rc == PLO_OK && hipMemcpy(&pm, d_pm, sizeof pm, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PLO_E_HIP, "copy back");
+    (void)hipFree(d_pm);
+    if (rc != PLO_OK) return rc;
+    if (count) {
+        uint32_t a, mu;
+        if (cost_mode == PLO_COST_SUM_THEN_ADD) { a = (uint32_t)(bkey & 0xFFFFu); mu = (uint32_t)(bkey >> 16) - a; }
+        else { a = (uint32_t)(bkey >> 16); mu = (uint32_t)(bkey & 0xFFFFu); }
+        out->adds = a; out->muls = mu; out->seed = bidx;
+    }
+    *maxprod = pm;
+    st->candidates = count;
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PLO_OK;
+}
+
 int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode,
                    plo_best_t *out, plo_stats_t *stats)
 {

@@ -50,6 +50,9 @@ struct WaveJob {
     unsigned long long *best;  // packed (cost,seed offset) minimum (may be null)
     uint32_t cost_mode;
     uint32_t *err;             // device error word
+    uint32_t enumerate;        // 1: candidate c is the schedule of index seed0 + c in RecSub's tree (see PickState)
+    unsigned long long *prodmax;   // enumerate: maximum over candidates of the product of their radices (may be null)
+    unsigned long long *prods;     // enumerate: that product per candidate (may be null)
 };
 
 enum { ERR_TABLE = 1, ERR_MULT = 2, ERR_STEPS = 3, ERR_PGEN = 4 };
@@ -391,9 +394,15 @@ __device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const u
     return ((uint64_t)nbadd << 32) | nbmul;
 }
 
+// How a candidate picks among the eligible triples of a step.  Random restarts (OneSub :260-265): the triples of maximal
+// frequency, one draw of the stream.  Enumeration (-E, RecSub :889-982 explores every pair of frequency > 1): all triples
+// of frequency > 1 are the children, the candidate's index is read in the mixed radix of its own path (digit = rem mod T,
+// rem /= T); prod = product of the radices (saturating): indices 0..N-1 cover the whole tree once N >= max prod.
+struct PickState { uint32_t rng; uint32_t enumerate; uint64_t rem, prod; };
+
 // One candidate.  Returns packed (adds<<32 | muls); sets *errw on failure.
 template <bool UNIT>
-__device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_t *rs, uint32_t &rng,
+__device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_t *rs, PickState &ps,
                                   uint32_t lane, uint32_t *errw)
 {
     uint64_t *tab   = (uint64_t *)(reg + P.off_tab);
@@ -429,7 +438,8 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         uint32_t T = 0;
         for (uint32_t s0 = 0; s0 < cap; s0 += 64u) {
             uint64_t v = tab[s0 + lane];
-            bool is = (uint32_t)(v & PLO_VMASK) == maxfrq;
+            const uint32_t cnt_ = (uint32_t)(v & PLO_VMASK);
+            bool is = ps.enumerate ? cnt_ >= 2u : cnt_ == maxfrq;
             uint64_t bm = __ballot(is);
             if (is) ties[T + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)(s0 + lane);
             T += (uint32_t)__popcll(bm);
@@ -440,7 +450,12 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         if (T == 1u) {
             key = tab[ties[0]] >> PLO_VB;
         } else {
-            const uint32_t k = uni32(rng_next(rng) % T);
+            uint32_t k;
+            if (ps.enumerate) {
+                k = (uint32_t)(ps.rem % T); ps.rem /= T;
+                ps.prod = ps.prod > 0xFFFFFFFFFFFFFFFFull / T ? 0xFFFFFFFFFFFFFFFFull : ps.prod * T;
+            } else k = rng_next(ps.rng) % T;
+            k = uni32(k);
             if (T <= 64u) {
                 const uint64_t mine = lane < T ? (tab[ties[lane]] >> PLO_VB) : ~0ull;
                 uint32_t rank = 0;
@@ -595,8 +610,9 @@ __global__ __launch_bounds__(256) void cse_wave_kernel(WavePlan P, WaveJob J)
         for (uint32_t i = lane; i < tw; i += 64u) ((uint64_t *)reg)[i] = P.tmpl[i];     // matrix image -> LDS
         PLO_WAVE_SYNC();
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        uint32_t rng = 1u + (uint32_t)(splitmix64(seed) % 2147483646ull);
-        const uint64_t res = run_candidate<UNIT>(P, reg, rs, rng, lane, J.err);
+        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), J.enumerate, seed, 1ull};
+        const uint64_t res = run_candidate<UNIT>(P, reg, rs, ps, lane, J.err);
+        if (J.enumerate && lane == 0) { if (J.prods) J.prods[c] = ps.prod; if (J.prodmax) atomicMax(J.prodmax, (unsigned long long)ps.prod); }
         const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
         if (lane == 0) {
             if (J.adds) J.adds[c] = a;
@@ -637,14 +653,14 @@ __global__ __launch_bounds__(256) void cse_chain_kernel(WavePlan P1, WavePlan P2
     const uint64_t stride = (uint64_t)gridDim.x * nwaves;
     for (uint64_t c = (uint64_t)blockIdx.x * nwaves + wave; c < J.ncand; c += stride) {
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        uint32_t rng = 1u + (uint32_t)(splitmix64(seed) % 2147483646ull);
+        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull};
         for (uint32_t i = lane; i < tw1; i += 64u) ((uint64_t *)reg)[i] = P1.tmpl[i];
         PLO_WAVE_SYNC();
-        const uint64_t r1 = P1.unit ? run_candidate<true>(P1, reg, rs1, rng, lane, J.err) : run_candidate<false>(P1, reg, rs1, rng, lane, J.err);
+        const uint64_t r1 = P1.unit ? run_candidate<true>(P1, reg, rs1, ps, lane, J.err) : run_candidate<false>(P1, reg, rs1, ps, lane, J.err);
         PLO_WAVE_SYNC();
         for (uint32_t i = lane; i < tw2; i += 64u) ((uint64_t *)reg)[i] = P2.tmpl[i];
         PLO_WAVE_SYNC();
-        const uint64_t r2 = P2.unit ? run_candidate<true>(P2, reg, rs2, rng, lane, J.err) : run_candidate<false>(P2, reg, rs2, rng, lane, J.err);
+        const uint64_t r2 = P2.unit ? run_candidate<true>(P2, reg, rs2, ps, lane, J.err) : run_candidate<false>(P2, reg, rs2, ps, lane, J.err);
         const uint32_t a = (uint32_t)(r1 >> 32) + (uint32_t)(r2 >> 32), mu_ = (uint32_t)r1 + (uint32_t)r2;
         if (lane == 0) {
             if (J.adds) J.adds[c] = a;

@@ -61,6 +61,25 @@ class CSEPlan:
         self.last_stats = st.as_dict()
         return b.adds, b.muls, b.seed
 
+    # -E: RecSub's schedule tree walked by index (include/plinopt_hip.h)
+    def enum_cost_many(self, first, n):
+        """(adds, muls, product of radices) of the schedules first..first+n-1"""
+        L = capi.lib()
+        adds = (ctypes.c_uint32 * max(n, 1))(); muls = (ctypes.c_uint32 * max(n, 1))(); prods = (ctypes.c_uint64 * max(n, 1))()
+        st = capi.Stats()
+        capi.check(L.plo_cse_enum_cost_many_plan(self._h, first, n, adds, muls, prods, ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return list(adds[:n]), list(muls[:n]), list(prods[:n])
+
+    def enum_search(self, first, count, cost_mode=capi.COST_ADD_THEN_MUL):
+        """Best (adds, muls, index) over the schedules first..first+count-1 and the largest radix product seen: the
+        enumeration from 0 is exhaustive once count >= that product."""
+        L = capi.lib()
+        b, st, mp = capi.Best(), capi.Stats(), ctypes.c_uint64()
+        capi.check(L.plo_cse_enum_search_plan(self._h, first, count, cost_mode, ctypes.byref(b), ctypes.byref(mp), ctypes.byref(st)))
+        self.last_stats = st.as_dict()
+        return (b.adds, b.muls, b.seed), mp.value
+
 
 def cmp_op_count_key(adds, muls, cost_mode=capi.COST_SUM_THEN_ADD):
     """Sort key equivalent to cmpOpCount (include/plinopt_optimize.h:53-64)."""

@@ -277,6 +277,10 @@ def oracle():
         L.plo_oracle_tril_cost_many.argtypes = [ctypes.c_uint32] + mat * 3 + [u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, ctypes.c_int]
         L.plo_oracle_tril_program.argtypes = [ctypes.c_uint32] + mat * 3 + [ctypes.c_uint64, ctypes.c_int, u32p, ctypes.POINTER(ctypes.c_void_p)]
         L.plo_oracle_tril_search.argtypes = [ctypes.c_uint32] + mat * 3 + [ctypes.c_uint64, ctypes.c_uint64, u32p, u64p, u32p]
+        L.plo_oracle_enum_optimizer.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_char_p,
+                                                u32p, u32p, u64p, ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_oracle_enum_cost_many.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
+                                                u32p, u32p, u64p, ctypes.c_int]
         L.plo_oracle_naive_ops.argtypes = [ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p, u32p]
         L.plo_oracle_naive_ops.restype = None
         L.plo_oracle_free.argtypes = [ctypes.c_void_p]
@@ -345,6 +349,21 @@ class OracleMatrix:
                                             cost_mode, ctypes.byref(a), ctypes.byref(mu), ctypes.byref(s), nthreads)
         assert rc == 0
         return a.value, mu.value, s.value
+
+    def enum_optimizer(self, index, letters=b"otri"):
+        """one schedule of RecSub's tree (-E): -> (adds, muls, radix product, text)"""
+        a = ctypes.c_uint32(); mu = ctypes.c_uint32(); pr = ctypes.c_uint64(); txt = ctypes.c_void_p()
+        rc = oracle().plo_oracle_enum_optimizer(self.m, self.n, _arr(self.rowptr), _arr(self.col), _arr(self.val), self.p, index, letters,
+                                                ctypes.byref(a), ctypes.byref(mu), ctypes.byref(pr), ctypes.byref(txt))
+        assert rc == 0
+        text = ctypes.string_at(txt).decode(); oracle().plo_oracle_free(txt)
+        return a.value, mu.value, pr.value, text
+
+    def enum_cost_many(self, first, n, nthreads=1):
+        a = (ctypes.c_uint32 * max(n, 1))(); mu = (ctypes.c_uint32 * max(n, 1))(); pr = (ctypes.c_uint64 * max(n, 1))()
+        rc = oracle().plo_oracle_enum_cost_many(self.m, self.n, _arr(self.rowptr), _arr(self.col), _arr(self.val), self.p, first, n, a, mu, pr, nthreads)
+        assert rc == 0
+        return list(a[:n]), list(mu[:n]), list(pr[:n])
 
     def first_ties(self, cap=4096):
         buf = (ctypes.c_uint32 * (3 * cap))()

@@ -97,3 +97,18 @@ def test_golden_costs_fixture():
         M = OracleMatrix.from_sms(os.path.join(DATA, name), G["p"])
         a, mu = M.cost_many(seed0=rec["seed0"], nseeds=len(rec["adds"]))
         assert a == rec["adds"] and mu == rec["muls"], name
+
+
+def test_enumerated_schedules_emit_valid_programs():
+    """-E: every schedule of RecSub's tree addressed by index prints a program that computes the matrix, with the reported
+    op-count; on Winograd's L the tree has three leaves and the best needs the known 4 additions."""
+    M = OracleMatrix.from_sms(os.path.join(DATA, "2x2x2_7_Winograd_L.sms"), 131071)
+    a, mu, pr = M.enum_cost_many(0, 64)
+    assert max(pr) == 3 and min(a) == 4
+    for name, idxs in (("2x2x2_7_Winograd_L.sms", range(3)), ("cyclic.sms", [0, 1, 5, 999, 123456789]), ("4x4x4_48_rational_P.sms", [0, 7, 10 ** 9])):
+        M = OracleMatrix.from_sms(os.path.join(DATA, name), 131071)
+        D = M.dense()
+        for idx in idxs:
+            adds, muls, prod, text = M.enum_optimizer(idx)
+            assert eval_slp(text, FieldP(131071)) == D
+            assert count_ops(text) == (adds, muls) and prod >= 1
