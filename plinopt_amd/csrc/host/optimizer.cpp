@@ -37,6 +37,9 @@ struct HipLib {
     decltype(&plo_cse_chain_search) chain_search = nullptr;
     decltype(&plo_cse_chain_destroy) chain_destroy = nullptr;
     decltype(&plo_shutdown) shutdown = nullptr;
+    decltype(&plo_cse_plan_create) plan_create = nullptr;
+    decltype(&plo_cse_plan_destroy) plan_destroy = nullptr;
+    decltype(&plo_cse_enum_search_plan) enum_search = nullptr;
     bool load(const char *argv0) {
         std::vector<std::string> cand;
         if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
@@ -50,7 +53,9 @@ struct HipLib {
         cse_search = (decltype(cse_search))dlsym(h, "plo_cse_search"); shutdown = (decltype(shutdown))dlsym(h, "plo_shutdown");
         chain_create = (decltype(chain_create))dlsym(h, "plo_cse_chain_create"); chain_search = (decltype(chain_search))dlsym(h, "plo_cse_chain_search");
         chain_destroy = (decltype(chain_destroy))dlsym(h, "plo_cse_chain_destroy");
-        return init && last_error && cse_search && shutdown && chain_create && chain_search && chain_destroy;
+        plan_create = (decltype(plan_create))dlsym(h, "plo_cse_plan_create"); plan_destroy = (decltype(plan_destroy))dlsym(h, "plo_cse_plan_destroy");
+        enum_search = (decltype(enum_search))dlsym(h, "plo_cse_enum_search_plan");
+        return init && last_error && cse_search && shutdown && chain_create && chain_search && chain_destroy && plan_create && plan_destroy && enum_search;
     }
 };
 
@@ -275,6 +280,74 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     return true;
 }
 
+// program text of one schedule of the exhaustive CSE tree
+template <class F> std::string schedule_text(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t index, Ops &ops, uint64_t &prod) {
+    std::ostringstream os;
+    input2temps(os, lM, 'i', 't');                                                                         // :1265
+    Replay<F> R(f, lM, 0, os, 'o', 't', 'r'); R.set_schedule(index);
+    ops = R.optimizer(); prod = R.eprod;
+    return os.str();
+}
+
+// AllCSEOpt / RecOptimizer / RecSub (-E, include/plinopt_optimize.inl:889-1013, :1252-1281): the best of ALL greedy CSE
+// schedules (every pair of frequency > 1 is a child, order additions then multiplications :958-959).  The tree is walked
+// by schedule index (include/plinopt_hip.h): ranges 0..N-1 with N growing to the largest radix product seen; exhaustive
+// when N reaches it, otherwise stopped at `budget` schedules (the reference has no bound and no termination on anything
+// but toy inputs).  Returns false when the method could not run.
+template <class F> bool exhaustive_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t budget, int gpu, uint32_t q,
+                                          int verbose, Ops &gops, std::string &gtext, const char *argv0) {
+    Ops best; uint64_t bidx = 0, maxprod = 1, done = 0; bool have = false, on_gpu = false; double kms = 0;
+    auto better = [](const Ops &a, const Ops &b) { return cmp_op_count(a, b, 1); };
+    HipLib L; plo_plan_t *plan = nullptr;
+    std::vector<uint32_t> rp, cc, vv;
+    if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -E: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        to_csr(lM, rp, cc, vv);
+        plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
+        if (L.plan_create(&A, q, &plan) != PLO_OK) { std::clog << "# -E skipped: " << L.last_error() << std::endl; return false; }
+        on_gpu = true;
+    }
+    uint64_t target = 1;
+    while (done < target) {
+        const uint64_t cnt = target - done;
+        Ops rb; uint64_t ri = 0, rp_ = 1; bool rh = false;
+        if (on_gpu) {
+            plo_best_t b{}; plo_stats_t st{}; uint64_t mp = 0;
+            if (L.enum_search(plan, done, cnt, PLO_COST_ADD_THEN_MUL, &b, &mp, &st) != PLO_OK) {
+                std::clog << "# -E skipped: " << L.last_error() << std::endl; L.plan_destroy(plan); return false;
+            }
+            rb = {b.adds, b.muls}; ri = b.seed; rp_ = mp; rh = true; kms += st.kernel_ms;
+        } else {
+#pragma omp parallel for schedule(dynamic, 8)
+            for (long long k = 0; k < (long long)cnt; ++k) {
+                Ops ops; uint64_t pr = 1; (void)schedule_text(f, lM, done + (uint64_t)k, ops, pr);
+#pragma omp critical
+                { const uint64_t ix = done + (uint64_t)k; if (!rh || better(ops, rb) || (!better(rb, ops) && ix < ri)) { rb = ops; ri = ix; rh = true; } rp_ = std::max(rp_, pr); }
+            }
+        }
+        if (rh && (!have || better(rb, best))) { best = rb; bidx = ri; have = true; }
+        maxprod = std::max(maxprod, rp_);
+        done = target;
+        target = std::min<uint64_t>(std::max<uint64_t>(maxprod, done), budget);      // grow to the largest tree size seen so far
+    }
+    if (on_gpu) L.plan_destroy(plan);
+    if (!have) return false;
+    Ops rops; uint64_t pr = 1; std::string t = schedule_text(f, lM, bidx, rops, pr);
+    if (rops != best) { std::cerr << "# \033[1;31mERROR: -E replay of schedule " << bidx << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    const bool complete = maxprod <= done;
+    if (verbose > 0) {
+        std::clog << "# Found E: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[schedule " << bidx << "] ("
+                  << done << (complete ? " schedules: the whole tree" : " schedules of a tree of at least ") ;
+        if (!complete) std::clog << maxprod;
+        std::clog << (on_gpu ? ", GPU" : ", host");
+        if (on_gpu) std::clog << " kernel " << kms << " ms";
+        std::clog << ')' << std::endl;
+    }
+    if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                              // :1270-1274
+    else std::clog << "# \033[1;36mNo greedy CSE schedule has less additions.\033[0m" << std::endl;       // :1275-1278
+    return true;
+}
+
 template <class F>
 int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool tryDirect, bool tryKernel, bool tryLU,
         bool tryAB, bool mostCSE, bool allkernels, int verbose, uint32_t q, const char *argv0)
@@ -337,7 +410,10 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         catch (const std::exception &e) { std::clog << "# -G skipped: " << e.what() << std::endl; }
     }
     if (allkernels) std::clog << "# -N (exhaustive nullspace permutations) is not part of this build" << std::endl;
-    if (mostCSE) std::clog << "# -E (exhaustive CSE tree) is not part of this build (SURVEY.md 8f)" << std::endl;
+    if (mostCSE) {                                                                    // :1469-1471
+        try { exhaustive_method(f, lM, std::max<uint64_t>(loops, 1ull << 22), gpu, q, verbose, nbops, text, argv0); }
+        catch (const std::exception &e) { std::clog << "# -E skipped: " << e.what() << std::endl; }
+    }
 
     if (cmp_op_count(opsinit, nbops) || opsinit == nbops) {                           // :1473-1485
         std::ostringstream os;
@@ -373,7 +449,8 @@ int main(int argc, char **argv)
                       << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only\n"
                       << "  --seed #: first candidate seed (default 0)\n"
                       << "  -A: also try the alternative factorization M = Alt.CoB (inner dimension = column count)\n"
-                      << "  --only D|K|G|A: run exactly that method\n";
+                      << "  -E: also walk the exhaustive tree of greedy CSE schedules (bounded by max(-O, 2^22) schedules)\n"
+                      << "  --only D|K|G|A|E: run exactly that method\n";
             exit(-1);
         } else if (a == "-M") printMaple = true;
         else if (a == "-P") printPretty = true;
@@ -394,7 +471,7 @@ int main(int argc, char **argv)
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing
         else filename = a;
     }
-    if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = only == "K"; }
+    if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = only == "K"; mostCSE = only == "E"; }
     else if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
     (void)printMaple; (void)printPretty;
     try {

@@ -343,6 +343,11 @@ template <class F> class Replay {
     };
     struct Mult { size_t idx, col; E val; };
     const F &f; Mat M; CandRng own_rng; CandRng &rng; std::ostream &out;
+public:
+    // -E: the candidate is the schedule of index `erem` in RecSub's tree (mixed radix of its own path, include/plinopt_hip.h)
+    bool enumerate = false; uint64_t erem = 0, eprod = 1;
+    void set_schedule(uint64_t index) { enumerate = true; erem = index; eprod = 1; }
+private:
     char ouv, tev, rav;
     std::vector<Mult> multiples;
     size_t nbadd = 0, nbmul = 0;
@@ -406,8 +411,12 @@ template <class F> class Replay {
             }
             if (maxfrq <= 1) return good;
             good = true;
+            if (enumerate) { mx.clear(); for (auto &kv : PM) if (kv.second > 1) mx.push_back(kv.first); }      // RecSub :935-937: every pair of frequency > 1
             Tri cse = mx[0];
-            if (mx.size() > 1) cse = mx[rng.next() % mx.size()];
+            if (mx.size() > 1) {
+                if (enumerate) { cse = mx[erem % mx.size()]; erem /= mx.size(); eprod = eprod > UINT64_MAX / mx.size() ? UINT64_MAX : eprod * mx.size(); }
+                else cse = mx[rng.next() % mx.size()];
+            }
             ++nbadd;
             rem_one_cse(cse, AP, PM);
         }

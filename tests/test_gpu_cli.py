@@ -122,3 +122,32 @@ def test_kernel_method_on_gpu_equals_host_search(name):
     assert "# GPU (K): 2000 candidates on 8 decompositions" in err and out == out0
     rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2, err2
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "2x2x2_7_Winograd_P.sms", "2x2x2_7_DPS-accurate_L.sms"])
+def test_exhaustive_method_on_gpu_equals_host(name):
+    """-E: the schedules of RecSub's tree are candidates of the wave kernel (enumeration pick mode); same tree size,
+    same best schedule and program as the host walk."""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "E", path])
+    assert rc == 0, err
+    rc0, out0, err0 = run([OPT, "-q", str(P), "--only", "E", "--gpu", "0", path])
+    assert rc0 == 0, err0
+    pat = r"# Found E: (\d+)\|(\d+) instead of \d+\|\d+\t\[schedule (\d+)\] \((\d+) schedules: the whole tree"
+    g, g0 = re.search(pat, err), re.search(pat, err0)
+    assert g and g0 and g.groups() == g0.groups() and "GPU" in err, (err, err0)
+    assert out == out0
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+
+
+def test_exhaustive_method_is_bounded_on_a_large_tree():
+    """cyclic.sms has a tree of more than 8e8 schedules: -E stops at its budget (2^22 by default), says so, and still
+    prints a verified program."""
+    path = os.path.join(DATA, "cyclic.sms")
+    rc, out, err = run([OPT, "-q", str(P), "--only", "E", path])
+    assert rc == 0, err
+    g = re.search(r"# Found E: (\d+)\|(\d+) instead of 26\|0\t\[schedule (\d+)\] \(4194304 schedules of a tree of at least (\d+), GPU", err)
+    assert g and int(g.group(4)) > 4194304 and int(g.group(1)) <= 15, err
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2

@@ -266,3 +266,23 @@ def test_kernel_method_reports_a_zero_dimensional_kernel():
     assert rc == 0 and "Zero dimensional kernel" in err
     rc, _, err2 = run([CHK, "-q", str(P), "-M", os.path.join(DATA, "cyclic.sms")], stdin=out)
     assert rc == 0 and "SUCCESS" in err2                      # the direct program is printed instead (:1473-1485)
+
+
+@pytest.mark.parametrize("name,schedules,best", [("2x2x2_7_Winograd_L.sms", 3, (4, 0)), ("2x2x2_7_Winograd_R.sms", None, (4, 0)),
+                                                 ("2x2x2_7_Winograd_P.sms", 10, (7, 0)), ("2x2x2_7_DPS-accurate_L.sms", 180, None)])
+@pytest.mark.parametrize("field", ["Q", "p"])
+def test_exhaustive_method_walks_the_whole_tree_of_small_inputs(name, schedules, best, field):
+    """-E (AllCSEOpt / RecOptimizer / RecSub, plinopt_optimize.inl:889-1013, :1252-1281): every greedy CSE schedule of a
+    small input, addressed by index; the best program computes the matrix with the reported count."""
+    path = os.path.join(DATA, name)
+    q = ["-q", str(P), "--gpu", "0"] if field == "p" else []
+    rc, out, err = run([OPT, "--only", "E"] + q + [path])
+    assert rc == 0, err
+    g = re.search(r"# Found E: (\d+)\|(\d+) instead of \d+\|\d+\t\[schedule (\d+)\] \((\d+) schedules: the whole tree", err)
+    assert g, err
+    if schedules is not None:
+        assert int(g.group(4)) == schedules
+    if best is not None:
+        assert (int(g.group(1)), int(g.group(2))) == best
+    rc, _, err2 = run([CHK] + (["-q", str(P)] if field == "p" else []) + ["-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2 and ("%s,%s" % (g.group(1), g.group(2))) in err2, err2
