@@ -229,6 +229,33 @@ template <class F> std::string kernel_text(const F &f, const KernelDecomp<F> &kd
 // Optimizer calls on it (the reference draws a new decomposition for every restart; with a per-restart elimination on
 // the host the GPU would idle).  Returns false when the method could not run.
 #define PLO_KERNEL_BLOCK 256ull
+// restarts s0 .. s0+cnt-1 of the two Optimizer calls on one decomposition: GPU (chained-candidate kernel) or host loop
+template <class F> bool kernel_block(const F &f, const KernelDecomp<F> &kd, uint64_t s0, uint64_t cnt, HipLib *L, uint32_t q, Ops &bops, uint64_t &bs, double &kms, uint64_t &ncand) {
+    bool bhave = false;
+    if constexpr (std::is_same<F, ZpField>::value) if (L) {
+        std::vector<uint32_t> rp1, c1, v1, rp2, c2, v2;
+        to_csr(kd.Free, rp1, c1, v1); to_csr(kd.Dep, rp2, c2, v2);
+        plo_csr_t A{(uint32_t)kd.Free.rowdim(), (uint32_t)kd.Free.coldim(), rp1.data(), c1.data(), v1.data()};
+        plo_csr_t B{(uint32_t)kd.Dep.rowdim(), (uint32_t)kd.Dep.coldim(), rp2.data(), c2.data(), v2.data()};
+        plo_chain_t *ch = nullptr;
+        if (L->chain_create(&A, &B, q, &ch) != PLO_OK) throw std::runtime_error(std::string("chain plan: ") + L->last_error());
+        plo_best_t b{}; plo_stats_t st{};
+        const int rc = L->chain_search(ch, s0, cnt, PLO_COST_SUM_THEN_ADD, &b, &st);
+        L->chain_destroy(ch);
+        if (rc != PLO_OK) throw std::runtime_error(std::string("GPU search failed: ") + L->last_error());
+        bops = {b.adds, b.muls}; bs = b.seed; kms += st.kernel_ms; ncand += st.candidates;
+        return true;
+    }
+#pragma omp parallel for schedule(dynamic)
+    for (long long k = 0; k < (long long)cnt; ++k) {
+        Ops ops; (void)kernel_text(f, kd, s0 + (uint64_t)k, ops);
+#pragma omp critical
+        { uint64_t s = s0 + (uint64_t)k; if (!bhave || cmp_op_count(ops, bops) || (!cmp_op_count(bops, ops) && s < bs)) { bops = ops; bs = s; bhave = true; } }
+    }
+    (void)q;
+    return bhave;
+}
+
 template <class F> bool kernel_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
                                       int verbose, Ops &gops, std::string &gtext, const char *argv0) {
     uint64_t seed = 0, bdec = 0; Ops best; bool have = false; double kms = 0; uint64_t ncand = 0;
@@ -243,29 +270,10 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
         const uint64_t s0 = seed0 + d * PLO_KERNEL_BLOCK, cnt = std::min<uint64_t>(PLO_KERNEL_BLOCK, loops - d * PLO_KERNEL_BLOCK);
         KernelDecomp<F> kd;
         if (!kernel_decomp(f, lM, s0, kd)) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }   // :1343-1346
-        Ops bops; uint64_t bs = 0; bool bhave = false;
-        if constexpr (std::is_same<F, ZpField>::value) if (use_gpu) {
-            std::vector<uint32_t> rp1, c1, v1, rp2, c2, v2;
-            to_csr(kd.Free, rp1, c1, v1); to_csr(kd.Dep, rp2, c2, v2);
-            plo_csr_t A{(uint32_t)kd.Free.rowdim(), (uint32_t)kd.Free.coldim(), rp1.data(), c1.data(), v1.data()};
-            plo_csr_t B{(uint32_t)kd.Dep.rowdim(), (uint32_t)kd.Dep.coldim(), rp2.data(), c2.data(), v2.data()};
-            plo_chain_t *ch = nullptr;
-            int rc = L.chain_create(&A, &B, q, &ch);
-            if (rc != PLO_OK) { std::clog << "# -K skipped: " << L.last_error() << std::endl; return false; }
-            plo_best_t b{}; plo_stats_t st{};
-            rc = L.chain_search(ch, s0, cnt, PLO_COST_SUM_THEN_ADD, &b, &st);
-            L.chain_destroy(ch);
-            if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: -K GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
-            bops = {b.adds, b.muls}; bs = b.seed; bhave = true; kms += st.kernel_ms; ncand += st.candidates;
-        }
-        if (!bhave) {
-#pragma omp parallel for schedule(dynamic)
-            for (long long k = 0; k < (long long)cnt; ++k) {
-                Ops ops; (void)kernel_text(f, kd, s0 + (uint64_t)k, ops);
-#pragma omp critical
-                { uint64_t s = s0 + (uint64_t)k; if (!bhave || cmp_op_count(ops, bops) || (!cmp_op_count(bops, ops) && s < bs)) { bops = ops; bs = s; bhave = true; } }
-            }
-        }
+        Ops bops; uint64_t bs = 0;
+        bool bhave;
+        try { bhave = kernel_block(f, kd, s0, cnt, use_gpu ? &L : nullptr, q, bops, bs, kms, ncand); }
+        catch (const std::exception &e) { std::clog << "# -K skipped: " << e.what() << std::endl; return false; }
         if (bhave && (!have || cmp_op_count(bops, best))) { best = bops; seed = bs; bdec = s0; have = true; }      // earlier block wins ties
     }
     if (!have) return false;
@@ -277,6 +285,54 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     if (verbose > 0) std::clog << "# Found K: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed
                                << "] (rank " << kd.rank << '+' << kd.notindep << ", " << kd.dep.size() << " dependent rows)" << std::endl;
     if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                              // :1347-1351
+    return true;
+}
+
+// AllKernelOpt (-N, :1357-1418): every order of the rows (m <= 9 here: m! eliminations on the host; the reference allows 12).
+// Orders that give the same decomposition (same computed rows, same combinations) are searched once; the restarts are
+// shared out between the distinct decompositions.
+template <class F> bool allkernels_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
+                                          int verbose, Ops &gops, std::string &gtext, const char *argv0) {
+    const size_t m = lM.rowdim();
+    if (m > 9) { std::clog << "# -N skipped: " << m << "! row orders (this build walks up to 9!)" << std::endl; return false; }
+    std::vector<size_t> ord(m);
+    for (size_t i = 0; i < m; ++i) ord[i] = i;
+    std::map<std::vector<size_t>, std::pair<std::vector<size_t>, uint64_t>> distinct;     // signature -> (order, permutation index)
+    uint64_t pi = 0;
+    do {
+        KernelDecomp<F> kd; CandRng rng(seed0 + pi);
+        if (!kernel_decomp_order(f, lM, ord, rng, kd)) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }
+        std::vector<size_t> sig(kd.dep); sig.push_back(m + kd.notindep);
+        for (auto &r : kd.Dep.rows) for (auto &e : r) sig.push_back(e.first);             // the basis rows used
+        distinct.emplace(sig, std::make_pair(ord, pi));
+        ++pi;
+    } while (std::next_permutation(ord.begin(), ord.end()));
+    bool use_gpu = false; HipLib L;
+    if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -N: cannot use the GPU\033[0m" << std::endl; return false; }
+        use_gpu = true;
+    }
+    const uint64_t per = std::max<uint64_t>(1, loops / distinct.size());
+    Ops best; uint64_t seed = 0, bpi = 0; std::vector<size_t> bord; bool have = false; double kms = 0; uint64_t ncand = 0, j = 0;
+    for (auto &kv : distinct) {
+        KernelDecomp<F> kd; CandRng rng(seed0 + kv.second.second);
+        kernel_decomp_order(f, lM, kv.second.first, rng, kd);
+        Ops bops; uint64_t bs = 0; bool bhave;
+        try { bhave = kernel_block(f, kd, seed0 + j * per, per, use_gpu ? &L : nullptr, q, bops, bs, kms, ncand); }
+        catch (const std::exception &e) { std::clog << "# -N skipped: " << e.what() << std::endl; return false; }
+        if (bhave && (!have || cmp_op_count(bops, best))) { best = bops; seed = bs; bord = kv.second.first; bpi = kv.second.second; have = true; }
+        ++j;
+    }
+    if (!have) return false;
+    KernelDecomp<F> kd; CandRng rng(seed0 + bpi);
+    kernel_decomp_order(f, lM, bord, rng, kd);
+    Ops rops; std::string t = kernel_text(f, kd, seed, rops);
+    if (rops != best) { std::cerr << "# \033[1;31mERROR: -N replay gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (verbose > 0) std::clog << "# Found N: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[order " << bpi << ", seed " << seed << "] ("
+                               << pi << " row orders, " << distinct.size() << " distinct decompositions, " << per << " restarts each" << (use_gpu ? ", GPU kernel " : ", host ") ;
+    if (verbose > 0) { if (use_gpu) std::clog << kms << " ms"; std::clog << ')' << std::endl; }
+    if (cmp_op_count(best, gops)) { gops = best; gtext = t; }
+    else std::clog << "# \033[1;36mNo kernel permutation has less additions.\033[0m" << std::endl;        // :1409-1413
     return true;
 }
 
@@ -409,7 +465,10 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         try { lu_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
         catch (const std::exception &e) { std::clog << "# -G skipped: " << e.what() << std::endl; }
     }
-    if (allkernels) std::clog << "# -N (exhaustive nullspace permutations) is not part of this build" << std::endl;
+    if (allkernels) {                                                                 // :1463-1465
+        try { allkernels_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
+        catch (const std::exception &e) { std::clog << "# -N skipped: " << e.what() << std::endl; }
+    }
     if (mostCSE) {                                                                    // :1469-1471
         try { exhaustive_method(f, lM, std::max<uint64_t>(loops, 1ull << 22), gpu, q, verbose, nbops, text, argv0); }
         catch (const std::exception &e) { std::clog << "# -E skipped: " << e.what() << std::endl; }
@@ -450,7 +509,7 @@ int main(int argc, char **argv)
                       << "  --seed #: first candidate seed (default 0)\n"
                       << "  -A: also try the alternative factorization M = Alt.CoB (inner dimension = column count)\n"
                       << "  -E: also walk the exhaustive tree of greedy CSE schedules (bounded by max(-O, 2^22) schedules)\n"
-                      << "  --only D|K|G|A|E: run exactly that method\n";
+                      << "  --only D|K|G|A|E|N: run exactly that method\n";
             exit(-1);
         } else if (a == "-M") printMaple = true;
         else if (a == "-P") printPretty = true;
@@ -471,7 +530,7 @@ int main(int argc, char **argv)
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing
         else filename = a;
     }
-    if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = only == "K"; mostCSE = only == "E"; }
+    if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = only == "K"; mostCSE = only == "E"; allkernels = only == "N"; }
     else if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
     (void)printMaple; (void)printPretty;
     try {

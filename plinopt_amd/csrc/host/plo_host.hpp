@@ -713,13 +713,19 @@ template <class F> struct KernelDecomp {
     std::vector<size_t> dep;                  // row of M computed by row j of Dep
     size_t rank = 0, notindep = 0;
 };
+template <class F> bool kernel_decomp_order(const F &f, const SparseMat<typename F::Elt> &M, const std::vector<size_t> &ord, CandRng &rng, KernelDecomp<F> &out);
 template <class F> bool kernel_decomp(const F &f, const SparseMat<typename F::Elt> &M, uint64_t seed, KernelDecomp<F> &out) {
-    using E = typename F::Elt;
-    const size_t m = M.rowdim(), n = M.coldim();
+    const size_t m = M.rowdim();
     std::vector<size_t> ord(m);
     for (size_t i = 0; i < m; ++i) ord[i] = i;
     CandRng rng(seed);
     for (size_t i = m; i > 1; --i) std::swap(ord[i - 1], ord[rng.next() % (uint32_t)i]);
+    return kernel_decomp_order(f, M, ord, rng, out);
+}
+// the same with a prescribed order of the rows (-N, AllKernelOpt :1357-1418 walks all of them)
+template <class F> bool kernel_decomp_order(const F &f, const SparseMat<typename F::Elt> &M, const std::vector<size_t> &ord, CandRng &rng, KernelDecomp<F> &out) {
+    using E = typename F::Elt;
+    const size_t m = M.rowdim(), n = M.coldim();
     std::vector<std::vector<E>> ech, comb; std::vector<size_t> piv, basis, deps;
     std::vector<std::vector<E>> depx;
     for (size_t t = 0; t < m; ++t) {

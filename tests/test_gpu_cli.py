@@ -151,3 +151,18 @@ def test_exhaustive_method_is_bounded_on_a_large_tree():
     assert g and int(g.group(4)) > 4194304 and int(g.group(1)) <= 15, err
     rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2, err2
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms"])
+def test_all_row_orders_on_gpu_equals_host(name):
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "N", "-O", "4000", path])
+    assert rc == 0, err
+    rc0, out0, err0 = run([OPT, "-q", str(P), "--only", "N", "-O", "4000", "--gpu", "0", path])
+    assert rc0 == 0, err0
+    pat = r"# Found N: (\d+)\|(\d+) instead of \d+\|\d+\t\[order (\d+), seed (\d+)\] \((\d+) row orders, (\d+) distinct decompositions, (\d+) restarts each"
+    g, g0 = re.search(pat, err), re.search(pat, err0)
+    assert g and g0 and g.groups() == g0.groups() and "GPU kernel" in err, (err, err0)
+    assert out == out0
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2

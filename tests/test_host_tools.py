@@ -286,3 +286,16 @@ def test_exhaustive_method_walks_the_whole_tree_of_small_inputs(name, schedules,
         assert (int(g.group(1)), int(g.group(2))) == best
     rc, _, err2 = run([CHK] + (["-q", str(P)] if field == "p" else []) + ["-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2 and ("%s,%s" % (g.group(1), g.group(2))) in err2, err2
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms", "2x2x2_7_Strassen_R.sms"])
+def test_all_row_orders_of_the_kernel_method(name):
+    """-N (AllKernelOpt, plinopt_optimize.inl:1357-1418): every order of the 7 rows (5040), distinct decompositions searched
+    once; the program computes the matrix."""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "--only", "N", "-q", str(P), "--gpu", "0", "-O", "1000", path])
+    assert rc == 0, err
+    g = re.search(r"# Found N: (\d+)\|(\d+) instead of \d+\|\d+\t\[order (\d+), seed (\d+)\] \(5040 row orders, (\d+) distinct decompositions", err)
+    assert g and 1 < int(g.group(5)) < 5040, err
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
