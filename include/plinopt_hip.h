@@ -112,6 +112,14 @@ int plo_cse_chain_search(plo_chain_t *chain, uint64_t seed0, uint64_t nseeds, in
 int plo_cse_chain_cost_many(plo_chain_t *chain, const uint64_t *seeds, uint64_t seed0, uint64_t n,
                             uint32_t *adds, uint32_t *muls, plo_stats_t *stats);
 
+/* The same chained evaluation for MANY pairs in one launch: candidate c (0 <= c < npairs*per_pair) runs on pair c / per_pair with
+ * seed seed0 + c.  The kernel method (nullspacedecomp :689-884) has a different pair (Free, Dep) for every restart, or small
+ * block of restarts; one plan + one launch per pair would leave the GPU idle.  adds/muls (npairs*per_pair entries) and best
+ * may each be NULL.  With PLO_COST_SUM the split of the winner is not returned (best->adds = the sum). */
+int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_t *seconds, uint32_t p, uint64_t seed0, uint32_t per_pair,
+                        int cost_mode, uint32_t *adds, uint32_t *muls, plo_best_t *best, plo_stats_t *stats);
+
+
 /* Change-of-basis (CoB) search of bin/sparsifier: one (block,row) enumeration of `localSparsifier`,
  * include/plinopt_sparsify.inl:282-314, i.e. |coeffs|^4 calls of `testLinComb` (:167-197).  TM is the n x m
  * matrix being sparsified (dense, row major, residues mod p), Cand the n x n matrix whose rows 0..row-1 are the

@@ -40,6 +40,7 @@ struct HipLib {
     decltype(&plo_cse_plan_create) plan_create = nullptr;
     decltype(&plo_cse_plan_destroy) plan_destroy = nullptr;
     decltype(&plo_cse_enum_search_plan) enum_search = nullptr;
+    decltype(&plo_cse_chain_batch) chain_batch = nullptr;
     bool load(const char *argv0) {
         std::vector<std::string> cand;
         if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
@@ -55,7 +56,8 @@ struct HipLib {
         chain_destroy = (decltype(chain_destroy))dlsym(h, "plo_cse_chain_destroy");
         plan_create = (decltype(plan_create))dlsym(h, "plo_cse_plan_create"); plan_destroy = (decltype(plan_destroy))dlsym(h, "plo_cse_plan_destroy");
         enum_search = (decltype(enum_search))dlsym(h, "plo_cse_enum_search_plan");
-        return init && last_error && cse_search && shutdown && chain_create && chain_search && chain_destroy && plan_create && plan_destroy && enum_search;
+        chain_batch = (decltype(chain_batch))dlsym(h, "plo_cse_chain_batch");
+        return init && last_error && cse_search && shutdown && chain_create && chain_search && chain_destroy && plan_create && plan_destroy && enum_search && chain_batch;
     }
 };
 
@@ -228,8 +230,16 @@ template <class F> std::string kernel_text(const F &f, const KernelDecomp<F> &kd
 // seeds: block d uses the decomposition drawn from its first seed, and every seed of the block is one run of the two
 // Optimizer calls on it (the reference draws a new decomposition for every restart; with a per-restart elimination on
 // the host the GPU would idle).  Returns false when the method could not run.
-#define PLO_KERNEL_BLOCK 256ull
+#define PLO_KERNEL_BLOCK 16ull
 // restarts s0 .. s0+cnt-1 of the two Optimizer calls on one decomposition: GPU (chained-candidate kernel) or host loop
+template <class F> bool kernel_block_serial(const F &f, const KernelDecomp<F> &kd, uint64_t s0, uint64_t cnt, Ops &bops, uint64_t &bs) {
+    bool have = false;
+    for (uint64_t k = 0; k < cnt; ++k) {
+        Ops ops; (void)kernel_text(f, kd, s0 + k, ops);
+        if (!have || cmp_op_count(ops, bops)) { bops = ops; bs = s0 + k; have = true; }        // increasing seeds: the first one keeps ties
+    }
+    return have;
+}
 template <class F> bool kernel_block(const F &f, const KernelDecomp<F> &kd, uint64_t s0, uint64_t cnt, HipLib *L, uint32_t q, Ops &bops, uint64_t &bs, double &kms, uint64_t &ncand) {
     bool bhave = false;
     if constexpr (std::is_same<F, ZpField>::value) if (L) {
@@ -256,6 +266,27 @@ template <class F> bool kernel_block(const F &f, const KernelDecomp<F> &kd, uint
     return bhave;
 }
 
+
+// restarts of many decompositions in ONE launch (plo_cse_chain_batch): decomposition j takes the seeds s0 + j*per .. + per - 1
+template <class F> bool kernel_batch_gpu(HipLib &L, const std::vector<KernelDecomp<F>> &kds, uint64_t s0, uint32_t per, uint32_t q,
+                                         Ops &bops, uint64_t &bs, double &kms, uint64_t &ncand) {
+    if constexpr (std::is_same<F, ZpField>::value) {
+        const size_t np = kds.size();
+        std::vector<std::vector<uint32_t>> rp(2 * np), cc(2 * np), vv(2 * np);
+        std::vector<plo_csr_t> A(np), B(np);
+        for (size_t j = 0; j < np; ++j) {
+            to_csr(kds[j].Free, rp[2 * j], cc[2 * j], vv[2 * j]); to_csr(kds[j].Dep, rp[2 * j + 1], cc[2 * j + 1], vv[2 * j + 1]);
+            A[j] = plo_csr_t{(uint32_t)kds[j].Free.rowdim(), (uint32_t)kds[j].Free.coldim(), rp[2 * j].data(), cc[2 * j].data(), vv[2 * j].data()};
+            B[j] = plo_csr_t{(uint32_t)kds[j].Dep.rowdim(), (uint32_t)kds[j].Dep.coldim(), rp[2 * j + 1].data(), cc[2 * j + 1].data(), vv[2 * j + 1].data()};
+        }
+        plo_best_t b{}; plo_stats_t st{};
+        if (L.chain_batch((uint32_t)np, A.data(), B.data(), q, s0, per, PLO_COST_SUM_THEN_ADD, nullptr, nullptr, &b, &st) != PLO_OK)
+            throw std::runtime_error(std::string("batched chain search: ") + L.last_error());
+        bops = {b.adds, b.muls}; bs = b.seed; kms += st.kernel_ms; ncand += st.candidates;
+        return true;
+    } else { (void)L; (void)kds; (void)s0; (void)per; (void)q; (void)bops; (void)bs; (void)kms; (void)ncand; return false; }
+}
+
 template <class F> bool kernel_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
                                       int verbose, Ops &gops, std::string &gtext, const char *argv0) {
     uint64_t seed = 0, bdec = 0; Ops best; bool have = false; double kms = 0; uint64_t ncand = 0;
@@ -266,13 +297,42 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
         if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -K: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
         use_gpu = true;
     }
-    for (uint64_t d = 0; d < nblocks; ++d) {
+    const uint64_t full = loops / PLO_KERNEL_BLOCK;                    // full blocks go to the GPU in batches of one launch each
+    const uint64_t BATCH = 4096;
+    uint64_t d = 0;
+    if (use_gpu) for (; d < full; ) {
+        const uint64_t nb = std::min<uint64_t>(BATCH, full - d), s0 = seed0 + d * PLO_KERNEL_BLOCK;
+        std::vector<KernelDecomp<F>> kds(nb); bool zero = false;
+#pragma omp parallel for schedule(dynamic, 8)
+        for (long long j = 0; j < (long long)nb; ++j) if (!kernel_decomp(f, lM, s0 + (uint64_t)j * PLO_KERNEL_BLOCK, kds[(size_t)j])) zero = true;
+        if (zero) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }              // :1343-1346
+        Ops bops; uint64_t bs = 0;
+        try { kernel_batch_gpu(L, kds, s0, (uint32_t)PLO_KERNEL_BLOCK, q, bops, bs, kms, ncand); }
+        catch (const std::exception &e) { std::clog << "# -K skipped: " << e.what() << std::endl; return false; }
+        if (!have || cmp_op_count(bops, best)) { best = bops; seed = bs; bdec = seed0 + ((bs - seed0) / PLO_KERNEL_BLOCK) * PLO_KERNEL_BLOCK; have = true; }
+        d += nb;
+    }
+    if (!use_gpu) {                                                    // host path: the blocks are shared out between the threads
+        bool zero = false;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long long dd = (long long)d; dd < (long long)nblocks; ++dd) {
+            const uint64_t s0 = seed0 + (uint64_t)dd * PLO_KERNEL_BLOCK, cnt = std::min<uint64_t>(PLO_KERNEL_BLOCK, loops - (uint64_t)dd * PLO_KERNEL_BLOCK);
+            KernelDecomp<F> kd; Ops bops; uint64_t bs = 0;
+            if (!kernel_decomp(f, lM, s0, kd)) { zero = true; continue; }
+            const bool bhave = kernel_block_serial(f, kd, s0, cnt, bops, bs);
+#pragma omp critical
+            if (bhave && (!have || cmp_op_count(bops, best) || (!cmp_op_count(best, bops) && bs < seed))) { best = bops; seed = bs; bdec = s0; have = true; }
+        }
+        if (zero) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }              // :1343-1346
+        d = nblocks;
+    }
+    for (; d < nblocks; ++d) {                                         // GPU: the last partial block
         const uint64_t s0 = seed0 + d * PLO_KERNEL_BLOCK, cnt = std::min<uint64_t>(PLO_KERNEL_BLOCK, loops - d * PLO_KERNEL_BLOCK);
         KernelDecomp<F> kd;
         if (!kernel_decomp(f, lM, s0, kd)) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }   // :1343-1346
         Ops bops; uint64_t bs = 0;
         bool bhave;
-        try { bhave = kernel_block(f, kd, s0, cnt, use_gpu ? &L : nullptr, q, bops, bs, kms, ncand); }
+        try { bhave = kernel_block(f, kd, s0, cnt, &L, q, bops, bs, kms, ncand); }
         catch (const std::exception &e) { std::clog << "# -K skipped: " << e.what() << std::endl; return false; }
         if (bhave && (!have || cmp_op_count(bops, best))) { best = bops; seed = bs; bdec = s0; have = true; }      // earlier block wins ties
     }
@@ -313,15 +373,28 @@ template <class F> bool allkernels_method(const F &f, const SparseMat<typename F
         use_gpu = true;
     }
     const uint64_t per = std::max<uint64_t>(1, loops / distinct.size());
-    Ops best; uint64_t seed = 0, bpi = 0; std::vector<size_t> bord; bool have = false; double kms = 0; uint64_t ncand = 0, j = 0;
-    for (auto &kv : distinct) {
-        KernelDecomp<F> kd; CandRng rng(seed0 + kv.second.second);
-        kernel_decomp_order(f, lM, kv.second.first, rng, kd);
-        Ops bops; uint64_t bs = 0; bool bhave;
-        try { bhave = kernel_block(f, kd, seed0 + j * per, per, use_gpu ? &L : nullptr, q, bops, bs, kms, ncand); }
+    Ops best; uint64_t seed = 0, bpi = 0; std::vector<size_t> bord; bool have = false; double kms = 0; uint64_t ncand = 0;
+    std::vector<const std::pair<const std::vector<size_t>, std::pair<std::vector<size_t>, uint64_t>> *> order;
+    for (auto &kv : distinct) order.push_back(&kv);
+    if (use_gpu) {                                                   // all distinct decompositions in one launch
+        std::vector<KernelDecomp<F>> kds(order.size());
+        for (size_t k = 0; k < order.size(); ++k) { CandRng rng(seed0 + order[k]->second.second); kernel_decomp_order(f, lM, order[k]->second.first, rng, kds[k]); }
+        Ops bops; uint64_t bs = 0;
+        try { kernel_batch_gpu(L, kds, seed0, (uint32_t)per, q, bops, bs, kms, ncand); }
         catch (const std::exception &e) { std::clog << "# -N skipped: " << e.what() << std::endl; return false; }
-        if (bhave && (!have || cmp_op_count(bops, best))) { best = bops; seed = bs; bord = kv.second.first; bpi = kv.second.second; have = true; }
-        ++j;
+        const size_t w = (size_t)((bs - seed0) / per);
+        best = bops; seed = bs; bord = order[w]->second.first; bpi = order[w]->second.second; have = true;
+    } else {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long long k = 0; k < (long long)order.size(); ++k) {
+            const auto &kv = *order[(size_t)k];
+            KernelDecomp<F> kd; CandRng rng(seed0 + kv.second.second);
+            kernel_decomp_order(f, lM, kv.second.first, rng, kd);
+            Ops bops; uint64_t bs = 0;
+            const bool bhave = kernel_block_serial(f, kd, seed0 + (uint64_t)k * per, per, bops, bs);
+#pragma omp critical
+            if (bhave && (!have || cmp_op_count(bops, best) || (!cmp_op_count(best, bops) && bs < seed))) { best = bops; seed = bs; bord = kv.second.first; bpi = kv.second.second; have = true; }
+        }
     }
     if (!have) return false;
     KernelDecomp<F> kd; CandRng rng(seed0 + bpi);
@@ -530,6 +603,7 @@ int main(int argc, char **argv)
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing
         else filename = a;
     }
+    if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
     if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = only == "K"; mostCSE = only == "E"; allkernels = only == "N"; }
     else if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
     (void)printMaple; (void)printPretty;

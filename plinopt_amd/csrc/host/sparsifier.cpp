@@ -13,6 +13,7 @@
 
 #include <chrono>
 #include <dlfcn.h>
+#include <omp.h>
 #include <libgen.h>
 #include <unistd.h>
 
@@ -106,6 +107,7 @@ template <class F> int tsparsifier(const F &f, const SparseMat<typename F::Elt> 
 
 int main(int argc, char **argv)
 {
+    if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
     Fmt fmt = PRETTY; std::string filename; size_t maxnumcoeff = 11, blocksize = 4; bool initialElimination = true; uint64_t q = 0; int gpu = 1;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);

@@ -55,6 +55,7 @@ ICsr icsr(const QMat &M) {
 } // namespace
 
 int main(int argc, char **argv) {
+    if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
     size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; std::vector<std::string> files;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);

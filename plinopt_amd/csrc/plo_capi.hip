@@ -15,6 +15,8 @@
 #include "../../include/plinopt_hip.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -67,7 +69,8 @@ struct plo_plan {
 
 namespace {
 
-int build_plan(plo_plan *pl)
+// img_out != nullptr: host part only (the template image and the plan fields; P.tmpl is left for the caller)
+int build_plan(plo_plan *pl, std::vector<uint8_t> *img_out = nullptr)
 {
     const uint32_t m = pl->m, n = pl->n, p = pl->p;
     const auto &rowptr = pl->rowptr; const auto &col = pl->col; const auto &val = pl->val;
@@ -168,6 +171,7 @@ int build_plan(plo_plan *pl)
     }
     pl->waves_per_wg = W; pl->lds_bytes = P.rs_bytes + W * P.region_bytes;
 
+    if (img_out) { *img_out = std::move(img); return PLO_OK; }
     if (pl->d_tmpl) { (void)hipFree(pl->d_tmpl); pl->d_tmpl = nullptr; }
     HIPCHK(hipMalloc(&pl->d_tmpl, img.size()));
     HIPCHK(hipMemcpy(pl->d_tmpl, img.data(), img.size(), hipMemcpyHostToDevice));
@@ -756,6 +760,103 @@ int plo_cse_chain_create(const plo_csr_t *first, const plo_csr_t *second, uint32
     if (rc != PLO_OK) { plo_cse_chain_destroy(ch); return rc; }
     *out = ch;
     return PLO_OK;
+}
+
+// Many pairs in one launch (plo::cse_chain_batch_kernel): candidate c = pair c / per_pair, seed seed0 + c.
+int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_t *seconds, uint32_t p, uint64_t seed0, uint32_t per_pair,
+                        int cost_mode, uint32_t *adds, uint32_t *muls, plo_best_t *best, plo_stats_t *st)
+{
+    if (!firsts || !seconds || npairs == 0 || per_pair == 0) return fail(PLO_E_ARG, "bad argument");
+    if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
+    if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
+    if (p < 3 || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime");
+    const uint64_t ncand = (uint64_t)npairs * per_pair;
+    if (ncand > 0xFFFFFFFFull) return fail(PLO_E_ARG, "at most 2^32-1 candidates per call");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (best) { best->adds = best->muls = 0xFFFFFFFFu; best->seed = ~0ull; }
+    for (uint32_t cap_scale = 2; cap_scale <= 16; cap_scale *= 2) {
+        // host part of all plans (OpenMP), one device buffer for all images
+        std::vector<plo::WavePlan> plans(2ull * npairs);
+        std::vector<std::vector<uint8_t>> imgs(2ull * npairs);
+        std::vector<int> rcs(2ull * npairs, PLO_OK); std::vector<std::string> errs(2ull * npairs);
+        {   // host threads share the plans out (no OpenMP runtime in this library: the callers bring their own)
+            std::atomic<long long> next{0};
+            auto work = [&]() {
+                for (;;) {
+                    const long long k = next.fetch_add(1);
+                    if (k >= 2ll * npairs) break;
+                    const plo_csr_t *A = (k & 1) ? &seconds[k >> 1] : &firsts[k >> 1];
+                    plo_plan tmp; tmp.m = A->m; tmp.n = A->n; tmp.p = p; tmp.cap_scale = cap_scale;
+                    if (!A->rowptr || (A->rowptr[A->m] && (!A->col || !A->val))) { rcs[k] = PLO_E_ARG; errs[k] = "null matrix arrays"; continue; }
+                    tmp.rowptr.assign(A->rowptr, A->rowptr + A->m + 1);
+                    tmp.col.assign(A->col, A->col + A->rowptr[A->m]); tmp.val.assign(A->val, A->val + A->rowptr[A->m]);
+                    rcs[k] = build_plan(&tmp, &imgs[k]);
+                    if (rcs[k] != PLO_OK) errs[k] = g_err; else plans[k] = tmp.P;
+                }
+            };
+            const unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), std::min<unsigned>(64u, npairs)));
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+            work();
+            for (auto &th : pool) th.join();
+        }
+        for (size_t k = 0; k < rcs.size(); ++k) if (rcs[k] != PLO_OK) return fail(rcs[k], "pair " + std::to_string(k >> 1) + ": " + errs[k]);
+        uint32_t region = 0, rsmax = 0; size_t total = 0; std::vector<size_t> offs(imgs.size());
+        for (size_t k = 0; k < imgs.size(); ++k) { region = std::max(region, plans[k].region_bytes); rsmax = std::max(rsmax, plans[k].rs_bytes); offs[k] = total; total += round_up((uint32_t)imgs[k].size(), 64); }
+        uint32_t W = 0, lds = 0;
+        for (uint32_t w : {4u, 2u, 1u}) { const uint32_t l = 64u + w * (2u * rsmax + region); if (l <= g_lds_max) { W = w; lds = l; break; } }
+        if (!W) return fail(PLO_E_CAPACITY, "chained candidate state does not fit LDS");
+        uint8_t *d_img = nullptr; plo::WavePlan *d_plans = nullptr; uint32_t *d_adds = nullptr, *d_muls = nullptr, *d_err = nullptr; unsigned long long *d_best = nullptr;
+        std::vector<uint8_t> blob(total + 64, 0);
+        for (size_t k = 0; k < imgs.size(); ++k) std::memcpy(blob.data() + offs[k], imgs[k].data(), imgs[k].size());
+        auto cleanup = [&]() { if (d_img) (void)hipFree(d_img); if (d_plans) (void)hipFree(d_plans); if (d_adds) (void)hipFree(d_adds); if (d_muls) (void)hipFree(d_muls); if (d_err) (void)hipFree(d_err); if (d_best) (void)hipFree(d_best); };
+#define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PLO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+        BCHK(hipMalloc((void **)&d_img, blob.size()));
+        BCHK(hipMemcpy(d_img, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        for (size_t k = 0; k < plans.size(); ++k) plans[k].tmpl = (const uint64_t *)(d_img + offs[k]);
+        BCHK(hipMalloc((void **)&d_plans, plans.size() * sizeof(plo::WavePlan)));
+        BCHK(hipMemcpy(d_plans, plans.data(), plans.size() * sizeof(plo::WavePlan), hipMemcpyHostToDevice));
+        BCHK(hipMalloc((void **)&d_err, 4)); BCHK(hipMemset(d_err, 0, 4));
+        BCHK(hipMalloc((void **)&d_best, 8)); BCHK(hipMemset(d_best, 0xFF, 8));
+        if (adds) BCHK(hipMalloc((void **)&d_adds, ncand * 4));
+        if (muls) BCHK(hipMalloc((void **)&d_muls, ncand * 4));
+        BCHK(hipFuncSetAttribute((const void *)plo::cse_chain_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nb = 0;
+        BCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)plo::cse_chain_batch_kernel, (int)(W * 64), lds));
+        const uint64_t need = (ncand + W - 1) / W;
+        const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g_cus * std::max(nb, 1), need));
+        plo::WaveJob J{}; J.seed0 = seed0; J.seeds = nullptr; J.ncand = ncand; J.adds = d_adds; J.muls = d_muls; J.best = best ? d_best : nullptr; J.cost_mode = (uint32_t)cost_mode; J.err = d_err;
+        hipEvent_t e0, e1;
+        BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
+        BCHK(hipEventRecord(e0, g_stream));
+        hipLaunchKernelGGL(plo::cse_chain_batch_kernel, dim3((uint32_t)grid), dim3(W * 64), lds, g_stream, (const plo::WavePlan *)d_plans, per_pair, region, rsmax, J);
+        BCHK(hipGetLastError());
+        BCHK(hipEventRecord(e1, g_stream)); BCHK(hipEventSynchronize(e1));
+        float ms = 0; BCHK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        uint32_t err = 0; unsigned long long w = 0;
+        BCHK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+        st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = lds; st->waves_per_wg = W; st->candidates = ncand;
+        if (err == plo::ERR_TABLE) { cleanup(); continue; }                         // a pair table filled up: all plans again with twice the slots
+        if (err) { cleanup(); return device_error((int)err); }
+        if (adds) BCHK(hipMemcpy(adds, d_adds, ncand * 4, hipMemcpyDeviceToHost));
+        if (muls) BCHK(hipMemcpy(muls, d_muls, ncand * 4, hipMemcpyDeviceToHost));
+        if (best) {
+            BCHK(hipMemcpy(&w, d_best, 8, hipMemcpyDeviceToHost));
+            const uint64_t key = w >> 32, off = w & 0xFFFFFFFFull;
+            uint32_t a = 0, mu = 0;
+            if (cost_mode == PLO_COST_SUM_THEN_ADD) { a = (uint32_t)(key & 0xFFFFu); mu = (uint32_t)(key >> 16) - a; }
+            else if (cost_mode == PLO_COST_ADD_THEN_MUL) { a = (uint32_t)(key >> 16); mu = (uint32_t)(key & 0xFFFFu); }
+            else { a = (uint32_t)key; mu = 0; }                                     // sum only: reported in .adds
+            best->adds = a; best->muls = mu; best->seed = seed0 + off;
+        }
+#undef BCHK
+        cleanup();
+        st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return PLO_OK;
+    }
+    return device_error(plo::ERR_TABLE);
 }
 
 int plo_cse_chain_cost_many(plo_chain_t *ch, const uint64_t *seeds, uint64_t seed0, uint64_t n,

@@ -685,4 +685,54 @@ __global__ __launch_bounds__(256) void cse_chain_kernel(WavePlan P1, WavePlan P2
 template __global__ void cse_wave_kernel<true>(WavePlan, WaveJob);
 template __global__ void cse_wave_kernel<false>(WavePlan, WaveJob);
 
+
+// The same chain for MANY pairs of matrices in one launch: candidate c runs on pair c / per (the kernel method draws a
+// decomposition -- hence a pair (Free, Dep) -- per restart or per small block of restarts; one launch per pair leaves the
+// GPU idle).  plans[2q], plans[2q+1] are the plans of pair q in global memory; their templates carry the row starts behind
+// the image, which each wave stages in its own LDS region because the pair changes with the candidate.
+__global__ __launch_bounds__(256) void cse_chain_batch_kernel(const WavePlan *plans, uint32_t per, uint32_t region, uint32_t rsmax, WaveJob J)
+{
+    extern __shared__ uint64_t lds64[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint8_t *base = (uint8_t *)lds64 + 64u + (size_t)wave * (2u * rsmax + region);      // first 64 bytes: the reduction scratch
+    uint16_t *rs1 = (uint16_t *)base, *rs2 = (uint16_t *)(base + rsmax);
+    uint8_t *reg = base + 2u * rsmax;
+    uint64_t best = ~0ull;
+    const uint64_t stride = (uint64_t)gridDim.x * nwaves;
+    for (uint64_t c = (uint64_t)blockIdx.x * nwaves + wave; c < J.ncand; c += stride) {
+        const uint64_t q = c / per;
+        const WavePlan &P1 = plans[2u * q], &P2 = plans[2u * q + 1u];
+        const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
+        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull};
+        const uint32_t tw1 = P1.tmpl_bytes >> 3, tw2 = P2.tmpl_bytes >> 3, rw1 = P1.rs_bytes >> 3, rw2 = P2.rs_bytes >> 3;
+        for (uint32_t i = lane; i < rw1; i += 64u) ((uint64_t *)rs1)[i] = P1.tmpl[tw1 + i];
+        for (uint32_t i = lane; i < rw2; i += 64u) ((uint64_t *)rs2)[i] = P2.tmpl[tw2 + i];
+        for (uint32_t i = lane; i < tw1; i += 64u) ((uint64_t *)reg)[i] = P1.tmpl[i];
+        PLO_WAVE_SYNC();
+        const uint64_t r1 = P1.unit ? run_candidate<true>(P1, reg, rs1, ps, lane, J.err) : run_candidate<false>(P1, reg, rs1, ps, lane, J.err);
+        PLO_WAVE_SYNC();
+        for (uint32_t i = lane; i < tw2; i += 64u) ((uint64_t *)reg)[i] = P2.tmpl[i];
+        PLO_WAVE_SYNC();
+        const uint64_t r2 = P2.unit ? run_candidate<true>(P2, reg, rs2, ps, lane, J.err) : run_candidate<false>(P2, reg, rs2, ps, lane, J.err);
+        const uint32_t a = (uint32_t)(r1 >> 32) + (uint32_t)(r2 >> 32), mu_ = (uint32_t)r1 + (uint32_t)r2;
+        if (lane == 0) {
+            if (J.adds) J.adds[c] = a;
+            if (J.muls) J.muls[c] = mu_;
+        }
+        const uint64_t packed = ((uint64_t)cost_key32(a, mu_, J.cost_mode) << 32) | (uint32_t)c;
+        best = packed < best ? packed : best;
+        PLO_WAVE_SYNC();
+    }
+    if (J.best) {
+        __syncthreads();
+        if (lane == 0) lds64[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = lds64[0];
+            for (uint32_t w = 1; w < nwaves; ++w) b = lds64[w] < b ? lds64[w] : b;
+            if (b != ~0ull) atomicMin(J.best, (unsigned long long)b);
+        }
+    }
+}
+
 } // namespace plo

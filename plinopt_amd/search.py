@@ -138,6 +138,24 @@ class CSEChain:
         return b.adds, b.muls, b.seed
 
 
+def chain_batch(pairs, p, seed0, per_pair, cost_mode=capi.COST_SUM_THEN_ADD, want_costs=True):
+    """Many chained pairs in one launch (`plo_cse_chain_batch`): pairs = [((m,n,rowptr,col,val), (m,n,rowptr,col,val)), ...];
+    candidate c runs on pair c // per_pair with seed seed0 + c.  Returns (adds, muls, (best adds, best muls, best seed), stats)."""
+    L = capi.lib()
+    keep, firsts, seconds = [], (capi.CSR * len(pairs))(), (capi.CSR * len(pairs))()
+    for k, (A, B) in enumerate(pairs):
+        for dst, (m, n, rp, col, val) in ((firsts, A), (seconds, B)):
+            a = ((ctypes.c_uint32 * len(rp))(*rp), (ctypes.c_uint32 * max(len(col), 1))(*col), (ctypes.c_uint32 * max(len(val), 1))(*val))
+            keep.append(a)
+            dst[k] = capi.CSR(m, n, a[0], a[1], a[2])
+    n = len(pairs) * per_pair
+    adds = (ctypes.c_uint32 * n)() if want_costs else None
+    muls = (ctypes.c_uint32 * n)() if want_costs else None
+    b, st = capi.Best(), capi.Stats()
+    capi.check(L.plo_cse_chain_batch(len(pairs), firsts, seconds, p, seed0, per_pair, cost_mode, adds, muls, ctypes.byref(b), ctypes.byref(st)))
+    return (list(adds) if want_costs else None), (list(muls) if want_costs else None), (b.adds, b.muls, b.seed), st.as_dict()
+
+
 def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1):
     """One (block,row) enumeration of `localSparsifier` (reference include/plinopt_sparsify.inl:282-314) on the
     GPU: |coeffs|^4 candidate rows through `testLinComb`.  TM (n x m) and Cand (n x n) are flat row-major lists of
