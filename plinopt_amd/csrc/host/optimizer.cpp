@@ -487,6 +487,13 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
     auto lM = rebind(MQ, f);
     Ops nbops = opsinit; std::string text;
 
+    // the eliminations of -K, -G, -A and -N run on the host with dense or map-based rows: not attempted on inputs like
+    // 32x32x32_15096_L (15096 x 1024), where only the direct method is meant to run (BASELINE config 5 uses -D)
+    const double elim_cost = (double)lM.rowdim() * (double)lM.coldim() * (double)std::min(lM.rowdim(), lM.coldim());
+    if (elim_cost > 2e9 && (tryAB || tryKernel || tryLU || allkernels)) {
+        std::clog << "# -K/-G/-A/-N skipped: host elimination of a " << lM.rowdim() << 'x' << lM.coldim() << " matrix is not attempted (use -D)" << std::endl;
+        tryAB = tryKernel = tryLU = allkernels = false;
+    }
     if (tryAB) {                                                                      // :1436-1440 (inner dimension = column count)
         try { ab_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
         catch (const std::exception &e) { std::clog << "# -A skipped: " << e.what() << std::endl; }
