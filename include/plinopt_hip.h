@@ -79,6 +79,12 @@ int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **plan);
 int plo_cse_plan_create_ex(const plo_csr_t *A, uint32_t p, uint32_t flags, plo_plan_t **plan);
 /* 1 if the plan runs on the HBM-resident kernel family, 0 for the LDS-resident wave kernel */
 int plo_cse_plan_is_hbm(const plo_plan_t *plan);
+/* Diagnostics of the HBM-resident family, summed over the candidates of the plan's last launch:
+ * out[0] CSE steps (OneSub iterations, include/plinopt_optimize.inl:237-312), [1] full pair-table scans,
+ * [2] frequency-level rebuilds, [3] tie picks (:260-265) resolved by bisection on the key (more ties in one
+ * column than the LDS list holds), [4] pairs that went through the spill list (no room in the LDS aggregation
+ * table), [5] sweeps whose claimed-slot list overflowed, [6] candidates, [7] reserved. */
+int plo_cse_plan_hbm_counters(const plo_plan_t *plan, uint32_t out[8]);
 int plo_cse_plan_destroy(plo_plan_t *plan);
 
 /* Replaces the body of `#pragma omp parallel for` in CSEOptimiser,

@@ -219,8 +219,20 @@ int build_big_plan(plo_plan *pl)
     if (m >= 0x7FFFu) return fail(PLO_E_CAPACITY, "more than 32766 rows: frequency does not fit the table slot");
     if (maxlen > 8192) return fail(PLO_E_CAPACITY, "row longer than 8192 entries");
 
-    std::vector<uint32_t> inv(nnz), tptr(n + 1, 0), trows(nnz), ucount(n, 0);
-    for (uint32_t k = 0; k < nnz; ++k) { inv[k] = inv_mod(val[k], p); ++tptr[col[k] + 1]; if (val[k] == 1u || val[k] == p - 1) ++ucount[col[k]]; }
+    // The values of a candidate are the distinct values of the input (a CSE step moves values, it creates none): rows are
+    // packed as column | +-1 flag << 15 | value index << 16, with one {value, inverse} table.
+    std::vector<uint32_t> dv(val.begin(), val.end());
+    std::sort(dv.begin(), dv.end()); dv.erase(std::unique(dv.begin(), dv.end()), dv.end());
+    if (dv.size() > 65536) return fail(PLO_E_CAPACITY, "more than 65536 distinct coefficients: the packed row entry holds a 16-bit value index");
+    std::vector<uint2> vt(dv.size());
+    for (size_t k = 0; k < dv.size(); ++k) vt[k] = make_uint2(dv[k], inv_mod(dv[k], p));
+    std::vector<uint32_t> inv(nnz), ent(nnz), tptr(n + 1, 0), trows(nnz), ucount(n, 0);
+    for (uint32_t k = 0; k < nnz; ++k) {
+        const uint32_t vi = (uint32_t)(std::lower_bound(dv.begin(), dv.end(), val[k]) - dv.begin());
+        const bool u1 = val[k] == 1u || val[k] == p - 1;
+        inv[k] = vt[vi].y; ent[k] = col[k] | (u1 ? 0x8000u : 0u) | (vi << 16);
+        ++tptr[col[k] + 1]; if (u1) ++ucount[col[k]];
+    }
     for (uint32_t c = 0; c < n; ++c) tptr[c + 1] += tptr[c];
     { std::vector<uint32_t> pos(tptr.begin(), tptr.end() - 1);
       for (uint32_t i = 0; i < m; ++i) for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) trows[pos[col[k]]++] = i; }
@@ -246,9 +258,15 @@ int build_big_plan(plo_plan *pl)
     }
     pl->pairs0 = pairs0; pl->distinct0 = keys.size();
     pl->algo_bytes = 8ull * nnz + 16ull * keys.size();       // distinct-triple form of B_cand for HBM-resident candidates
+    B.prune = getenv("PLO_BIG_PRUNE") ? 1u : 0u;
+    if (B.prune) {   // triples of frequency 1 are never chosen and never grow: they are not kept (plo_cse_big.hip, "pruning")
+        size_t w = 0;
+        for (size_t k = 0; k < keys.size(); ++k) if (cnts[k] >= 2u) { keys[w] = keys[k]; cnts[w] = cnts[k]; ++w; }
+        keys.resize(w); cnts.resize(w);
+    }
     const uint32_t multcap = (uint32_t)std::min<uint64_t>((uint64_t)naive / 2 + 8, NC);
     uint64_t cap = 1024;
-    while (cap < 2ull * keys.size() + 1024ull || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;
+    while (cap < (B.prune ? keys.size() + (keys.size() >> 1) + (keys.size() >> 2) : 2ull * keys.size()) + 1024ull || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;   // load <= 0.57 at the start; dead slots are reused
     if (const char *e = getenv("PLO_BIG_HBITS")) { const long hb = strtol(e, nullptr, 10); if (hb >= 10 && hb <= 30 && (1ull << hb) > keys.size() + keys.size() / 8) cap = 1ull << hb; }   // experiment knob
     const uint32_t hbits = ceil_log2((uint32_t)std::min<uint64_t>(cap, 1ull << 31));
     if (cap > (1ull << 30)) return fail(PLO_E_CAPACITY, "pair table above 2^30 slots");
@@ -266,30 +284,44 @@ int build_big_plan(plo_plan *pl)
     B.mu = (~0ull) / p;
     B.mers = 0; for (uint32_t k = 2; k < 31; ++k) if (p == (1u << k) - 1u) B.mers = k;     // Mersenne modulus: shift-and-add reduction
     int rc;
-    if ((rc = upload(pl, pl->rowptr, &B.rs)) || (rc = upload(pl, pl->col, &B.col0)) || (rc = upload(pl, pl->val, &B.val0)) ||
-        (rc = upload(pl, inv, &B.inv0)) || (rc = upload(pl, tptr, &B.tptr)) || (rc = upload(pl, trows, &B.trows)) ||
+    if ((rc = upload(pl, pl->rowptr, &B.rs)) || (rc = upload(pl, ent, &B.ent0)) || (rc = upload(pl, vt, &B.vt)) ||
+        (rc = upload(pl, tptr, &B.tptr)) || (rc = upload(pl, trows, &B.trows)) ||
         (rc = upload(pl, ucount, &B.ucount0)) || (rc = upload(pl, hist, &B.hist0)) || (rc = upload(pl, tab, &B.tab0))) return rc;
+    B.nv = (uint32_t)dv.size(); B.vt_lds = (dv.size() <= 512 && !getenv("PLO_BIG_VT_GLOBAL")) ? 1u : 0u;   // (test knob: the global-memory value table)
+    B.invtab = nullptr;
+    if (p <= (1u << 20)) {                                   // 1/x for every residue (the flush needs v_a/v_c from v_c/v_a): i^-1 = -(p/i) (p mod i)^-1
+        std::vector<uint32_t> it(p, 0); it[1] = 1;
+        for (uint32_t i = 2; i < p; ++i) it[i] = (uint32_t)((uint64_t)(p - p / i) * it[p % i] % p);
+        if ((rc = upload(pl, it, &B.invtab))) return rc;
+    }
     // workspace layout of one candidate
     uint64_t off = 0;
     auto take = [&](uint64_t bytes) { uint64_t o = off; off = (off + bytes + 255) & ~255ull; return o; };
-    B.o_tab = take(cap * 8); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
+    B.o_tab = take(cap * 8); B.o_ent = take(((uint64_t)nnz + 64) * 4); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
     B.o_len = take((uint64_t)m * 4); B.o_ucount = take(NC * 4); B.o_cntM = take(NC * 4);
     B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 16); B.o_aff = take((uint64_t)m * 32);
     B.o_ncrptr = take((NC + 2) * 4); B.o_ncr = take(((uint64_t)nnz + 64) * 4);
     B.o_multc = take((uint64_t)multcap * 4); B.o_multv = take((uint64_t)multcap * 4);
-    B.o_tcnt = take(NC * 4); B.o_tptr2 = take((NC + 2) * 4); B.o_tlist = take(((uint64_t)nnz + 64) * 4); B.o_cols2 = take(NC * 4);
+    B.o_tcnt = take(NC * 4); B.o_tptr2 = take((NC + 2) * 4); B.o_tlist = take(((uint64_t)nnz + 64) * 4); B.o_cols2 = take(NC * 4); B.o_spill = take(((uint64_t)nnz + 64) * 8);
     B.ws_stride = off;
     // dynamic LDS: histogram + max(ProgramGen scratch, aggregation table of 2^aggbits u64)
     B.aggbits = std::min(13u, std::max(6u, ceil_log2((uint32_t)std::min<uint64_t>(4 * pairs0 + 64, 1u << 13))));
     if (const char *e = getenv("PLO_BIG_AGGBITS")) B.aggbits = (uint32_t)std::min(14l, std::max(6l, strtol(e, nullptr, 10)));
+    // LDS aggregation entry: key | count.  When column, ratio, inverse ratio and a count up to m fit 64 bits the key carries
+    // both x and 1/x (the flush then needs no inversion); otherwise (column, x) with a 16-bit count.
+    { const uint32_t cb = ceil_log2(m + 2u);
+      if (bb + 2u * rb + cb <= 64u && !getenv("PLO_BIG_NODUAL")) { B.agg_dual = 1u; B.agg_cb = 64u - bb - 2u * rb; if (B.agg_cb > 16u) B.agg_cb = 16u; }
+      else { B.agg_dual = 0u; B.agg_cb = 16u; } }
     const uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, 2u << B.aggbits);
-    pl->big_lds = (((B.maxf0 + 2u) & ~1u) + scr_words) * 4u;
+    pl->big_lds = (((B.maxf0 + 2u) & ~1u) + (B.vt_lds ? 2u * ((B.nv + 1u) & ~1u) : 0u) + scr_words) * 4u;
     if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
-    HIPCHK(hipFuncSetAttribute((const void *)plo::cse_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
+    HIPCHK(hipFuncSetAttribute(B.vt_lds ? (const void *)plo::cse_big_kernel<true> : (const void *)plo::cse_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
     if (!pl->d_err) HIPCHK(hipMalloc((void **)&pl->d_err, sizeof(uint32_t)));
     if (!pl->d_best) HIPCHK(hipMalloc((void **)&pl->d_best, sizeof(unsigned long long)));
     if (!pl->d_next) HIPCHK(hipMalloc((void **)&pl->d_next, sizeof(unsigned long long)));
-    if (!pl->d_stats) HIPCHK(hipMalloc((void **)&pl->d_stats, 32 * sizeof(uint32_t)));
+    if (!pl->d_stats) HIPCHK(hipMalloc((void **)&pl->d_stats, 64 * sizeof(uint32_t)));
+    B.selcap = PLO_BIG_SELCAP;
+    if (const char *e = getenv("PLO_BIG_SELCAP")) B.selcap = (uint32_t)std::min<long>(PLO_BIG_SELCAP, std::max<long>(1, strtol(e, nullptr, 10)));   // test knob: forces the bisection tie pick
     pl->big = true; pl->waves_per_wg = PLO_BIG_THREADS / 64; pl->lds_bytes = pl->big_lds + (uint32_t)sizeof(plo::BigShared);
     return PLO_OK;
 }
@@ -316,11 +348,13 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     pl->B.ws = (uint8_t *)pl->d_ws;
     HIPCHK(hipMemsetAsync(pl->d_err, 0, sizeof(uint32_t), g_stream));
     HIPCHK(hipMemsetAsync(pl->d_next, 0, sizeof(unsigned long long), g_stream));
+    HIPCHK(hipMemsetAsync(pl->d_stats, 0, 64 * sizeof(uint32_t), g_stream));
     J.err = pl->d_err; J.next = pl->d_next; J.stats = pl->d_stats;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, g_stream));
-    hipLaunchKernelGGL(plo::cse_big_kernel, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+    if (pl->B.vt_lds) hipLaunchKernelGGL(plo::cse_big_kernel<true>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+    else hipLaunchKernelGGL(plo::cse_big_kernel<false>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, g_stream));
     HIPCHK(hipEventSynchronize(e1));
@@ -524,6 +558,16 @@ int plo_cse_plan_create_ex(const plo_csr_t *A, uint32_t p, uint32_t flags, plo_p
 int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **out) { return plo_cse_plan_create_ex(A, p, 0u, out); }
 
 int plo_cse_plan_is_hbm(const plo_plan_t *pl) { return pl && pl->big ? 1 : 0; }
+
+int plo_cse_plan_hbm_counters(const plo_plan_t *pl, uint32_t out[8])
+{
+    if (!pl || !out) return fail(PLO_E_ARG, "null argument");
+    if (!pl->big || !pl->d_stats) return fail(PLO_E_UNSUPPORTED, "the counters belong to the HBM-resident kernel family");
+    uint32_t hs[64];
+    HIPCHK(hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) out[k] = hs[32 + k];
+    return PLO_OK;
+}
 
 int plo_cse_plan_destroy(plo_plan_t *pl)
 {

@@ -10,7 +10,18 @@
 //                   key = col_a<<(bb+rb) | col_b<<rb | ratio: integer order ==
 //                   std::map order of (size_t,size_t,Element); the initial image
 //                   is built once on the host and copied per candidate.
-//   rows       col/val/inv u32[nnz] at fixed row offsets rs[i] (rows only shrink)
+//   rows       ONE u32 per entry at fixed row offsets rs[i] (rows only shrink):
+//              column (15 bits) | +-1 flag (bit 15) | value index (16 bits).  A CSE step
+//              never creates a value: the new column's entry carries the value of one of
+//              the two entries it replaces, so the values of a candidate are the input's
+//              distinct values (25 on config 5); {value, inverse} per index live in LDS
+//              (global memory above 512 values).  ProgramGen, which does create values,
+//              first expands the rows to col/val/inv arrays.
+//   pruning    a triple of frequency 1 can never be chosen (OneSub :255 stops at 1) and
+//              frequencies only fall after the step that creates a triple, so triples
+//              are kept in the table only from frequency 2 on: count-1 triples of the
+//              input are not in the image, a fresh triple seen once in its step is not
+//              inserted, and retiring an absent triple is a no-op.
 //   levels     the maximal frequency M never increases during a candidate, and
 //              only ~60 distinct values occur on config 5.  hist[f] (LDS) counts
 //              triples per frequency; cntM[c] counts triples of frequency M whose
@@ -49,13 +60,16 @@ namespace plo {
 #define PLO_GEMPTY 0xFFFFFFFFFFFF0000ull
 
 struct BigPlan {
-    uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride, aggbits, mers;
+    uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride, aggbits, mers, agg_cb, agg_dual, selcap, prune;   // agg_cb: count bits of an LDS aggregation entry; agg_dual: its key is (column, x, 1/x)
     uint64_t mu;
-    const uint32_t *rs, *col0, *val0, *inv0, *tptr, *trows, *ucount0, *hist0;
+    uint32_t nv, vt_lds;                  // distinct values; their {value, inverse} table is staged in LDS when it has <= 512 entries
+    const uint32_t *rs, *ent0, *tptr, *trows, *ucount0, *hist0;
+    const uint2 *vt;                      // {value, inverse} per value index
+    const uint32_t *invtab;               // 1/x for every residue x (p <= 2^20), or nullptr
     const uint64_t *tab0;
     uint8_t *ws; uint64_t ws_stride;
-    uint64_t o_tab, o_col, o_val, o_inv, o_len, o_ucount, o_cntM, o_dm, o_hl, o_aff, o_ncrptr, o_ncr, o_multc, o_multv,
-             o_tcnt, o_tptr2, o_tlist, o_cols2;
+    uint64_t o_tab, o_ent, o_col, o_val, o_inv, o_len, o_ucount, o_cntM, o_dm, o_hl, o_aff, o_ncrptr, o_ncr, o_multc, o_multv,
+             o_tcnt, o_tptr2, o_tlist, o_cols2, o_spill;
 };
 
 struct BigJob {
@@ -225,21 +239,22 @@ __device__ unsigned long long g_prof[16];      // thread 0 of every workgroup, s
 #define PROF_T(k_) do { } while (0)
 #endif
 #define PLO_AGG_LIST (PLO_BIG_SELCAP * 4u)     // slot list (u16) kept in the tie-selection buffer, idle during the sweeps
-__device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_t key, uint32_t *aggn, uint16_t *agglist) {
+__device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_t acb, uint64_t key, uint32_t hk, uint32_t *aggn, uint16_t *agglist) {
     const uint32_t mask = (1u << aggbits) - 1u;
-    uint32_t s = ((((uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32u - aggbits));   // keys are (column, ratio): 32 bits on config 5
+    const uint64_t EMPTY = ~0ull << acb;
+    uint32_t s = (hk * 0x9E3779B1u) >> (32u - aggbits);       // hk: 32 bits that determine the key ((column, ratio) on config 5)
     uint32_t claimed = 0xFFFFFFFFu; bool done = false;
     // two slots per trip (both LDS reads in flight together): the wave pays the longest probe sequence of its lanes
     for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
         const uint32_t s1 = (s + 1u) & mask;
         const uint64_t v0 = __hip_atomic_load(&agg[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), v1 = __hip_atomic_load(&agg[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_read_b64 (a volatile read would be a flat load)
-        const bool hit0 = (v0 >> PLO_GVB) == key, emp0 = v0 == PLO_GEMPTY, first = hit0 || emp0;
-        const bool hit = hit0 || (!emp0 && (v1 >> PLO_GVB) == key), emp = emp0 || (!hit && v1 == PLO_GEMPTY);
+        const bool hit0 = (v0 >> acb) == key, emp0 = v0 == EMPTY, first = hit0 || emp0;
+        const bool hit = hit0 || (!emp0 && (v1 >> acb) == key), emp = emp0 || (!hit && v1 == EMPTY);
         const uint32_t t = first ? s : s1;
         if (hit) { wg_add((unsigned long long *)&agg[t], 1ull); done = true; break; }
         if (emp) {
-            const uint64_t old = wg_cas((unsigned long long *)&agg[t], (unsigned long long)PLO_GEMPTY, (unsigned long long)((key << PLO_GVB) | 1ull));
-            if (old == PLO_GEMPTY) { claimed = t; done = true; break; }
+            const uint64_t old = wg_cas((unsigned long long *)&agg[t], (unsigned long long)EMPTY, (unsigned long long)((key << acb) | 1ull));
+            if (old == EMPTY) { claimed = t; done = true; break; }
             continue;                      // somebody took the slot: look at both again
         }
         s = (s + 2u) & mask; pr += 2u;
@@ -259,16 +274,21 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint64_
     return done;
 }
 
+// packed row entry: column (15 bits) | +-1 flag (bit 15) | value index (16 bits)
+#define PLO_ECOL(e_) ((e_) & 0x7FFFu)
+#define PLO_EUNIT(e_) (((e_) >> 15) & 1u)
+#define PLO_EVI(e_) ((e_) >> 16)
 // position of column c in row [base, base+L) (sorted by column), or -1
-__device__ __forceinline__ int row_find(const uint32_t *col, uint32_t base, uint32_t L, uint32_t c) {
+__device__ __forceinline__ int row_find(const uint32_t *ent, uint32_t base, uint32_t L, uint32_t c) {
     uint32_t lo = 0, hi = L;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (col[base + mid] < c) lo = mid + 1; else hi = mid; }
-    return (lo < L && col[base + lo] == c) ? (int)lo : -1;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (PLO_ECOL(ent[base + mid]) < c) lo = mid + 1; else hi = mid; }
+    return (lo < L && PLO_ECOL(ent[base + lo]) == c) ? (int)lo : -1;
 }
 
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r, aggn, nspill; uint64_t kprime; uint64_t selkey;
+    uint32_t nbisect, spilltot, listover;   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
     uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
 #ifdef PLO_BIG_PROFILE
@@ -284,16 +304,21 @@ struct BigShared {
 // ---------------------------------------------------------------------------
 // One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
 // ---------------------------------------------------------------------------
-__device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, uint32_t *errw)
+template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const uint2 *vts, uint32_t *errw)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
     uint64_t *tab   = (uint64_t *)(ws + P.o_tab);
-    uint32_t *col   = (uint32_t *)(ws + P.o_col), *val = (uint32_t *)(ws + P.o_val), *inv = (uint32_t *)(ws + P.o_inv);
+    uint32_t *ent   = (uint32_t *)(ws + P.o_ent);
     uint32_t *len   = (uint32_t *)(ws + P.o_len), *ucount = (uint32_t *)(ws + P.o_ucount), *cntM = (uint32_t *)(ws + P.o_cntM);
     uint64_t *DM    = (uint64_t *)(ws + P.o_dm), *HL = (uint64_t *)(ws + P.o_hl);
+    // {value, inverse} per value index: LDS copy, or global memory above 512 values.  Two typed accesses,
+    // never one generic pointer: a flat load waits for vmcnt(0) AND lgkmcnt(0) and would drain every prefetch.
+    // (VTL is a template parameter: the compiler turns a run-time choice between the two address spaces into a flat load)
+    const uint2 *vtg = P.vt;
+    auto VT = [&](uint32_t vi) -> uint2 { if constexpr (VTL) return vts[vi]; else return vtg[vi]; };
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
     uint16_t *agglist = (uint16_t *)sh.sel;       // slots claimed in the aggregation table by the running sweep
-    uint64_t *spill = (uint64_t *)(ws + P.o_tlist); const uint32_t spillcap = (P.nnz + 64u) / 2u;   // new-column pairs of entries that found no room in LDS (ProgramGen's list area is idle here)
+    uint64_t *spill = (uint64_t *)(ws + P.o_spill); const uint32_t spillcap = P.nnz + 64u;   // new-column pairs of entries that found no room in LDS (a step touches every entry at most once)
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
     const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
     const uint64_t mu = P.mu, cap = 1ull << P.hbits;
@@ -308,14 +333,14 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             d4[s] = x0; if (b1) d4[s + nth] = x1; if (b2) d4[s + 2ull * nth] = x2; if (b3) d4[s + 3ull * nth] = x3;
         }
         const uint32_t q4 = (P.nnz + 3u) >> 2;
-        const uint4 *c4 = (const uint4 *)P.col0, *v4 = (const uint4 *)P.val0, *i4 = (const uint4 *)P.inv0;
-        uint4 *dc = (uint4 *)col, *dv = (uint4 *)val, *di = (uint4 *)inv;
-        for (uint32_t k = tid; k < q4; k += nth) { uint4 x = c4[k], y = v4[k], z = i4[k]; dc[k] = x; dv[k] = y; di[k] = z; }
+        const uint4 *e4 = (const uint4 *)P.ent0; uint4 *de = (uint4 *)ent;
+        for (uint32_t k = tid; k < q4; k += 2u * nth) { uint4 x = e4[k], y; const bool b1 = k + nth < q4; if (b1) y = e4[k + nth]; de[k] = x; if (b1) de[k + nth] = y; }
     }
     for (uint32_t i = tid; i < m; i += nth) len[i] = P.rs[i + 1] - P.rs[i];
     for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; }
     for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = P.hist0[f];
-    for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = PLO_GEMPTY;
+    const uint32_t acb = P.agg_cb; const uint64_t AEMPTY = ~0ull << acb;
+    for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = AEMPTY;
     if (tid == 0) {
         uint64_t x = seed + 0x9E3779B97F4A7C15ull;
         x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
@@ -325,7 +350,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
 #ifdef PLO_BIG_PROFILE
         for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0;
 #endif
-        sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0;
+        sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0; sh.nbisect = 0; sh.spilltot = 0; sh.listover = 0;
     }
     PLO_BIG_FENCE(); BSYNC();
 
@@ -430,12 +455,13 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 const uint64_t key = DM[k];
                 if ((uint32_t)(key >> abits) == a && gtab_find(tab, key, hbits) == M) {
                     uint32_t idx = wg_add(&sh.sel_n, 1u);
-                    if (idx < PLO_BIG_SELCAP) sh.sel[idx] = key; else sh.sel_over = 1u;
+                    if (idx < P.selcap) sh.sel[idx] = key; else sh.sel_over = 1u;
                 }
             }
             BSYNC();
             if (sh.sel_over) {
                 // rare: more ties in one column than the LDS list holds -> bisection on the key value
+                if (tid == 0) ++sh.nbisect;
                 uint64_t lo = (uint64_t)a << abits, hi = (((uint64_t)a + 1ull) << abits) - 1ull;
                 while (lo < hi) {
                     const uint64_t mid = lo + ((hi - lo) >> 1);
@@ -482,18 +508,22 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             const uint32_t *lst = na <= nb ? la : lb; const uint32_t ln = na <= nb ? na : nb;
             for (uint32_t k = tid; k < ln; k += nth) {
                 const uint32_t i = lst[k], base = P.rs[i], L = len[i];
-                const int pa = row_find(col, base, L, a);
+                const int pa = row_find(ent, base, L, a);
                 if (pa < 0) continue;
-                const int pb = row_find(col, base, L, b);
+                const int pb = row_find(ent, base, L, b);
                 if (pb < 0) continue;
-                const uint32_t va = val[base + pa], vb = val[base + pb];
-                if (vb != bmul(r, va, p, mu, mers)) continue;
+                const uint32_t ea = ent[base + pa], eb = ent[base + pb];
+                const uint2 A = VT(PLO_EVI(ea)), B = VT(PLO_EVI(eb));
+                if (B.x != bmul(r, A.x, p, mu, mers)) continue;
                 const uint32_t idx = wg_add(&sh.naff, 1u);
-                const uint32_t ia = inv[base + pa], ib = inv[base + pb];
-                uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each) and values/inverses of the two entries, row start and length
-                *(uint4 *)rec = make_uint4(i, (uint32_t)pa | ((uint32_t)pb << 16), va, ia);
-                *(uint4 *)(rec + 4) = make_uint4(vb, ib, base, L);
-                if (idx == 0) sh.invr = bmul(va, ib, p, mu, mers);               // 1/r
+                uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each), row start and length; the two packed entries
+                *(uint4 *)rec = make_uint4(i, (uint32_t)pa | ((uint32_t)pb << 16), base, L);
+                *(uint2 *)(rec + 4) = make_uint2(ea, eb);
+                if (idx == 0) sh.invr = bmul(A.x, B.y, p, mu, mers);             // 1/r
+                len[i] = L - 1u;                                               // the sweep works from the record
+                if (PLO_EUNIT(ea)) wg_sub(&ucount[a], 1u);                     // :70-77 counts, kept incrementally
+                if (PLO_EUNIT(eb)) wg_sub(&ucount[b], 1u);
+                if (PLO_EUNIT(swap ? eb : ea)) wg_add(&ucount[lm], 1u);
             }
         }
         PLO_BIG_FENCE(); BSYNC();
@@ -506,76 +536,88 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
         // pair with a has ratio x, the pair with b has ratio r x (c < a), r/x (a < c < b) or x/r (b < c).  One LDS entry
         // per (c, x) therefore carries both retirements; the flush derives the two table keys.
         {
-            auto retire_entry = [&](uint32_t c, uint32_t v, uint32_t iv, uint32_t va, uint32_t ia, uint32_t vb, uint32_t ib) {
-                const uint32_t x = bmul(c < a ? va : v, c < a ? iv : ia, p, mu, mers);        // one product, operands selected (no divergent branch)
-                if (agg_add(agg, aggbits, ((uint64_t)c << rb) | x, &sh.aggn, agglist)) return;
+            auto retire_entry = [&](uint32_t e, uint2 VA, uint2 VB) {
+                const uint32_t c = PLO_ECOL(e); const uint2 V = VT(PLO_EVI(e));
+                // x = v_a/v_c (c < a) or v_c/v_a (c > a) names both retired pairs; y = v_a/v_c names the pair with the new column
+                // (x itself, or 1/x: kept beside x in the entry when the bits allow, so that the flush needs no inversion)
+                const uint32_t y = bmul(VA.x, V.y, p, mu, mers);
+                const uint32_t x = c < a ? y : bmul(V.x, VA.y, p, mu, mers);
+                const uint64_t cx = ((uint64_t)c << rb) | x;
+                if (agg_add(agg, aggbits, acb, P.agg_dual ? (cx << rb) | y : cx, (uint32_t)cx ^ ((uint32_t)(cx >> 32) * 0x85EBCA6Bu), &sh.aggn, agglist)) return;
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fb1, 1u);
 #endif
+                // no room in the LDS table (the key is then absent from it for the whole sweep): retire in HBM directly.
+                // A triple that is not in the table had frequency 1 (pruned): nothing to do for it.
                 const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x);
-                const uint64_t k2 = c < b ? BKEY(c, b, bmul(vb, iv, p, mu, mers)) : BKEY(b, c, bmul(v, ib, p, mu, mers));
-                uint32_t o1 = gtab_dec(tab, k1, hbits);
-                if (!o1) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
-                wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
-                if (o1 == M) { wg_sub(&cntM[c < a ? c : a], 1u); wg_sub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
-                uint32_t o2 = gtab_dec(tab, k2, hbits);
-                if (!o2) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
-                wg_sub(&hist[o2], 1u); if (o2 > 1u) wg_add(&hist[o2 - 1u], 1u);
-                if (o2 == M) { wg_sub(&cntM[c < b ? c : b], 1u); wg_sub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
+                const uint64_t k2 = c < b ? BKEY(c, b, bmul(VB.x, V.y, p, mu, mers)) : BKEY(b, c, bmul(V.x, VB.y, p, mu, mers));
+                const uint32_t o1 = gtab_dec(tab, k1, hbits);
+                if (o1) {
+                    wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
+                    if (o1 == M) { wg_sub(&cntM[c < a ? c : a], 1u); wg_sub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
+                }
+                const uint32_t o2 = gtab_dec(tab, k2, hbits);
+                if (o2) {
+                    wg_sub(&hist[o2], 1u); if (o2 > 1u) wg_add(&hist[o2 - 1u], 1u);
+                    if (o2 == M) { wg_sub(&cntM[c < b ? c : b], 1u); wg_sub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
+                }
                 // its pair with the new column is inserted after all retirements (flush, second pass)
                 const uint32_t idx = wg_add(&sh.nspill, 1u);
-                if (idx < spillcap) spill[idx] = BKEY(c, lm, bmul(l0 == a ? va : vb, iv, p, mu, mers)); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
+                if (idx < spillcap) spill[idx] = BKEY(c, lm, bmul(l0 == a ? VA.x : VB.x, V.y, p, mu, mers)); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
             };
-            // two rows per wave and trip: both records, then the first 64 entries of both rows, are in flight together
-            for (uint32_t q = wave; q < naff; q += 2u * nwaves) {
-                const uint32_t q2 = q + nwaves < naff ? q + nwaves : q;
+            // Two rows per wave and trip, software-pipelined: a wave first loads the records of its next 64 rows, ONE PER LANE
+            // (a record = row start, length, the two positions, the two removed entries), and reads them back with
+            // v_readlane; the first 64 entries of the next pair of rows are requested before the current pair is worked on.
+            // A trip therefore never waits for a record -> row dependency (two memory round trips per row otherwise: most
+            // rows are one chunk long).  Prefetches are unconditional (clamped index, length 0 past the end).
+#define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
+            const uint32_t nrw = naff > wave ? (naff - wave + nwaves - 1u) / nwaves : 0u;      // rows of this wave: wave, wave + nwaves, ...
+            for (uint32_t k0 = 0; k0 < nrw; k0 += 64u) {
+                const bool have = k0 + lane < nrw;
+                const uint32_t qq = have ? wave + (k0 + lane) * nwaves : wave;
+                const uint4 R0 = *(const uint4 *)(aff + 8u * qq); const uint2 R1 = *(const uint2 *)(aff + 8u * qq + 4u);
+                const uint32_t Rpp = R0.y, Rbase = R0.z, RL_ = have ? R0.w : 0u, Rea = R1.x, Reb = R1.y;
+                const uint32_t cnt = nrw - k0 < 64u ? nrw - k0 : 64u;
+                uint32_t baseA = RL(Rbase, 0), LA = RL(RL_, 0), baseB = RL(Rbase, 1), LB = RL(RL_, 1);
+                uint32_t eA = ent[baseA + (lane < LA ? lane : 0u)], eB = ent[baseB + (lane < LB ? lane : 0u)];
+                for (uint32_t kk = 0; kk < cnt; kk += 2u) {
 #ifdef PLO_BIG_PROFILE
-                unsigned long long tp = clock64();
+                    unsigned long long tp = clock64();
 #endif
-                const uint4 A0 = *(const uint4 *)(aff + 8u * q), A1 = *(const uint4 *)(aff + 8u * q + 4u);
-                const uint4 B0 = *(const uint4 *)(aff + 8u * q2), B1 = *(const uint4 *)(aff + 8u * q2 + 4u);
-                const uint32_t baseA = A1.z, LA = A1.w, baseB = B1.z, LB = q2 != q ? B1.w : 0u;
-                uint32_t cA = 0, vA = 0, iA = 0, cB = 0, vB = 0, iB = 0;
-                const uint32_t paA = A0.y & 0xFFFFu, pbA = A0.y >> 16, paB = B0.y & 0xFFFFu, pbB = B0.y >> 16;
-                if (lane < LA) { cA = col[baseA + lane]; vA = val[baseA + lane]; iA = inv[baseA + lane]; }
-                if (lane < LB) { cB = col[baseB + lane]; vB = val[baseB + lane]; iB = inv[baseB + lane]; }
-                const uint32_t Lmax = LA > LB ? LA : LB;
-                for (uint32_t z0 = 0; z0 < Lmax; z0 += 64u) {
-                    // the next 64 entries of both rows are requested before this chunk is worked on (and before it is
-                    // stored: the stores reach back at most two positions, never into the next chunk)
-                    const uint32_t z = z0 + lane, zn = z + 64u;
-                    uint32_t ncA = 0, nvA = 0, niA = 0, ncB = 0, nvB = 0, niB = 0;
-                    if (zn < LA) { ncA = col[baseA + zn]; nvA = val[baseA + zn]; niA = inv[baseA + zn]; }
-                    if (zn < LB) { ncB = col[baseB + zn]; nvB = val[baseB + zn]; niB = inv[baseB + zn]; }
-                    __builtin_amdgcn_wave_barrier();
-                    const bool actA = z < LA && z != paA && z != pbA, actB = z < LB && z != paB && z != pbB;
-                    // the row is rewritten in the same pass (:96-110): entries shift left over the two removed positions
-                    if (actA) { const uint32_t np = baseA + z - (z > paA ? 1u : 0u) - (z > pbA ? 1u : 0u); col[np] = cA; val[np] = vA; inv[np] = iA; }
-                    if (actB) { const uint32_t np = baseB + z - (z > paB ? 1u : 0u) - (z > pbB ? 1u : 0u); col[np] = cB; val[np] = vB; inv[np] = iB; }
-                    if (actA) retire_entry(cA, vA, iA, A0.z, A0.w, A1.x, A1.y);
-                    if (actB) retire_entry(cB, vB, iB, B0.z, B0.w, B1.x, B1.y);
-                    __builtin_amdgcn_wave_barrier();
-                    cA = ncA; vA = nvA; iA = niA; cB = ncB; vB = nvB; iB = niB;
-                }
-                if (lane == 0) {                       // the new column's entry goes last
-                    {
-                        const uint32_t coeff = (l0 == a) ? A0.z : A1.x, icoeff = (l0 == a) ? A0.w : A1.y;
-                        col[baseA + LA - 2u] = lm; val[baseA + LA - 2u] = coeff; inv[baseA + LA - 2u] = icoeff;
-                        len[A0.x] = LA - 1u;
-                        if (babsone(A0.z, p)) wg_sub(&ucount[a], 1u);
-                        if (babsone(A1.x, p)) wg_sub(&ucount[b], 1u);
-                        if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
+                    // next pair: first chunks requested now
+                    const uint32_t k2 = (kk + 2u) & 63u, k3 = (kk + 3u) & 63u; const bool more = kk + 2u < 64u;
+                    const uint32_t nbaseA = RL(Rbase, k2), nLA = more ? RL(RL_, k2) : 0u, nbaseB = RL(Rbase, k3), nLB = more ? RL(RL_, k3) : 0u;
+                    const uint32_t nfA = ent[nbaseA + (lane < nLA ? lane : 0u)], nfB = ent[nbaseB + (lane < nLB ? lane : 0u)];
+                    const uint32_t ppA = RL(Rpp, kk), ppB = RL(Rpp, kk + 1u);
+                    const uint32_t paA = ppA & 0xFFFFu, pbA = ppA >> 16, paB = ppB & 0xFFFFu, pbB = ppB >> 16;
+                    const uint32_t eaA = RL(Rea, kk), ebA = RL(Reb, kk), eaB = RL(Rea, kk + 1u), ebB = RL(Reb, kk + 1u);
+                    const uint2 VaA = VT(PLO_EVI(eaA)), VbA = VT(PLO_EVI(ebA)), VaB = VT(PLO_EVI(eaB)), VbB = VT(PLO_EVI(ebB));
+                    const uint32_t Lmax = LA > LB ? LA : LB;
+                    for (uint32_t z0 = 0; z0 < Lmax; z0 += 64u) {
+                        // the next 64 entries of both rows are requested before this chunk is worked on (and before it is
+                        // stored: the stores reach back at most two positions, never into the next chunk)
+                        const uint32_t z = z0 + lane, zn = z + 64u;
+                        const bool morez = z0 + 64u < Lmax;                       // wave-uniform: rows of one chunk issue no further load (and wait for none)
+                        uint32_t neA = 0, neB = 0;
+                        if (morez) { neA = ent[baseA + (zn < LA ? zn : 0u)]; neB = ent[baseB + (zn < LB ? zn : 0u)]; }
+                        __builtin_amdgcn_wave_barrier();
+                        const bool actA = z < LA && z != paA && z != pbA, actB = z < LB && z != paB && z != pbB;
+                        // the row is rewritten in the same pass (:96-110): entries right of the first removed position shift left
+                        if (actA && z > paA) ent[baseA + z - 1u - (z > pbA ? 1u : 0u)] = eA;
+                        if (actB && z > paB) ent[baseB + z - 1u - (z > pbB ? 1u : 0u)] = eB;
+                        if (actA) retire_entry(eA, VaA, VbA);
+                        if (actB) retire_entry(eB, VaB, VbB);
+                        __builtin_amdgcn_wave_barrier();
+                        if (morez) { eA = neA; eB = neB; }
                     }
-                    if (LB) {
-                        const uint32_t coeff = (l0 == a) ? B0.z : B1.x, icoeff = (l0 == a) ? B0.w : B1.y;
-                        col[baseB + LB - 2u] = lm; val[baseB + LB - 2u] = coeff; inv[baseB + LB - 2u] = icoeff;
-                        len[B0.x] = LB - 1u;
-                        if (babsone(B0.z, p)) wg_sub(&ucount[a], 1u);
-                        if (babsone(B1.x, p)) wg_sub(&ucount[b], 1u);
-                        if (babsone(coeff, p)) wg_add(&ucount[lm], 1u);
+                    if (lane == 0) {                       // the new column's entry goes last (len and the +-1 counters were updated by the search)
+                        if (LA) ent[baseA + LA - 2u] = (((l0 == a) ? eaA : ebA) & 0xFFFF8000u) | lm;
+                        if (LB) ent[baseB + LB - 2u] = (((l0 == a) ? eaB : ebB) & 0xFFFF8000u) | lm;
                     }
+                    baseA = nbaseA; LA = nLA; baseB = nbaseB; LB = nLB; eA = nfA; eB = nfB;
                 }
             }
+#undef RL
         }
         BSYNC();
 #ifdef PLO_BIG_PROFILE
@@ -590,6 +632,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             const uint32_t invr = sh.invr;
             auto retire = [&](uint64_t k, uint32_t d) {
                 const uint32_t o = gtab_subn(tab, k, d, hbits);
+                if (o == 0u) return;                                       // not in the table: a triple of frequency 1 (pruned)
                 if (o < d) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
                 wg_sub(&hist[o], 1u); if (o > d) wg_add(&hist[o - d], 1u);
                 if (o == M) { wg_sub(&cntM[(uint32_t)(k >> abits)], 1u); wg_sub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
@@ -599,13 +642,15 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             for (uint32_t e = tid; e < nslot; e += nth) {
                 const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
                 const uint64_t v = agg[s];
-                if (v == PLO_GEMPTY) continue;
-                const uint64_t k = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+                if (v == AEMPTY) continue;
+                uint64_t k = v >> acb; const uint32_t d = (uint32_t)(v & ((1ull << acb) - 1ull));
+                uint32_t y = 0;
+                if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
                 const uint32_t c = (uint32_t)(k >> rb), x = (uint32_t)(k & ((1ull << rb) - 1ull));
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fl1, 1u);
 #endif
-                const uint32_t y = c > a ? binv(x, p, mu, mers) : x;               // v_a / v_c
+                if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
                 const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
                 const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
                 retire(c < a ? BKEY(c, a, x) : BKEY(a, c, x), d);
@@ -634,9 +679,10 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
             for (uint32_t e = tid; e < nslot; e += nth) {
                 const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
                 const uint64_t v = agg[s];
-                if (v == PLO_GEMPTY) continue;
-                agg[s] = PLO_GEMPTY;
+                if (v == AEMPTY) continue;                                 // (an entry rewritten by the first pass has a count below 2^acb in its low 16 bits: never this pattern)
+                agg[s] = AEMPTY;
                 const uint64_t kc = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+                if (d < 2u && P.prune) continue;                           // seen once in its only step: frequency 1 for ever, never chosen, not kept
                 const uint64_t k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
                 const uint32_t o = gtab_addn(tab, k, d, hbits);
 #ifdef PLO_BIG_PROFILE
@@ -676,7 +722,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
                 }
             }
         }
-        if (tid == 0) { ++sh.nbadd; ++sh.steps; sh.ncols = lm + 1u; }      // :292, :190-191
+        if (tid == 0) { ++sh.nbadd; ++sh.steps; sh.ncols = lm + 1u; sh.spilltot += sh.nspill; if (sh.aggn > PLO_AGG_LIST) ++sh.listover; }      // :292, :190-191
         PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(7);
     }
@@ -698,6 +744,7 @@ __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, 
 // |values|, so they are few and short).
 __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *scratch, uint32_t *errw)
 {
+    // (the {value, inverse} table is read from global memory here: `scratch` may overlap its LDS copy)
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
     uint64_t *tab   = (uint64_t *)(ws + P.o_tab);
     uint32_t *col   = (uint32_t *)(ws + P.o_col), *val = (uint32_t *)(ws + P.o_val), *inv = (uint32_t *)(ws + P.o_inv);
@@ -716,6 +763,15 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
         BSYNC();
         return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | sh.nbmul;
     }
+    // ProgramGen creates values (FactorOutRows sums, Triangle quotients): expand the packed rows to col / val / inv
+    {
+        const uint32_t *ent = (const uint32_t *)(ws + P.o_ent);
+        for (uint32_t i = wave; i < m; i += nwaves) {
+            const uint32_t base = P.rs[i], L = len[i];
+            for (uint32_t z = lane; z < L; z += 64u) { const uint32_t e = ent[base + z]; const uint2 V = P.vt[PLO_EVI(e)]; col[base + z] = PLO_ECOL(e); val[base + z] = V.x; inv[base + z] = V.y; }
+        }
+    }
+    PLO_BIG_FENCE(); BSYNC();
     // table region for the (column,|v|) multiset, sized by the live entries
     {
         uint32_t acc = 0;
@@ -924,14 +980,17 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
     return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | (sh.nbmul + sh.acc1);
 }
 
-__global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, BigJob J)
+template <bool VTL> __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, BigJob J)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bigdyn[];                 // hist[maxf0+1] then per-wave scratch (nwaves * stride)
     __shared__ BigShared sh;
     __shared__ unsigned long long cur;
     uint32_t *hist = bigdyn;
-    uint32_t *scratch = bigdyn + ((P.maxf0 + 2u) & ~1u);           // ProgramGen scratch and the CSE aggregation table share this space
+    uint2 *vts = (uint2 *)(bigdyn + ((P.maxf0 + 2u) & ~1u));       // {value, inverse} per value index (when VTL)
+    uint32_t *scratch = (uint32_t *)(vts + (VTL ? ((P.nv + 1u) & ~1u) : 0u));   // ProgramGen scratch and the CSE aggregation table share this space
     uint64_t *agg = (uint64_t *)scratch;
+    if (VTL) { for (uint32_t k = threadIdx.x; k < P.nv; k += blockDim.x) vts[k] = P.vt[k]; }
+    __syncthreads();
     uint8_t *ws = P.ws + (uint64_t)blockIdx.x * P.ws_stride;
     uint64_t best = ~0ull;
     for (;;) {
@@ -941,7 +1000,7 @@ __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, Big
         __syncthreads();
         if (c >= J.ncand) break;
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        uint64_t ok = big_candidate(P, ws, seed, sh, hist, agg, P.aggbits, J.err);
+        uint64_t ok = big_candidate<VTL>(P, ws, seed, sh, hist, agg, P.aggbits, vts, J.err);
         uint64_t res = 0;
         __syncthreads();
         if (ok) res = big_program_gen(P, ws, sh, scratch, J.err);
@@ -951,7 +1010,8 @@ __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, Big
             const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
-            if (J.stats) { J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull);
+            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u);
+                J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull);
 #ifdef PLO_BIG_PROFILE
                 for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }
                 J.stats[28] = sh.fb1; J.stats[29] = sh.fb2; J.stats[30] = sh.fl1; J.stats[31] = sh.fl2;

@@ -524,3 +524,60 @@ def run_inplace_program(text, a, b, c):
             env[var][idx] = -v0 if neg else v0
             nsca += 1
     return nadd, nsca, nmul
+
+
+# ----------------------------------------------------------------------------- cuts of 32x32x32_15096_L
+def l32_rows(p=131071):
+    """32x32x32_15096_L regenerated from its stored SLP by bin/SLPchecker (reference Makefile:79-80): list of rows,
+    each a sorted list of (column, residue)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+    out = subprocess.run([os.path.join(ROOT, "bin", "SLPchecker"), "-q", str(p), os.path.join(DATA, "32x32x32_15096_L.slp")],
+                         capture_output=True, text=True, check=True).stdout
+    lines = out.splitlines()
+    m, n = int(lines[0].split()[0]), int(lines[0].split()[1])
+    rows = [[] for _ in range(m)]
+    for ln in lines[1:-1]:
+        i, j, v = ln.split()
+        rows[int(i) - 1].append((int(j) - 1, int(v)))
+    for r in rows:
+        r.sort()
+    return m, n, rows
+
+
+def l32_cut(row_lo, row_hi, p=131071, rows=None):
+    """The row block [row_lo, row_hi) of 32x32x32_15096_L as CSR over Z_p: (m, n, rowptr, col, val)."""
+    if rows is None:
+        _, n, rows = l32_rows(p)
+    else:
+        n = 1 + max(c for r in rows for c, _ in r)
+    rp, c, v = [0], [], []
+    for i in range(row_lo, row_hi):
+        for j, x in rows[i]:
+            c.append(j)
+            v.append(x)
+        rp.append(len(c))
+    return row_hi - row_lo, n, rp, c, v
+
+
+def write_sms(path, m, n, rp, c, v):
+    with open(path, "w") as f:
+        f.write("%d %d M\n" % (m, n))
+        for i in range(m):
+            for k in range(rp[i], rp[i + 1]):
+                f.write("%d %d %d\n" % (i + 1, c[k] + 1, v[k]))
+        f.write("0 0 0\n")
+
+
+def l32_cut_b(p=131071, rows=None):
+    """Second cut: rows [0,24) and the first two rows of >= 768 entries of 32x32x32_15096_L, each cut to its first 256
+    entries (so that the literal oracle still walks it): rows of up to four 64-lane chunks on the device."""
+    if rows is None:
+        _, _, rows = l32_rows(p)
+    sel = list(range(24)) + [i for i, r in enumerate(rows) if len(r) >= 768][:2]
+    rp, c, v = [0], [], []
+    for i in sel:
+        for j, x in rows[i][:256]:
+            c.append(j)
+            v.append(x)
+        rp.append(len(c))
+    return len(sel), 1024, rp, c, v
