@@ -258,7 +258,7 @@ int build_big_plan(plo_plan *pl)
     }
     pl->pairs0 = pairs0; pl->distinct0 = keys.size();
     pl->algo_bytes = 8ull * nnz + 16ull * keys.size();       // distinct-triple form of B_cand for HBM-resident candidates
-    B.prune = getenv("PLO_BIG_PRUNE") ? 1u : 0u;
+    B.prune = getenv("PLO_BIG_NOPRUNE") ? 0u : 1u;
     if (B.prune) {   // triples of frequency 1 are never chosen and never grow: they are not kept (plo_cse_big.hip, "pruning")
         size_t w = 0;
         for (size_t k = 0; k < keys.size(); ++k) if (cnts[k] >= 2u) { keys[w] = keys[k]; cnts[w] = cnts[k]; ++w; }
@@ -266,7 +266,8 @@ int build_big_plan(plo_plan *pl)
     }
     const uint32_t multcap = (uint32_t)std::min<uint64_t>((uint64_t)naive / 2 + 8, NC);
     uint64_t cap = 1024;
-    while (cap < (B.prune ? keys.size() + (keys.size() >> 1) + (keys.size() >> 2) : 2ull * keys.size()) + 1024ull || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;   // load <= 0.57 at the start; dead slots are reused
+    // load <= 0.5 at the start: the retirement of a pruned triple probes to the first empty slot, and dead slots are not empty
+    while (cap < 2ull * keys.size() + 1024ull || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;
     if (const char *e = getenv("PLO_BIG_HBITS")) { const long hb = strtol(e, nullptr, 10); if (hb >= 10 && hb <= 30 && (1ull << hb) > keys.size() + keys.size() / 8) cap = 1ull << hb; }   // experiment knob
     const uint32_t hbits = ceil_log2((uint32_t)std::min<uint64_t>(cap, 1ull << 31));
     if (cap > (1ull << 30)) return fail(PLO_E_CAPACITY, "pair table above 2^30 slots");
@@ -288,6 +289,19 @@ int build_big_plan(plo_plan *pl)
         (rc = upload(pl, tptr, &B.tptr)) || (rc = upload(pl, trows, &B.trows)) ||
         (rc = upload(pl, ucount, &B.ucount0)) || (rc = upload(pl, hist, &B.hist0)) || (rc = upload(pl, tab, &B.tab0))) return rc;
     B.nv = (uint32_t)dv.size(); B.vt_lds = (dv.size() <= 512 && !getenv("PLO_BIG_VT_GLOBAL")) ? 1u : 0u;   // (test knob: the global-memory value table)
+    B.mode = B.vt_lds ? 1u : 0u; B.nr = 0;
+    if (dv.size() <= 32 && !getenv("PLO_BIG_VT_GLOBAL") && !getenv("PLO_BIG_NORID")) {
+        // at most 32 values: the <= 1024 ratios v_i/v_j get identifiers (kernel mode 2: 6-byte aggregation entries, no product in the sweep)
+        const uint32_t nv = (uint32_t)dv.size();
+        std::vector<uint32_t> rat(nv * nv);
+        for (uint32_t i = 0; i < nv; ++i) for (uint32_t j = 0; j < nv; ++j) rat[i * nv + j] = (uint32_t)((uint64_t)vt[i].x * vt[j].y % p);
+        std::vector<uint32_t> rv(rat); std::sort(rv.begin(), rv.end()); rv.erase(std::unique(rv.begin(), rv.end()), rv.end());
+        std::vector<uint16_t> rt(nv * nv), iv(rv.size());
+        for (uint32_t k = 0; k < nv * nv; ++k) rt[k] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), rat[k]) - rv.begin());
+        for (size_t k = 0; k < rv.size(); ++k) iv[k] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), inv_mod(rv[k], p)) - rv.begin());   // the inverse of v_i/v_j is v_j/v_i: in the set
+        if ((rc = upload(pl, rv, &B.rval)) || (rc = upload(pl, rt, &B.rtid)) || (rc = upload(pl, iv, &B.invid))) return rc;
+        B.nr = (uint32_t)rv.size(); B.mode = 2u;
+    }
     B.invtab = nullptr;
     if (p <= (1u << 20)) {                                   // 1/x for every residue (the flush needs v_a/v_c from v_c/v_a): i^-1 = -(p/i) (p mod i)^-1
         std::vector<uint32_t> it(p, 0); it[1] = 1;
@@ -312,10 +326,13 @@ int build_big_plan(plo_plan *pl)
     { const uint32_t cb = ceil_log2(m + 2u);
       if (bb + 2u * rb + cb <= 64u && !getenv("PLO_BIG_NODUAL")) { B.agg_dual = 1u; B.agg_cb = 64u - bb - 2u * rb; if (B.agg_cb > 16u) B.agg_cb = 16u; }
       else { B.agg_dual = 0u; B.agg_cb = 16u; } }
-    const uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, 2u << B.aggbits);
-    pl->big_lds = (((B.maxf0 + 2u) & ~1u) + (B.vt_lds ? 2u * ((B.nv + 1u) & ~1u) : 0u) + scr_words) * 4u;
+    // dynamic LDS, in words: histogram, tables of the mode, then max(ProgramGen scratch, aggregation table: 2^aggbits entries of 8 bytes, 6 in mode 2)
+    const uint32_t agg_words = B.mode == 2u ? (1u << B.aggbits) + (1u << B.aggbits) / 2u : 2u << B.aggbits;
+    const uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, agg_words);
+    const uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + (B.nv * B.nv + 3u) / 4u * 2u + (B.nr + 3u) / 4u * 2u + (PLO_BIG_THREADS / 64) * PLO_RING : 0u;
+    pl->big_lds = (((B.maxf0 + 2u) & ~1u) + tab_words + scr_words) * 4u;
     if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
-    HIPCHK(hipFuncSetAttribute(B.vt_lds ? (const void *)plo::cse_big_kernel<true> : (const void *)plo::cse_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
+    HIPCHK(hipFuncSetAttribute(B.mode == 2u ? (const void *)plo::cse_big_kernel<2> : B.mode == 1u ? (const void *)plo::cse_big_kernel<1> : (const void *)plo::cse_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
     if (!pl->d_err) HIPCHK(hipMalloc((void **)&pl->d_err, sizeof(uint32_t)));
     if (!pl->d_best) HIPCHK(hipMalloc((void **)&pl->d_best, sizeof(unsigned long long)));
     if (!pl->d_next) HIPCHK(hipMalloc((void **)&pl->d_next, sizeof(unsigned long long)));
@@ -353,8 +370,9 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, g_stream));
-    if (pl->B.vt_lds) hipLaunchKernelGGL(plo::cse_big_kernel<true>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
-    else hipLaunchKernelGGL(plo::cse_big_kernel<false>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+    if (pl->B.mode == 2u) hipLaunchKernelGGL(plo::cse_big_kernel<2>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+    else if (pl->B.mode == 1u) hipLaunchKernelGGL(plo::cse_big_kernel<1>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+    else hipLaunchKernelGGL(plo::cse_big_kernel<0>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, g_stream));
     HIPCHK(hipEventSynchronize(e1));
@@ -369,6 +387,7 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
             fprintf(stderr, "# big kernel (last candidate): steps %u, full scans %u, level rebuilds %u; phase us: level %u select %u rows %u sweep1 %u flush1 %u sweep2 %u flush2 %u tail %u\n",
                     hs[0], hs[1], hs[2], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11]);
 #ifdef PLO_BIG_PROFILE
+            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[3]) fprintf(stderr, "#   sweep of the steps with >= 256 rows, all candidates: %llu trips by %llu wave-sweeps; cycles per trip: chunk wait + stores %.0f, aggregation of both chunks %.0f, rest of the loop %.0f; per wave-sweep %.0f cycles, %.1f trips\n", gp[3], gp[5], (double)gp[0] / gp[3], (double)gp[1] / gp[3], (double)gp[2] / gp[3], (double)gp[4] / gp[5], (double)gp[3] / gp[5]); }
             { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[11]) fprintf(stderr, "#   flush 1, thread 0 of every workgroup, cycles per entry (%llu entries): inverse+products %.0f, retire 1 %.0f, retire 2 %.0f\n", gp[11], (double)gp[8] / gp[11], (double)gp[9] / gp[11], (double)gp[10] / gp[11]); }
             fprintf(stderr, "#   steps by rows/step [>=256, 64.., 16.., <16]: %u %u %u %u; sweep1 us %u %u %u %u; sweep2 us %u %u %u %u; fallbacks %u %u; flushed keys %u %u\n",
                     hs[24], hs[25], hs[26], hs[27], hs[16], hs[17], hs[18], hs[19], hs[20], hs[21], hs[22], hs[23], hs[28], hs[29], hs[30], hs[31]);

@@ -63,6 +63,9 @@ struct BigPlan {
     uint32_t m, n, nnz, p, NCmax, hbits, rb, bb, unit, maxf0, M0, multcap, dmcap, hlcap, scr_stride, aggbits, mers, agg_cb, agg_dual, selcap, prune;   // agg_cb: count bits of an LDS aggregation entry; agg_dual: its key is (column, x, 1/x)
     uint64_t mu;
     uint32_t nv, vt_lds;                  // distinct values; their {value, inverse} table is staged in LDS when it has <= 512 entries
+    uint32_t mode, nr;                    // kernel instance: 0 value table in global memory, 1 in LDS, 2 ratio identifiers (nv <= 32); nr = distinct ratios v_i/v_j
+    const uint16_t *rtid, *invid;         // mode 2: identifier of v_i/v_j at [i*nv+j]; identifier of the inverse ratio
+    const uint32_t *rval;                 // mode 2: the ratio of an identifier
     const uint32_t *rs, *ent0, *tptr, *trows, *ucount0, *hist0;
     const uint2 *vt;                      // {value, inverse} per value index
     const uint32_t *invtab;               // 1/x for every residue x (p <= 2^20), or nullptr
@@ -211,6 +214,25 @@ __device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint3
     }
     return 0u;
 }
+// the same for two keys at once: both probe sequences and then both atomics are in flight together (two memory round
+// trips for the pair instead of four); o1/o2 = the frequencies before, 0 = key not found
+__device__ __forceinline__ void gtab_subn2(uint64_t *tab, uint64_t k1, uint64_t k2, uint32_t d, uint32_t hbits, uint32_t &o1, uint32_t &o2) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s1 = ghash(k1, hbits), s2 = ghash(k2, hbits);
+    uint64_t v1 = gload64(&tab[s1]), v2 = gload64(&tab[s2]);
+    bool p1 = true, p2 = true, m1 = false, m2 = false;
+    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+        if (p1) { if ((v1 >> PLO_GVB) == k1) { m1 = true; p1 = false; } else if (v1 == PLO_GEMPTY) p1 = false; else s1 = (s1 + 1u) & mask; }
+        if (p2) { if ((v2 >> PLO_GVB) == k2) { m2 = true; p2 = false; } else if (v2 == PLO_GEMPTY) p2 = false; else s2 = (s2 + 1u) & mask; }
+        if (!p1 && !p2) break;
+        if (p1) v1 = gload64(&tab[s1]);
+        if (p2) v2 = gload64(&tab[s2]);
+    }
+    uint64_t a1 = 0, a2 = 0;
+    if (m1) a1 = wg_add((unsigned long long *)&tab[s1], (unsigned long long)(0ull - (uint64_t)d));
+    if (m2) a2 = wg_add((unsigned long long *)&tab[s2], (unsigned long long)(0ull - (uint64_t)d));
+    o1 = m1 ? (uint32_t)(a1 & PLO_GVMASK) : 0u; o2 = m2 ? (uint32_t)(a2 & PLO_GVMASK) : 0u;
+}
 // frequency[key] += d (claims an empty or dead slot); returns the frequency before, 0xFFFFFFFF = table full
 __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint32_t d, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
@@ -274,6 +296,44 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_
     return done;
 }
 
+// Mode 2 (at most 32 distinct values, hence at most 1024 distinct ratios v_i/v_j): an aggregation entry is
+// (column << 10 | ratio identifier) in a u32 key array and a u16 count array -- 6 bytes per entry instead of 8, 32-bit
+// LDS operations, and no modular product in the sweep (the identifier comes from a 2-byte table lookup).
+#define PLO_RIDB 10u
+#define PLO_RING 256u                         // keys per wave in the sweep's ring (mode 2)
+struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint32_t *ring; };
+__device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *aggn, uint16_t *agglist) {
+    const uint32_t mask = (1u << aggbits) - 1u;
+    uint32_t s = (key * 0x9E3779B1u) >> (32u - aggbits);
+    uint32_t claimed = 0xFFFFFFFFu; bool done = false;
+    for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
+        const uint32_t s1 = (s + 1u) & mask;
+        const uint32_t k0 = __hip_atomic_load(&aggk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k1 = __hip_atomic_load(&aggk[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool hit0 = k0 == key, emp0 = k0 == 0xFFFFFFFFu, first = hit0 || emp0;
+        const bool hit = hit0 || (!emp0 && k1 == key), emp = emp0 || (!hit && k1 == 0xFFFFFFFFu);
+        const uint32_t t = first ? s : s1;
+        if (hit) { wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); done = true; break; }
+        if (emp) {
+            const uint32_t old = wg_cas(&aggk[t], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) { if (old != key) claimed = t; wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); done = true; break; }
+            continue;                      // somebody took the slot for another key: look at both again
+        }
+        s = (s + 2u) & mask; pr += 2u;
+    }
+    const unsigned long long cm = __builtin_amdgcn_ballot_w64(claimed != 0xFFFFFFFFu);
+    if (cm) {
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(cm);
+        uint32_t base = 0;
+        if (lane == leader) base = wg_add(aggn, (uint32_t)__builtin_popcountll(cm));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+        if (claimed != 0xFFFFFFFFu) {
+            const uint32_t idx = base + (uint32_t)__builtin_popcountll(cm & ((1ull << lane) - 1ull));
+            if (idx < PLO_AGG_LIST) agglist[idx] = (uint16_t)claimed;
+        }
+    }
+    return done;
+}
+
 // packed row entry: column (15 bits) | +-1 flag (bit 15) | value index (16 bits)
 #define PLO_ECOL(e_) ((e_) & 0x7FFFu)
 #define PLO_EUNIT(e_) (((e_) >> 15) & 1u)
@@ -293,6 +353,7 @@ struct BigShared {
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
 #ifdef PLO_BIG_PROFILE
     unsigned long long tb1[4], tb2[4]; uint32_t nb[4], fb1, fb2, fl1, fl2;   // sweep clocks by step size class, fallbacks, flushed keys
+    unsigned long long pw[8];      // sweep of the big steps, summed over waves: cycles waiting for the chunk + stores, aggregation, loop overhead; trips; wave time; waves
 #endif
     uint32_t part[8];
     uint64_t sel[PLO_BIG_SELCAP];
@@ -304,7 +365,7 @@ struct BigShared {
 // ---------------------------------------------------------------------------
 // One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
 // ---------------------------------------------------------------------------
-template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const uint2 *vts, uint32_t *errw)
+template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const BigTabs &TB, uint32_t *errw)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
     uint64_t *tab   = (uint64_t *)(ws + P.o_tab);
@@ -313,9 +374,11 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
     uint64_t *DM    = (uint64_t *)(ws + P.o_dm), *HL = (uint64_t *)(ws + P.o_hl);
     // {value, inverse} per value index: LDS copy, or global memory above 512 values.  Two typed accesses,
     // never one generic pointer: a flat load waits for vmcnt(0) AND lgkmcnt(0) and would drain every prefetch.
-    // (VTL is a template parameter: the compiler turns a run-time choice between the two address spaces into a flat load)
-    const uint2 *vtg = P.vt;
-    auto VT = [&](uint32_t vi) -> uint2 { if constexpr (VTL) return vts[vi]; else return vtg[vi]; };
+    // (MODE is a template parameter: the compiler turns a run-time choice between the two address spaces into a flat load)
+    const uint2 *vtg = P.vt; const uint2 *vts = TB.vts;
+    auto VT = [&](uint32_t vi) -> uint2 { if constexpr (MODE == 1) return vts[vi]; else return vtg[vi]; };
+    const uint16_t *rtid = TB.rtid, *invid = TB.invid; const uint32_t *rval = TB.rval; const uint32_t nv = P.nv; uint32_t *ringbase = TB.ring;   // mode 2
+    uint32_t *aggk = (uint32_t *)agg, *aggc32 = aggk + (1u << aggbits); uint16_t *aggc16 = (uint16_t *)aggc32;      // mode 2: key array, count array
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
     uint16_t *agglist = (uint16_t *)sh.sel;       // slots claimed in the aggregation table by the running sweep
     uint64_t *spill = (uint64_t *)(ws + P.o_spill); const uint32_t spillcap = P.nnz + 64u;   // new-column pairs of entries that found no room in LDS (a step touches every entry at most once)
@@ -340,7 +403,8 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
     for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; }
     for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = P.hist0[f];
     const uint32_t acb = P.agg_cb; const uint64_t AEMPTY = ~0ull << acb;
-    for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = AEMPTY;
+    if constexpr (MODE == 2) { for (uint32_t s = tid; s < (1u << aggbits); s += nth) { aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0; } }
+    else for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = AEMPTY;
     if (tid == 0) {
         uint64_t x = seed + 0x9E3779B97F4A7C15ull;
         x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
@@ -348,7 +412,7 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         sh.M = P.M0; sh.theta = P.M0 + 1u; sh.ncols = n; sh.nbadd = 0; sh.nbmul = 0; sh.nmult = 0; sh.dmcount = 0; sh.hlcount = 0;
         for (int q = 0; q < 8; ++q) sh.tph[q] = 0;
 #ifdef PLO_BIG_PROFILE
-        for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0;
+        for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0; for (int q = 0; q < 8; ++q) sh.pw[q] = 0;
 #endif
         sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0; sh.nbisect = 0; sh.spilltot = 0; sh.listover = 0;
     }
@@ -513,13 +577,20 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 const int pb = row_find(ent, base, L, b);
                 if (pb < 0) continue;
                 const uint32_t ea = ent[base + pa], eb = ent[base + pb];
-                const uint2 A = VT(PLO_EVI(ea)), B = VT(PLO_EVI(eb));
-                if (B.x != bmul(r, A.x, p, mu, mers)) continue;
+                uint32_t inv_r;
+                if constexpr (MODE == 2) {
+                    if (rval[rtid[PLO_EVI(eb) * nv + PLO_EVI(ea)]] != r) continue;
+                    inv_r = rval[rtid[PLO_EVI(ea) * nv + PLO_EVI(eb)]];
+                } else {
+                    const uint2 A = VT(PLO_EVI(ea)), B = VT(PLO_EVI(eb));
+                    if (B.x != bmul(r, A.x, p, mu, mers)) continue;
+                    inv_r = bmul(A.x, B.y, p, mu, mers);
+                }
                 const uint32_t idx = wg_add(&sh.naff, 1u);
                 uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each), row start and length; the two packed entries
                 *(uint4 *)rec = make_uint4(i, (uint32_t)pa | ((uint32_t)pb << 16), base, L);
                 *(uint2 *)(rec + 4) = make_uint2(ea, eb);
-                if (idx == 0) sh.invr = bmul(A.x, B.y, p, mu, mers);             // 1/r
+                if (idx == 0) sh.invr = inv_r;                                   // 1/r
                 len[i] = L - 1u;                                               // the sweep works from the record
                 if (PLO_EUNIT(ea)) wg_sub(&ucount[a], 1u);                     // :70-77 counts, kept incrementally
                 if (PLO_EUNIT(eb)) wg_sub(&ucount[b], 1u);
@@ -536,21 +607,36 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         // pair with a has ratio x, the pair with b has ratio r x (c < a), r/x (a < c < b) or x/r (b < c).  One LDS entry
         // per (c, x) therefore carries both retirements; the flush derives the two table keys.
         {
-            auto retire_entry = [&](uint32_t e, uint2 VA, uint2 VB) {
-                const uint32_t c = PLO_ECOL(e); const uint2 V = VT(PLO_EVI(e));
+            // ea_, eb_: the row's two removed entries (their value indices name v_a and v_b)
+            auto retire_entry = [&](uint32_t e, uint32_t ea_, uint32_t eb_, uint2 VA, uint2 VB) {
+                const uint32_t c = PLO_ECOL(e);
                 // x = v_a/v_c (c < a) or v_c/v_a (c > a) names both retired pairs; y = v_a/v_c names the pair with the new column
                 // (x itself, or 1/x: kept beside x in the entry when the bits allow, so that the flush needs no inversion)
-                const uint32_t y = bmul(VA.x, V.y, p, mu, mers);
-                const uint32_t x = c < a ? y : bmul(V.x, VA.y, p, mu, mers);
-                const uint64_t cx = ((uint64_t)c << rb) | x;
-                if (agg_add(agg, aggbits, acb, P.agg_dual ? (cx << rb) | y : cx, (uint32_t)cx ^ ((uint32_t)(cx >> 32) * 0x85EBCA6Bu), &sh.aggn, agglist)) return;
+                uint32_t x, y, q2, ins;                                        // q2: ratio of the pair with b; ins: ratio of the pair with the new column (both only on the fallback path)
+                if constexpr (MODE == 2) {
+                    const uint32_t vi = PLO_EVI(e), via = PLO_EVI(ea_);
+                    const uint32_t yid = rtid[via * nv + vi], xid = c < a ? yid : (uint32_t)rtid[vi * nv + via];
+                    if (agg_add_rid(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, &sh.aggn, agglist)) return;
+                    const uint32_t vib = PLO_EVI(eb_), bc = rval[rtid[vib * nv + vi]];                       // v_b / v_c
+                    x = rval[xid]; y = rval[yid];
+                    q2 = c < b ? bc : rval[rtid[vi * nv + vib]];
+                    ins = l0 == a ? y : bc;
+                } else {
+                    const uint2 V = VT(PLO_EVI(e));
+                    y = bmul(VA.x, V.y, p, mu, mers);
+                    x = c < a ? y : bmul(V.x, VA.y, p, mu, mers);
+                    const uint64_t cx = ((uint64_t)c << rb) | x;
+                    if (agg_add(agg, aggbits, acb, P.agg_dual ? (cx << rb) | y : cx, (uint32_t)cx ^ ((uint32_t)(cx >> 32) * 0x85EBCA6Bu), &sh.aggn, agglist)) return;
+                    q2 = c < b ? bmul(VB.x, V.y, p, mu, mers) : bmul(V.x, VB.y, p, mu, mers);
+                    ins = bmul(l0 == a ? VA.x : VB.x, V.y, p, mu, mers);
+                }
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fb1, 1u);
 #endif
                 // no room in the LDS table (the key is then absent from it for the whole sweep): retire in HBM directly.
                 // A triple that is not in the table had frequency 1 (pruned): nothing to do for it.
                 const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x);
-                const uint64_t k2 = c < b ? BKEY(c, b, bmul(VB.x, V.y, p, mu, mers)) : BKEY(b, c, bmul(V.x, VB.y, p, mu, mers));
+                const uint64_t k2 = c < b ? BKEY(c, b, q2) : BKEY(b, c, q2);
                 const uint32_t o1 = gtab_dec(tab, k1, hbits);
                 if (o1) {
                     wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
@@ -563,16 +649,131 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 }
                 // its pair with the new column is inserted after all retirements (flush, second pass)
                 const uint32_t idx = wg_add(&sh.nspill, 1u);
-                if (idx < spillcap) spill[idx] = BKEY(c, lm, bmul(l0 == a ? VA.x : VB.x, V.y, p, mu, mers)); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
+                if (idx < spillcap) spill[idx] = BKEY(c, lm, ins); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
             };
-            // Two rows per wave and trip, software-pipelined: a wave first loads the records of its next 64 rows, ONE PER LANE
-            // (a record = row start, length, the two positions, the two removed entries), and reads them back with
-            // v_readlane; the first 64 entries of the next pair of rows are requested before the current pair is worked on.
-            // A trip therefore never waits for a record -> row dependency (two memory round trips per row otherwise: most
-            // rows are one chunk long).  Prefetches are unconditional (clamped index, length 0 past the end).
+            // The sweep proper.  A wave owns the rows wave, wave + nwaves, ... of the step and first loads the records of its
+            // next 64 rows, ONE PER LANE (a record = row start, length, the two positions, the two removed entries), reading
+            // them back with v_readlane: no trip waits for a record -> row dependency.  Prefetches are unconditional
+            // (clamped index, length 0 past the end): no branch around a load.  In-place rewrite: a chunk's stores reach back
+            // at most two positions and never forward, the chunks of a row are worked on in order by one wave, and a chunk
+            // is loaded before the chunks before it are stored -- so no load sees a store.
 #define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
             const uint32_t nrw = naff > wave ? (naff - wave + nwaves - 1u) / nwaves : 0u;      // rows of this wave: wave, wave + nwaves, ...
+#ifdef PLO_BIG_PROFILE
+            unsigned long long pw0 = 0, pw1 = 0, pw2 = 0, ptr = 0, tl_ = clock64(); const unsigned long long ts_ = tl_;
+#endif
+#ifndef PLO_BIG_RING_SWEEP
+#define PLO_BIG_RING_SWEEP 0      /* measured slower than the two-row loop (0.48 s against 0.30 s of sweep per candidate): kept for reference */
+#endif
+            if constexpr (MODE == 2 && PLO_BIG_RING_SWEEP) {
+                // Mode 2: the aggregation key of an entry is 25 bits and names everything the flush needs, so the sweep is
+                // split into a PRODUCER (lock step: load a chunk, rewrite the row, compute 64 keys, append them to a ring of
+                // keys private to the wave) and a CONSUMER in which every lane owns one key at a time, probes two slots per
+                // round and takes the next key from the ring as soon as its own is settled.  A round then costs the
+                // AVERAGE number of probes of a key, not the maximum over the 64 keys of a chunk (which is 3-4 rounds at
+                // the table loads of the big steps, each an LDS round trip).
+                uint32_t *ring = ringbase + wave * PLO_RING;
+                uint32_t head = 0, tail = 0;                                   // wave-uniform, monotonic
+                uint32_t key = 0xFFFFFFFFu, slot = 0, probes = 0;              // the lane's key in flight (none: all ones)
+                uint32_t k0 = 0, ck = 0, cz = 0, cnt = 0;                      // block of records, row in the block, offset in the row
+                uint32_t Rpp = 0, Rbase = 0, RL_ = 0, Rea = 0, Reb = 0, eNext = 0;
+                bool more = nrw > 0u, fresh = true;
+                const uint64_t lt = (1ull << lane) - 1ull;
+                for (;;) {
+                    if (more && tail - head <= PLO_RING - 64u) {
+                        if (fresh) {                                           // records of the next 64 rows, and the first chunk
+                            const bool have = k0 + lane < nrw;
+                            const uint32_t qq = have ? wave + (k0 + lane) * nwaves : wave;
+                            const uint4 R0 = *(const uint4 *)(aff + 8u * qq); const uint2 R1 = *(const uint2 *)(aff + 8u * qq + 4u);
+                            Rpp = R0.y; Rbase = R0.z; RL_ = have ? R0.w : 0u; Rea = R1.x; Reb = R1.y;
+                            cnt = nrw - k0 < 64u ? nrw - k0 : 64u; ck = 0; cz = 0; fresh = false;
+                            const uint32_t L0 = RL(RL_, 0);
+                            eNext = ent[RL(Rbase, 0) + (lane < L0 ? lane : 0u)];
+                        }
+                        const uint32_t L = RL(RL_, ck), base = RL(Rbase, ck), pp = RL(Rpp, ck), ea_ = RL(Rea, ck), eb_ = RL(Reb, ck);
+                        const uint32_t pa = pp & 0xFFFFu, pb = pp >> 16, z = cz + lane, e = eNext;
+                        // cursor of the following chunk, requested now
+                        uint32_t nk = ck, nz = cz + 64u;
+                        if (nz >= L) { nk = ck + 1u; nz = 0u; }
+                        { const uint32_t kx = nk & 63u, Ln = nk < cnt ? RL(RL_, kx) : 0u, zn = nz + lane; eNext = ent[RL(Rbase, kx) + (zn < Ln ? zn : 0u)]; }
+                        const bool act = z < L && z != pa && z != pb;
+                        // the row is rewritten in the same pass (:96-110): entries right of the first removed position shift left
+                        if (act && z > pa) ent[base + z - 1u - (z > pb ? 1u : 0u)] = e;
+                        if (nz == 0u && lane == 0) ent[base + L - 2u] = (((l0 == a) ? ea_ : eb_) & 0xFFFF8000u) | lm;   // last chunk: the new column's entry goes last
+                        // keys of the chunk, compacted into the ring
+                        const uint32_t c = PLO_ECOL(e), vi = PLO_EVI(e), via = PLO_EVI(ea_);
+                        const uint32_t yid = rtid[via * nv + (act ? vi : 0u)], xid = c < a ? yid : (uint32_t)rtid[(act ? vi : 0u) * nv + via];
+                        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
+                        if (act) __hip_atomic_store(&ring[(tail + (uint32_t)__builtin_popcountll(am & lt)) & (PLO_RING - 1u)], (c << PLO_RIDB) | xid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        tail += (uint32_t)__builtin_popcountll(am);
+                        ck = nk; cz = nz;
+                        if (ck >= cnt) { k0 += 64u; fresh = true; more = k0 < nrw; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    // lanes without a key take the next ones of the ring
+                    {
+                        const uint64_t need = __builtin_amdgcn_ballot_w64(key == 0xFFFFFFFFu);
+                        const uint32_t avail = tail - head, rank = (uint32_t)__builtin_popcountll(need & lt);
+                        if (key == 0xFFFFFFFFu && rank < avail) {
+                            key = __hip_atomic_load(&ring[(head + rank) & (PLO_RING - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            slot = (key * 0x9E3779B1u) >> (32u - aggbits); probes = 0;
+                        }
+                        const uint32_t want = (uint32_t)__builtin_popcountll(need);
+                        head += want < avail ? want : avail;
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(key != 0xFFFFFFFFu)) { if (!more && head == tail) break; continue; }
+                    // one round: two slots per lane
+                    uint32_t claimed = 0xFFFFFFFFu;
+                    if (key != 0xFFFFFFFFu) {
+                        const uint32_t amask = (1u << aggbits) - 1u, s1 = (slot + 1u) & amask;
+                        const uint32_t q0 = __hip_atomic_load(&aggk[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), q1 = __hip_atomic_load(&aggk[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const bool hit0 = q0 == key, emp0 = q0 == 0xFFFFFFFFu, first = hit0 || emp0;
+                        const bool hit = hit0 || (!emp0 && q1 == key), emp = emp0 || (!hit && q1 == 0xFFFFFFFFu);
+                        const uint32_t t = first ? slot : s1;
+                        if (hit) { wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); key = 0xFFFFFFFFu; }
+                        else if (emp) {
+                            const uint32_t old = wg_cas(&aggk[t], 0xFFFFFFFFu, key);
+                            if (old == 0xFFFFFFFFu || old == key) { if (old != key) claimed = t; wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); key = 0xFFFFFFFFu; }
+                            // else: somebody took the slot for another key: look at both again next round
+                        } else {
+                            slot = (slot + 2u) & amask; probes += 2u;
+                            if (probes >= PLO_AGG_PROBES) {
+                                // no room in the LDS table (the key then stays out of it for the whole sweep): retire in HBM directly;
+                                // everything follows from the key, as in the flush.  An absent triple had frequency 1 (pruned).
+                                const uint32_t c = key >> PLO_RIDB, xid = key & ((1u << PLO_RIDB) - 1u);
+                                const uint32_t x = rval[xid], y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                                const uint32_t ry = bmul(r, y, p, mu, mers), q2 = c < b ? ry : bmul(x, sh.invr, p, mu, mers);
+                                const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x), k2 = c < b ? BKEY(c, b, q2) : BKEY(b, c, q2);
+                                const uint32_t o1 = gtab_dec(tab, k1, hbits);
+                                if (o1) {
+                                    wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
+                                    if (o1 == M) { wg_sub(&cntM[c < a ? c : a], 1u); wg_sub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
+                                }
+                                const uint32_t o2 = gtab_dec(tab, k2, hbits);
+                                if (o2) {
+                                    wg_sub(&hist[o2], 1u); if (o2 > 1u) wg_add(&hist[o2 - 1u], 1u);
+                                    if (o2 == M) { wg_sub(&cntM[c < b ? c : b], 1u); wg_sub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
+                                }
+                                const uint32_t idx = wg_add(&sh.nspill, 1u);
+                                if (idx < spillcap) spill[idx] = BKEY(c, lm, l0 == a ? y : ry); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
+                                key = 0xFFFFFFFFu;
+                            }
+                        }
+                    }
+                    // new entries: remember their slots (the flush walks the entries, not the table); one counter update per wave
+                    const uint64_t cm = __builtin_amdgcn_ballot_w64(claimed != 0xFFFFFFFFu);
+                    if (cm) {
+                        const uint32_t leader = (uint32_t)__builtin_ctzll(cm);
+                        uint32_t bs = 0;
+                        if (lane == leader) bs = wg_add(&sh.aggn, (uint32_t)__builtin_popcountll(cm));
+                        bs = RL(bs, leader);
+                        if (claimed != 0xFFFFFFFFu) { const uint32_t idx = bs + (uint32_t)__builtin_popcountll(cm & lt); if (idx < PLO_AGG_LIST) agglist[idx] = (uint16_t)claimed; }
+                    }
+                }
+            } else
             for (uint32_t k0 = 0; k0 < nrw; k0 += 64u) {
+                // two rows per trip; the first chunks of the next pair are requested before the current pair is worked on
                 const bool have = k0 + lane < nrw;
                 const uint32_t qq = have ? wave + (k0 + lane) * nwaves : wave;
                 const uint4 R0 = *(const uint4 *)(aff + 8u * qq); const uint2 R1 = *(const uint2 *)(aff + 8u * qq + 4u);
@@ -584,30 +785,37 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
 #ifdef PLO_BIG_PROFILE
                     unsigned long long tp = clock64();
 #endif
-                    // next pair: first chunks requested now
-                    const uint32_t k2 = (kk + 2u) & 63u, k3 = (kk + 3u) & 63u; const bool more = kk + 2u < 64u;
-                    const uint32_t nbaseA = RL(Rbase, k2), nLA = more ? RL(RL_, k2) : 0u, nbaseB = RL(Rbase, k3), nLB = more ? RL(RL_, k3) : 0u;
+                    const uint32_t k2 = (kk + 2u) & 63u, k3 = (kk + 3u) & 63u; const bool morep = kk + 2u < 64u;
+                    const uint32_t nbaseA = RL(Rbase, k2), nLA = morep ? RL(RL_, k2) : 0u, nbaseB = RL(Rbase, k3), nLB = morep ? RL(RL_, k3) : 0u;
                     const uint32_t nfA = ent[nbaseA + (lane < nLA ? lane : 0u)], nfB = ent[nbaseB + (lane < nLB ? lane : 0u)];
                     const uint32_t ppA = RL(Rpp, kk), ppB = RL(Rpp, kk + 1u);
                     const uint32_t paA = ppA & 0xFFFFu, pbA = ppA >> 16, paB = ppB & 0xFFFFu, pbB = ppB >> 16;
                     const uint32_t eaA = RL(Rea, kk), ebA = RL(Reb, kk), eaB = RL(Rea, kk + 1u), ebB = RL(Reb, kk + 1u);
-                    const uint2 VaA = VT(PLO_EVI(eaA)), VbA = VT(PLO_EVI(ebA)), VaB = VT(PLO_EVI(eaB)), VbB = VT(PLO_EVI(ebB));
+                    uint2 VaA = make_uint2(0, 0), VbA = VaA, VaB = VaA, VbB = VaA;
+                    if constexpr (MODE != 2) { VaA = VT(PLO_EVI(eaA)); VbA = VT(PLO_EVI(ebA)); VaB = VT(PLO_EVI(eaB)); VbB = VT(PLO_EVI(ebB)); }
                     const uint32_t Lmax = LA > LB ? LA : LB;
                     for (uint32_t z0 = 0; z0 < Lmax; z0 += 64u) {
-                        // the next 64 entries of both rows are requested before this chunk is worked on (and before it is
-                        // stored: the stores reach back at most two positions, never into the next chunk)
                         const uint32_t z = z0 + lane, zn = z + 64u;
                         const bool morez = z0 + 64u < Lmax;                       // wave-uniform: rows of one chunk issue no further load (and wait for none)
                         uint32_t neA = 0, neB = 0;
                         if (morez) { neA = ent[baseA + (zn < LA ? zn : 0u)]; neB = ent[baseB + (zn < LB ? zn : 0u)]; }
                         __builtin_amdgcn_wave_barrier();
+#ifdef PLO_BIG_PROFILE
+                        const unsigned long long t0_ = clock64();
+#endif
                         const bool actA = z < LA && z != paA && z != pbA, actB = z < LB && z != paB && z != pbB;
                         // the row is rewritten in the same pass (:96-110): entries right of the first removed position shift left
                         if (actA && z > paA) ent[baseA + z - 1u - (z > pbA ? 1u : 0u)] = eA;
                         if (actB && z > paB) ent[baseB + z - 1u - (z > pbB ? 1u : 0u)] = eB;
-                        if (actA) retire_entry(eA, VaA, VbA);
-                        if (actB) retire_entry(eB, VaB, VbB);
+#ifdef PLO_BIG_PROFILE
+                        const unsigned long long t1_ = clock64();
+#endif
+                        if (actA) retire_entry(eA, eaA, ebA, VaA, VbA);
+                        if (actB) retire_entry(eB, eaB, ebB, VaB, VbB);
                         __builtin_amdgcn_wave_barrier();
+#ifdef PLO_BIG_PROFILE
+                        { const unsigned long long t2_ = clock64(); pw0 += t1_ - t0_; pw1 += t2_ - t1_; pw2 += t0_ - tl_; tl_ = t2_; ++ptr; }
+#endif
                         if (morez) { eA = neA; eB = neB; }
                     }
                     if (lane == 0) {                       // the new column's entry goes last (len and the +-1 counters were updated by the search)
@@ -618,6 +826,9 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 }
             }
 #undef RL
+#ifdef PLO_BIG_PROFILE
+            if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[0], pw0); atomicAdd(&sh.pw[1], pw1); atomicAdd(&sh.pw[2], pw2); atomicAdd(&sh.pw[3], ptr); atomicAdd(&sh.pw[4], clock64() - ts_); atomicAdd(&sh.pw[5], 1ull); }
+#endif
         }
         BSYNC();
 #ifdef PLO_BIG_PROFILE
@@ -630,32 +841,41 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         // place to (c, that ratio) and the second pass inserts it -- the rows are not hashed a second time.
         {
             const uint32_t invr = sh.invr;
-            auto retire = [&](uint64_t k, uint32_t d) {
-                const uint32_t o = gtab_subn(tab, k, d, hbits);
+            auto retired = [&](uint64_t k, uint32_t d, uint32_t o) {       // bookkeeping of a retirement that found frequency o
                 if (o == 0u) return;                                       // not in the table: a triple of frequency 1 (pruned)
                 if (o < d) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); return; }
                 wg_sub(&hist[o], 1u); if (o > d) wg_add(&hist[o - d], 1u);
                 if (o == M) { wg_sub(&cntM[(uint32_t)(k >> abits)], 1u); wg_sub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
             };
-            if (tid == 0) retire(key, M);
+            if (tid == 0) retired(key, M, gtab_subn(tab, key, M, hbits));
             const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
             for (uint32_t e = tid; e < nslot; e += nth) {
                 const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
-                const uint64_t v = agg[s];
-                if (v == AEMPTY) continue;
-                uint64_t k = v >> acb; const uint32_t d = (uint32_t)(v & ((1ull << acb) - 1ull));
-                uint32_t y = 0;
-                if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
-                const uint32_t c = (uint32_t)(k >> rb), x = (uint32_t)(k & ((1ull << rb) - 1ull));
+                uint32_t c, x, y = 0, d;
+                if constexpr (MODE == 2) {
+                    const uint32_t kq = aggk[s];
+                    if (kq == 0xFFFFFFFFu) continue;
+                    d = aggc16[s]; c = kq >> PLO_RIDB;
+                    const uint32_t xid = kq & ((1u << PLO_RIDB) - 1u);
+                    x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                } else {
+                    const uint64_t v = agg[s];
+                    if (v == AEMPTY) continue;
+                    uint64_t k = v >> acb; d = (uint32_t)(v & ((1ull << acb) - 1ull));
+                    if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
+                    c = (uint32_t)(k >> rb); x = (uint32_t)(k & ((1ull << rb) - 1ull));
+                    if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
+                }
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fl1, 1u);
 #endif
-                if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
                 const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
                 const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
-                retire(c < a ? BKEY(c, a, x) : BKEY(a, c, x), d);
-                retire(c < b ? BKEY(c, b, x2) : BKEY(b, c, x2), d);
-                agg[s] = (((((uint64_t)c) << rb) | (l0 == a ? y : ry)) << PLO_GVB) | d;    // (c, coeff / v_c), same count
+                const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x), k2 = c < b ? BKEY(c, b, x2) : BKEY(b, c, x2);
+                uint32_t o1, o2;
+                gtab_subn2(tab, k1, k2, d, hbits, o1, o2);
+                retired(k1, d, o1); retired(k2, d, o2);
+                if constexpr (MODE != 2) agg[s] = (((((uint64_t)c) << rb) | (l0 == a ? y : ry)) << PLO_GVB) | d;    // (c, coeff / v_c), same count (mode 2: the second pass derives it again)
             }
         }
         PLO_BIG_FENCE(); BSYNC();
@@ -678,12 +898,21 @@ template <bool VTL> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
             for (uint32_t e = tid; e < nslot; e += nth) {
                 const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
-                const uint64_t v = agg[s];
-                if (v == AEMPTY) continue;                                 // (an entry rewritten by the first pass has a count below 2^acb in its low 16 bits: never this pattern)
-                agg[s] = AEMPTY;
-                const uint64_t kc = v >> PLO_GVB; const uint32_t d = (uint32_t)(v & PLO_GVMASK);
+                uint64_t k; uint32_t d;
+                if constexpr (MODE == 2) {
+                    const uint32_t kq = aggk[s];
+                    if (kq == 0xFFFFFFFFu) continue;
+                    d = aggc16[s]; aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0;
+                    const uint32_t c = kq >> PLO_RIDB, xid = kq & ((1u << PLO_RIDB) - 1u), y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                    k = BKEY(c, lm, l0 == a ? y : bmul(r, y, p, mu, mers));
+                } else {
+                    const uint64_t v = agg[s];
+                    if (v == AEMPTY) continue;                             // (an entry rewritten by the first pass has a count below 2^acb in its low 16 bits: never this pattern)
+                    agg[s] = AEMPTY;
+                    const uint64_t kc = v >> PLO_GVB; d = (uint32_t)(v & PLO_GVMASK);
+                    k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
+                }
                 if (d < 2u && P.prune) continue;                           // seen once in its only step: frequency 1 for ever, never chosen, not kept
-                const uint64_t k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
                 const uint32_t o = gtab_addn(tab, k, d, hbits);
 #ifdef PLO_BIG_PROFILE
                 wg_add(&sh.fl2, 1u);
@@ -980,16 +1209,30 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
     return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | (sh.nbmul + sh.acc1);
 }
 
-template <bool VTL> __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_kernel(BigPlan P, BigJob J)
+template <int MODE> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_big_kernel(BigPlan P, BigJob J)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t bigdyn[];                 // hist[maxf0+1] then per-wave scratch (nwaves * stride)
+    extern __shared__ __attribute__((aligned(16))) uint32_t bigdyn[];                 // hist[maxf0+1], the value / ratio tables, then per-wave scratch (nwaves * stride)
     __shared__ BigShared sh;
     __shared__ unsigned long long cur;
     uint32_t *hist = bigdyn;
-    uint2 *vts = (uint2 *)(bigdyn + ((P.maxf0 + 2u) & ~1u));       // {value, inverse} per value index (when VTL)
-    uint32_t *scratch = (uint32_t *)(vts + (VTL ? ((P.nv + 1u) & ~1u) : 0u));   // ProgramGen scratch and the CSE aggregation table share this space
+    uint32_t *nextw = bigdyn + ((P.maxf0 + 2u) & ~1u);
+    BigTabs TB{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if constexpr (MODE == 1) {                                     // {value, inverse} per value index
+        uint2 *vts = (uint2 *)nextw; nextw += 2u * ((P.nv + 1u) & ~1u);
+        for (uint32_t k = threadIdx.x; k < P.nv; k += blockDim.x) vts[k] = P.vt[k];
+        TB.vts = vts;
+    }
+    if constexpr (MODE == 2) {                                     // ratio identifiers, ratios, inverse identifiers
+        uint32_t *rv = nextw; nextw += (P.nr + 1u) & ~1u;
+        uint16_t *rt = (uint16_t *)nextw; nextw += (P.nv * P.nv + 3u) / 4u * 2u;
+        uint16_t *iv = (uint16_t *)nextw; nextw += (P.nr + 3u) / 4u * 2u;
+        for (uint32_t k = threadIdx.x; k < P.nr; k += blockDim.x) { rv[k] = P.rval[k]; iv[k] = P.invid[k]; }
+        for (uint32_t k = threadIdx.x; k < P.nv * P.nv; k += blockDim.x) rt[k] = P.rtid[k];
+        TB.rval = rv; TB.rtid = rt; TB.invid = iv;
+        TB.ring = nextw; nextw += (PLO_BIG_THREADS / 64) * PLO_RING;
+    }
+    uint32_t *scratch = nextw;                                     // ProgramGen scratch and the CSE aggregation table share this space
     uint64_t *agg = (uint64_t *)scratch;
-    if (VTL) { for (uint32_t k = threadIdx.x; k < P.nv; k += blockDim.x) vts[k] = P.vt[k]; }
     __syncthreads();
     uint8_t *ws = P.ws + (uint64_t)blockIdx.x * P.ws_stride;
     uint64_t best = ~0ull;
@@ -1000,7 +1243,7 @@ template <bool VTL> __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_k
         __syncthreads();
         if (c >= J.ncand) break;
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        uint64_t ok = big_candidate<VTL>(P, ws, seed, sh, hist, agg, P.aggbits, vts, J.err);
+        uint64_t ok = big_candidate<MODE>(P, ws, seed, sh, hist, agg, P.aggbits, TB, J.err);
         uint64_t res = 0;
         __syncthreads();
         if (ok) res = big_program_gen(P, ws, sh, scratch, J.err);
@@ -1015,6 +1258,7 @@ template <bool VTL> __global__ __launch_bounds__(PLO_BIG_THREADS) void cse_big_k
 #ifdef PLO_BIG_PROFILE
                 for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }
                 J.stats[28] = sh.fb1; J.stats[29] = sh.fb2; J.stats[30] = sh.fl1; J.stats[31] = sh.fl2;
+                for (int q = 0; q < 6; ++q) atomicAdd(&g_prof[q], sh.pw[q]);
 #endif
             }   // phase times in us
             // 64-bit cost word: the op-counts of config 5 do not fit 16 bits
