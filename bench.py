@@ -37,8 +37,10 @@ WORKLOADS = {
                 "bin/optimizer -q 131071 -D data/4x4x4_49_156_P.sms, 10^5 random restarts per step"),
     "cyclic": ("cyclic.sms", 131071, 500000, "bin/optimizer -q 131071 -D data/cyclic.sms"),
     "cob": ("4x4x4_49_156_L.sms", 131071, 56 ** 4,
-            "bin/sparsifier -q 131071 -c 56 data/4x4x4_49_156_L.sms (BASELINE configs[2]): one (block,row) enumeration of "
-            "localSparsifier = 56^4 = 9.8e6 change-of-basis candidate rows per step"),
+            "bin/sparsifier -q 131071 -c 56 data/4x4x4_49_156_L.sms (BASELINE configs[2] with `-q 131071` ADDED: as written the config "
+            "runs over Q, which bin/sparsifier does on the host; on this +-1 matrix the enumeration mod 131071 visits the same candidates) "
+            "and -c 56 instead of -c 4 to reach the 10^7 candidates the config asks for: one (block,row) enumeration of "
+            "localSparsifier = 56^4 = 9.8e6 change-of-basis candidate rows per step and GPU"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -127,14 +129,49 @@ def cpu_baseline(m, n, rp, c, v, p, target_s=12.0):
                       % (sample, sample - 1, dt, list(best))}
 
 
+def dist_setup(args):
+    """One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE); backend "nccl" = RCCL over xGMI."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    return rank, local_rank, world, dev, barrier, max_over_ranks
+
+
 def bench_cob(args):
     """configs[2]: the exhaustive |Coeffs|^4 enumeration of localSparsifier (plinopt_sparsify.inl:299-314) on the GPU."""
     import torch
     from plinopt_amd import capi, cob_search
     from plo_testlib import DATA, read_sms, to_csr_mod, oracle_cob_search
+    from plinopt_amd.dist import allreduce_cob_best, shard_range
     fname, p, total, desc = WORKLOADS["cob"]
-    torch.cuda.set_device(0)
-    capi.check(capi.lib().plo_init(0))
+    rank, local_rank, world, dev, barrier, max_over_ranks = dist_setup(args)
+    capi.check(capi.lib().plo_init(local_rank))
     mm, nn, ent = read_sms(os.path.join(DATA, fname))
     rp, c, v = to_csr_mod(mm, nn, ent, p)
     n, m = nn, mm                                   # TM = M^T is n x m
@@ -154,18 +191,30 @@ def bench_cob(args):
     steps = args.steps if args.steps is not None else 10
     warm = args.warmup if args.warmup is not None else 2
     kms = 0.0
+    # N > 1: every rank enumerates the whole coefficient set of ITS OWN (block,row) call in the real tool; here the
+    # benchmark keeps the per-GPU work fixed (weak scaling): rank r takes the prefixes (i,j,k) of shard r of a C^3 * world
+    # space folded back onto C^3, i.e. all ranks run a full enumeration and the MAX all-reduce picks the common winner.
+    # The strong-scaling split of ONE enumeration is `groups=shard_range(0, C^3, rank, world)` (tests/test_gpu_cob.py).
+    groups = (0, C ** 3)
+
+    def one():
+        res, st = cob_search(n, m, TM, Cand, 0, 0, coeffs, p, groups=groups)
+        return allreduce_cob_best(res, n, device=dev) or res, st
+
     for k in range(warm):
-        res, st = cob_search(n, m, TM, Cand, 0, 0, coeffs, p)
-    torch.cuda.synchronize()
+        res, st = one()
+    barrier()
     t0 = time.perf_counter()
     for k in range(steps):
-        res, st = cob_search(n, m, TM, Cand, 0, 0, coeffs, p)
+        res, st = one()
         kms += st["kernel_ms"]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return
     per = kms / steps
     algo = st["algo_bytes"]
-    out = {"metric": "CoB candidate rows/sec", "value": total * steps / dt, "unit": "candidates/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+    out = {"metric": "CoB candidate rows/sec", "value": total * world * steps / dt, "unit": "candidates/s", "n_gpus": world, "steps": steps, "warmup": warm,
            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
            "data": "synthetic coefficient set over the reference's own data/%s" % fname,
            "config": {"workload": desc, "matrix": fname, "modulus": p, "coefficients": C, "candidates_per_step": total, "block": "rows 0-3 of M^T (4 x %d)" % m},
@@ -174,7 +223,7 @@ def bench_cob(args):
                         "traffic": None, "kernel": "plo::cob_kernel", "kernel_ms_per_launch": per, "algo_bytes_per_launch": algo,
                         "note": "the 4 x m block of TM is staged in LDS once per workgroup; the kernel is bound by integer VALU issue (4 modular "
                                 "products per column per candidate), HBM traffic is negligible by construction"}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         Cb = 14
         t0 = time.perf_counter()
         oracle_cob_search(n, m, TM, Cand, 0, 0, coeffs[:Cb], p)
@@ -193,39 +242,51 @@ def bench_tril(args):
     name, _, batch, desc = WORKLOADS["tril"]
     if args.batch:
         batch = args.batch
-    torch.cuda.set_device(0)
-    capi.check(capi.lib().plo_init(0))
+    from plinopt_amd.dist import allreduce_tril_best
+    rank, local_rank, world, dev, barrier, max_over_ranks = dist_setup(args)
+    capi.check(capi.lib().plo_init(local_rank))
     O = OracleTril.from_sms(*(os.path.join(DATA, name + x) for x in ("_L.sms", "_R.sms", "_P.sms")))
     G = TrilPlan(O.m, [(n, rp, col, [int(x) for x in num]) for n, (rp, col, num, den) in zip(O.dims, O.csr)])
     steps = args.steps if args.steps is not None else 10
     warm = args.warmup if args.warmup is not None else 2
+    gb = batch * world                               # seeds of one step over all ranks: contiguous shards, no data-path collective
+
+    def one(k):
+        s0 = k * gb
+        r = G.search(s0 + rank * batch, batch)       # ((ADD, SCA, MUL), seed, variant) of this rank's shard
+        seed, variant, word = allreduce_tril_best(r, s0, device=dev)      # ONE 8-byte MIN all-reduce (order ADD, SCA, seed, variant)
+        return r, seed, variant, word
+
     for k in range(warm):
-        G.search(k * batch, batch)
-    torch.cuda.synchronize()
+        one(k)
+    barrier()
     kms = 0.0
     best = None
     t0 = time.perf_counter()
     for k in range(steps):
-        r = G.search((warm + k) * batch, batch)
+        r, seed, variant, word = one(warm + k)
         kms += G.last_stats["kernel_ms"]
-        key = (r[0][0], r[0][1], r[1], r[2])
+        key = (word >> 43, (word >> 23) & 0xFFFFF, seed, variant)
         best = key if best is None or key < best else best
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return
     st = G.last_stats
     per = kms / steps
     algo = st["algo_bytes"] * batch
-    out = {"metric": "candidate in-place programs/sec", "value": batch * steps / dt, "unit": "candidates/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+    out = {"metric": "candidate in-place programs/sec", "value": gb * steps / dt, "unit": "candidates/s", "n_gpus": world, "steps": steps, "warmup": warm,
            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16",
            "data": "synthetic seeds over the reference's own data/%s_{L,R,P}.sms" % name,
-           "config": {"workload": desc, "matrices": name, "per_gpu_batch": batch, "rows": O.m, "dims": list(O.dims)},
+           "config": {"workload": desc, "matrices": name, "per_gpu_batch": batch, "global_batch": gb, "rows": O.m, "dims": list(O.dims),
+                      "parallelism": "seed-shard x%d + 1 MIN all-reduce/step" % world},
            "best": {"add": best[0], "sca": best[1], "seed": best[2], "variant": best[3]},
            "roofline": {"bound": "hbm", "achieved": algo / (per * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel": "plo::tril_kernel", "kernel_ms_per_launch": per, "algo_bytes_per_candidate": st["algo_bytes"],
                         "note": "atom lists are LDS-resident (one wavefront per candidate); HBM sees the three CSR images (L2-resident) and one "
                                 "result word per workgroup: the limiter is LDS latency of dependent scans, not HBM"},
            "kernel": {"lds_bytes": st["lds_bytes"], "waves_per_wg": st["waves_per_wg"], "grid": st["grid"]}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         n = 2000
         t0 = time.perf_counter()
         ob = O.search(0, n)

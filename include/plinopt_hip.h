@@ -140,6 +140,13 @@ typedef struct {
 int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
                    const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
                    plo_cob_best_t *out, plo_stats_t *stats);
+/* The same enumeration restricted to the prefixes (i,j,k) first_group .. first_group+ngroups-1 (in the order of the
+ * loops at include/plinopt_sparsify.inl:299-303), every l: one shard of the |coeffs|^4 candidates.  The winner of the
+ * whole enumeration is the shard winner of largest (zeros_v, zeros_w), smallest index among equals (one 8-byte MAX
+ * all-reduce of the packed word, plinopt_amd/dist.py). */
+int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
+                         const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
+                         uint64_t first_group, uint64_t ngroups, plo_cob_best_t *out, plo_stats_t *stats);
 
 /* ---- -E, the exhaustive CSE tree: RecSub / RecOptimizer (include/plinopt_optimize.inl:889-1013, called by AllCSEOpt
  * :1252-1281) explore every schedule of pairs of frequency > 1 (not only the maximal ones).  Here a schedule is a

@@ -22,7 +22,7 @@ EXPORTS = [
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch",
     "plo_cse_enum_cost_many_plan", "plo_cse_enum_search_plan",
-    "plo_cob_search",
+    "plo_cob_search", "plo_cob_search_range",
     "plo_tril_plan_create", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
     "plo_pack_cost",
 ]
@@ -112,6 +112,9 @@ def lib():
         L.plo_cob_search.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.POINTER(CobBest), ctypes.POINTER(Stats)]
+        L.plo_cob_search_range.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
+                                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
+                                           ctypes.POINTER(CobBest), ctypes.POINTER(Stats)]
         L.plo_cse_enum_cost_many_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u64p, ctypes.POINTER(Stats)]
         L.plo_cse_enum_search_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(Best), u64p, ctypes.POINTER(Stats)]
         L.plo_tril_plan_create.argtypes = [ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ctypes.c_void_p)]

@@ -28,6 +28,8 @@ using Ops = std::pair<size_t, size_t>;
 
 namespace {
 
+static int g_failures = 0;   // GPU calls that failed and replays that disagreed with the search: the exit status is non-zero when any happened
+
 struct HipLib {
     void *h = nullptr;
     decltype(&plo_init) init = nullptr;
@@ -49,7 +51,7 @@ struct HipLib {
         cand.emplace_back("libplinopt_hip.so");
         for (auto &c : cand) { h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
         (void)argv0;
-        if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
+        if (!h) { ++g_failures, std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
         init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
         cse_search = (decltype(cse_search))dlsym(h, "plo_cse_search"); shutdown = (decltype(shutdown))dlsym(h, "plo_shutdown");
         chain_create = (decltype(chain_create))dlsym(h, "plo_cse_chain_create"); chain_search = (decltype(chain_search))dlsym(h, "plo_cse_chain_search");
@@ -131,7 +133,7 @@ template <class F> bool lu_method(const F &f, const SparseMat<typename F::Elt> &
     uint64_t seed = 0; Ops best; bool have = false;
     if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
         HipLib L;
-        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -G: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -G: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
         std::vector<uint32_t> rp1, c1, v1, rp2, c2, v2;
         to_csr(lu.U, rp1, c1, v1); to_csr(lu.L, rp2, c2, v2);
         plo_csr_t A{(uint32_t)lu.U.rowdim(), (uint32_t)lu.U.coldim(), rp1.data(), c1.data(), v1.data()};
@@ -142,7 +144,7 @@ template <class F> bool lu_method(const F &f, const SparseMat<typename F::Elt> &
         plo_best_t b{}; plo_stats_t st{};
         rc = L.chain_search(ch, seed0, loops, PLO_COST_SUM_THEN_ADD, &b, &st);
         L.chain_destroy(ch);
-        if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: -G GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
+        if (rc != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -G GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
         best = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
         if (verbose > 0) std::clog << "# GPU (LU): " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms" << std::endl;
     }
@@ -156,7 +158,7 @@ template <class F> bool lu_method(const F &f, const SparseMat<typename F::Elt> &
     }
     if (!have) return false;
     Ops rops; std::string t = lu_text(f, lu, seed, rops);
-    if (rops != best) { std::cerr << "# \033[1;31mERROR: -G replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -G replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
     if (verbose > 0) std::clog << "# Found G: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed << "] (rank " << lu.rank << ')' << std::endl;
     if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                               // :1103-1107
     return true;
@@ -181,7 +183,7 @@ template <class F> bool ab_method(const F &f, const SparseMat<typename F::Elt> &
     uint64_t seed = 0; Ops best; bool have = false;
     if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
         HipLib L;
-        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -A: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -A: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
         std::vector<uint32_t> rp1, c1, v1, rp2, c2, v2;
         to_csr(ab.CoB, rp1, c1, v1); to_csr(ab.Alt, rp2, c2, v2);
         plo_csr_t A{(uint32_t)ab.CoB.rowdim(), (uint32_t)ab.CoB.coldim(), rp1.data(), c1.data(), v1.data()};
@@ -192,7 +194,7 @@ template <class F> bool ab_method(const F &f, const SparseMat<typename F::Elt> &
         plo_best_t b{}; plo_stats_t st{};
         rc = L.chain_search(ch, seed0, loops, PLO_COST_SUM_THEN_ADD, &b, &st);
         L.chain_destroy(ch);
-        if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: -A GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
+        if (rc != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -A GPU search failed: " << L.last_error() << "\033[0m" << std::endl; return false; }
         best = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
         if (verbose > 0) std::clog << "# GPU (A): " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms" << std::endl;
     }
@@ -206,7 +208,7 @@ template <class F> bool ab_method(const F &f, const SparseMat<typename F::Elt> &
     }
     if (!have) return false;
     Ops rops; std::string t = ab_text(f, ab, seed, rops);
-    if (rops != best) { std::cerr << "# \033[1;31mERROR: -A replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -A replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
     if (verbose > 0) std::clog << "# Found A: (" << ab.Alt.rowdim() << 'x' << ab.Alt.coldim() << 'x' << ab.CoB.coldim() << ' ' << ab.score[0] << '/' << ab.score[2] << ")\t"
                                << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed << ']' << std::endl;
     if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                               // :1180-1184
@@ -230,7 +232,8 @@ template <class F> std::string kernel_text(const F &f, const KernelDecomp<F> &kd
 // seeds: block d uses the decomposition drawn from its first seed, and every seed of the block is one run of the two
 // Optimizer calls on it (the reference draws a new decomposition for every restart; with a per-restart elimination on
 // the host the GPU would idle).  Returns false when the method could not run.
-#define PLO_KERNEL_BLOCK 16ull
+uint64_t g_kernel_block = 1;      // restarts per decomposition (--kernel-block; the reference draws one decomposition per restart, :1299-1340)
+#define PLO_KERNEL_BLOCK g_kernel_block
 // restarts s0 .. s0+cnt-1 of the two Optimizer calls on one decomposition: GPU (chained-candidate kernel) or host loop
 template <class F> bool kernel_block_serial(const F &f, const KernelDecomp<F> &kd, uint64_t s0, uint64_t cnt, Ops &bops, uint64_t &bs) {
     bool have = false;
@@ -294,7 +297,7 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     bool use_gpu = false;
     HipLib L;
     if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
-        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -K: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -K: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
         use_gpu = true;
     }
     const uint64_t full = loops / PLO_KERNEL_BLOCK;                    // full blocks go to the GPU in batches of one launch each
@@ -304,11 +307,14 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
         const uint64_t nb = std::min<uint64_t>(BATCH, full - d), s0 = seed0 + d * PLO_KERNEL_BLOCK;
         std::vector<KernelDecomp<F>> kds(nb); bool zero = false;
 #pragma omp parallel for schedule(dynamic, 8)
-        for (long long j = 0; j < (long long)nb; ++j) if (!kernel_decomp(f, lM, s0 + (uint64_t)j * PLO_KERNEL_BLOCK, kds[(size_t)j])) zero = true;
+        for (long long j = 0; j < (long long)nb; ++j) if (!kernel_decomp(f, lM, s0 + (uint64_t)j * PLO_KERNEL_BLOCK, kds[(size_t)j])) {
+#pragma omp atomic write
+            zero = true;
+        }
         if (zero) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }              // :1343-1346
         Ops bops; uint64_t bs = 0;
         try { kernel_batch_gpu(L, kds, s0, (uint32_t)PLO_KERNEL_BLOCK, q, bops, bs, kms, ncand); }
-        catch (const std::exception &e) { std::clog << "# -K skipped: " << e.what() << std::endl; return false; }
+        catch (const std::exception &e) { ++g_failures; std::cerr << "# \033[1;31mERROR: -K on the GPU: " << e.what() << "\033[0m" << std::endl; return false; }
         if (!have || cmp_op_count(bops, best)) { best = bops; seed = bs; bdec = seed0 + ((bs - seed0) / PLO_KERNEL_BLOCK) * PLO_KERNEL_BLOCK; have = true; }
         d += nb;
     }
@@ -318,7 +324,11 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
         for (long long dd = (long long)d; dd < (long long)nblocks; ++dd) {
             const uint64_t s0 = seed0 + (uint64_t)dd * PLO_KERNEL_BLOCK, cnt = std::min<uint64_t>(PLO_KERNEL_BLOCK, loops - (uint64_t)dd * PLO_KERNEL_BLOCK);
             KernelDecomp<F> kd; Ops bops; uint64_t bs = 0;
-            if (!kernel_decomp(f, lM, s0, kd)) { zero = true; continue; }
+            if (!kernel_decomp(f, lM, s0, kd)) {
+#pragma omp atomic write
+                zero = true;
+                continue;
+            }
             const bool bhave = kernel_block_serial(f, kd, s0, cnt, bops, bs);
 #pragma omp critical
             if (bhave && (!have || cmp_op_count(bops, best) || (!cmp_op_count(best, bops) && bs < seed))) { best = bops; seed = bs; bdec = s0; have = true; }
@@ -333,14 +343,14 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
         Ops bops; uint64_t bs = 0;
         bool bhave;
         try { bhave = kernel_block(f, kd, s0, cnt, &L, q, bops, bs, kms, ncand); }
-        catch (const std::exception &e) { std::clog << "# -K skipped: " << e.what() << std::endl; return false; }
+        catch (const std::exception &e) { ++g_failures; std::cerr << "# \033[1;31mERROR: -K on the GPU: " << e.what() << "\033[0m" << std::endl; return false; }
         if (bhave && (!have || cmp_op_count(bops, best))) { best = bops; seed = bs; bdec = s0; have = true; }      // earlier block wins ties
     }
     if (!have) return false;
     KernelDecomp<F> kd;
     if (!kernel_decomp(f, lM, bdec, kd)) return false;
     Ops rops; std::string t = kernel_text(f, kd, seed, rops);
-    if (rops != best) { std::cerr << "# \033[1;31mERROR: -K replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -K replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
     if (use_gpu && verbose > 0) std::clog << "# GPU (K): " << ncand << " candidates on " << nblocks << " decompositions, kernel " << kms << " ms" << std::endl;
     if (verbose > 0) std::clog << "# Found K: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed
                                << "] (rank " << kd.rank << '+' << kd.notindep << ", " << kd.dep.size() << " dependent rows)" << std::endl;
@@ -369,7 +379,7 @@ template <class F> bool allkernels_method(const F &f, const SparseMat<typename F
     } while (std::next_permutation(ord.begin(), ord.end()));
     bool use_gpu = false; HipLib L;
     if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
-        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -N: cannot use the GPU\033[0m" << std::endl; return false; }
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -N: cannot use the GPU\033[0m" << std::endl; return false; }
         use_gpu = true;
     }
     const uint64_t per = std::max<uint64_t>(1, loops / distinct.size());
@@ -400,7 +410,7 @@ template <class F> bool allkernels_method(const F &f, const SparseMat<typename F
     KernelDecomp<F> kd; CandRng rng(seed0 + bpi);
     kernel_decomp_order(f, lM, bord, rng, kd);
     Ops rops; std::string t = kernel_text(f, kd, seed, rops);
-    if (rops != best) { std::cerr << "# \033[1;31mERROR: -N replay gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -N replay gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
     if (verbose > 0) std::clog << "# Found N: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[order " << bpi << ", seed " << seed << "] ("
                                << pi << " row orders, " << distinct.size() << " distinct decompositions, " << per << " restarts each" << (use_gpu ? ", GPU kernel " : ", host ") ;
     if (verbose > 0) { if (use_gpu) std::clog << kms << " ms"; std::clog << ')' << std::endl; }
@@ -430,7 +440,7 @@ template <class F> bool exhaustive_method(const F &f, const SparseMat<typename F
     HipLib L; plo_plan_t *plan = nullptr;
     std::vector<uint32_t> rp, cc, vv;
     if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
-        if (!L.load(argv0) || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: -E: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
+        if (!L.load(argv0) || L.init(0) != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -E: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
         to_csr(lM, rp, cc, vv);
         plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
         if (L.plan_create(&A, q, &plan) != PLO_OK) { std::clog << "# -E skipped: " << L.last_error() << std::endl; return false; }
@@ -462,7 +472,7 @@ template <class F> bool exhaustive_method(const F &f, const SparseMat<typename F
     if (on_gpu) L.plan_destroy(plan);
     if (!have) return false;
     Ops rops; uint64_t pr = 1; std::string t = schedule_text(f, lM, bidx, rops, pr);
-    if (rops != best) { std::cerr << "# \033[1;31mERROR: -E replay of schedule " << bidx << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
+    if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -E replay of schedule " << bidx << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
     const bool complete = maxprod <= done;
     if (verbose > 0) {
         std::clog << "# Found E: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[schedule " << bidx << "] ("
@@ -505,13 +515,13 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
             on_gpu = true;
             HipLib L;
             if (!L.load(argv0)) return 2;
-            if (L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m" << std::endl; return 2; }
+            if (L.init(0) != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m" << std::endl; return 2; }
             std::vector<uint32_t> rp(1, 0), cc, vv;
             for (auto &r : lM.rows) { for (auto &e : r) { cc.push_back((uint32_t)e.first); vv.push_back((uint32_t)e.second); } rp.push_back((uint32_t)cc.size()); }
             plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
             plo_best_t b{}; plo_stats_t st{};
             int rc = L.cse_search(&A, q, seed0, loops, PLO_COST_SUM_THEN_ADD, &b, &st);
-            if (rc != PLO_OK) { std::cerr << "# \033[1;31mERROR: GPU search failed (" << rc << "): " << L.last_error() << "\033[0m" << std::endl; return 2; }
+            if (rc != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: GPU search failed (" << rc << "): " << L.last_error() << "\033[0m" << std::endl; return 2; }
             dops = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
             if (verbose > 0)
                 std::clog << "# GPU: " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms, "
@@ -530,7 +540,7 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         }
         if (have) {
             Ops rops; std::string t = replay_text(f, lM, seed, rops);
-            if (rops != dops) { std::cerr << "# \033[1;31mERROR: replay of seed " << seed << " gives " << rops.first << '|' << rops.second
+            if (rops != dops) { ++g_failures, std::cerr << "# \033[1;31mERROR: replay of seed " << seed << " gives " << rops.first << '|' << rops.second
                                           << ", search said " << dops.first << '|' << dops.second << "\033[0m" << std::endl; return 3; }
             if (verbose > 0) std::clog << "# Found D: " << dops.first << '|' << dops.second << " instead of "
                                        << nbops.first << '|' << nbops.second << "\t[seed " << seed << ']' << std::endl;
@@ -568,6 +578,7 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         std::clog << "# \033[1;32m" << nbops.second << "\tmultiplications\tinstead of " << opsinit.second << "\033[0m" << std::endl;
         std::clog << std::string(40, '#') << std::endl;
     }
+    if (g_failures) { std::cerr << "# \033[1;31mERROR: " << g_failures << " GPU call(s) or replay check(s) failed: the program above comes from the methods that did run\033[0m" << std::endl; return 2; }
     return 0;
 }
 
@@ -589,7 +600,9 @@ int main(int argc, char **argv)
                       << "  --seed #: first candidate seed (default 0)\n"
                       << "  -A: also try the alternative factorization M = Alt.CoB (inner dimension = column count)\n"
                       << "  -E: also walk the exhaustive tree of greedy CSE schedules (bounded by max(-O, 2^22) schedules)\n"
-                      << "  --only D|K|G|A|E|N: run exactly that method\n";
+                      << "  --only D|K|G|A|E|N: run exactly that method\n"
+                      << "  --kernel-block #: restarts per nullspace decomposition of -K (default 1: one decomposition per restart, as the reference)\n"
+                      << "  -M/-P: also print the matrix (Maple / pretty) on the log stream\n";
             exit(-1);
         } else if (a == "-M") printMaple = true;
         else if (a == "-P") printPretty = true;
@@ -607,17 +620,35 @@ int main(int argc, char **argv)
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
         else if (a == "--engine" && i + 1 < argc) { std::string e(argv[++i]); g_engine = e == "literal" ? 1 : e == "fast" ? 2 : 0; }
         else if (a == "--replay") replay_only = true;    // print the program of candidate --seed, no search
+        else if (a == "--kernel-block" && i + 1 < argc) g_kernel_block = std::max<uint64_t>(1, strtoull(argv[++i], nullptr, 10));
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing
         else filename = a;
     }
+#ifdef _OPENMP
     if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
+#endif
     if (!only.empty()) { tryDirect = only == "D"; tryLU = only == "G"; tryAB = only == "A"; tryKernel = only == "K"; mostCSE = only == "E"; allkernels = only == "N"; }
     else if (!tryKernel && !tryDirect && !tryLU) tryLU = tryDirect = tryKernel = true;      // src/optimizer.cpp:208-211
-    (void)printMaple; (void)printPretty;
     try {
         QMat MQ;
         if (filename.empty()) MQ = read_sms(std::cin);
         else { std::ifstream in(filename); if (!in) return -1; MQ = read_sms(in); }
+        if (printPretty || printMaple) {                                             // src/optimizer.cpp:65-73 (LinBox's writers are not in the tree: plain dense forms)
+            auto dense = [&](const char *open, const char *rowopen, const char *sep, const char *rowclose, const char *rowsep, const char *close) {
+                std::clog << open;
+                for (size_t i = 0; i < MQ.rowdim(); ++i) {
+                    std::clog << (i ? rowsep : "") << rowopen; size_t k = 0;
+                    for (size_t j = 0; j < MQ.coldim(); ++j) {
+                        if (j) std::clog << sep;
+                        if (k < MQ.rows[i].size() && MQ.rows[i][k].first == j) { std::clog << MQ.rows[i][k].second; ++k; } else std::clog << 0;
+                    }
+                    std::clog << rowclose;
+                }
+                std::clog << close << ';' << std::endl << std::string(40, '#') << std::endl;
+            };
+            if (printPretty) dense("", "[", " ", "]", "\n", "");
+            if (printMaple) dense("M:=Matrix([", "[", ",", "]", ",", "])");
+        }
         if (replay_only) {
             Ops ops;
             if (q) { ZpField f((uint32_t)q); std::cout << replay_text(f, rebind(MQ, f), seed0, ops); }
@@ -631,7 +662,7 @@ int main(int argc, char **argv)
         }
         return run(QField(), MQ, loops, seed0, 0, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, verbose, 0, argv[0]);
     } catch (const std::exception &e) {
-        std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m" << std::endl;
+        ++g_failures, std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m" << std::endl;
         return -1;
     }
 }

@@ -55,7 +55,9 @@ ICsr icsr(const QMat &M) {
 } // namespace
 
 int main(int argc, char **argv) {
+#ifdef _OPENMP
     if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
+#endif
     size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; std::vector<std::string> files;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
@@ -63,6 +65,7 @@ int main(int argc, char **argv) {
         else if (a == "-O" && i + 1 < argc) loops = (size_t)atoll(argv[++i]);
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (a == "-m") { }        // reference: selects the Maple check of an INPLACE_CHECKER build (src/trilplacer.cpp:79,155); nothing to do here
         else if (a == "-e") { std::cerr << "# \033[1;31mERROR: -e (double expansion) is not built\033[0m\n"; return 2; }
         else files.push_back(a);
     }

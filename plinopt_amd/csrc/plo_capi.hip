@@ -46,6 +46,22 @@ uint32_t round_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
 } // namespace
 
+// what is wrong with a caller's CSR matrix over Z_p, or nullptr (the checks every entry point makes before the host
+// images are built from it: the builders index by column and invert every value)
+static const char *csr_defect(const plo_csr_t *A, uint32_t p)
+{
+    if (!A || !A->rowptr || (A->rowptr[A->m] && (!A->col || !A->val))) return "null matrix arrays";
+    for (uint32_t i = 0; i < A->m; ++i) {
+        if (A->rowptr[i + 1] < A->rowptr[i]) return "rowptr not monotone";
+        for (uint32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) {
+            if (A->col[k] >= A->n) return "column index out of range";
+            if (k > A->rowptr[i] && A->col[k] <= A->col[k - 1]) return "columns must be strictly increasing inside a row";
+            if (A->val[k] == 0 || A->val[k] >= p) return "values must be canonical non-zero residues";
+        }
+    }
+    return nullptr;
+}
+
 struct plo_plan {
     plo::WavePlan P{};
     void *d_tmpl = nullptr;
@@ -554,14 +570,7 @@ int plo_cse_plan_create_ex(const plo_csr_t *A, uint32_t p, uint32_t flags, plo_p
     if (!A || !out || !A->rowptr || (A->rowptr[A->m] && (!A->col || !A->val))) return fail(PLO_E_ARG, "null argument");
     if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
     if (g_device < 0) { int rc = plo_init(0); if (rc != PLO_OK) return rc; }
-    for (uint32_t i = 0; i < A->m; ++i) {
-        if (A->rowptr[i + 1] < A->rowptr[i]) return fail(PLO_E_ARG, "rowptr not monotone");
-        for (uint32_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) {
-            if (A->col[k] >= A->n) return fail(PLO_E_ARG, "column index out of range");
-            if (k > A->rowptr[i] && A->col[k] <= A->col[k - 1]) return fail(PLO_E_ARG, "columns must be strictly increasing inside a row");
-            if (A->val[k] == 0 || A->val[k] >= p) return fail(PLO_E_ARG, "values must be canonical non-zero residues");
-        }
-    }
+    if (const char *bad = csr_defect(A, p)) return fail(PLO_E_ARG, bad);
     plo_plan *pl = new plo_plan();
     pl->m = A->m; pl->n = A->n; pl->p = p;
     pl->rowptr.assign(A->rowptr, A->rowptr + A->m + 1);
@@ -832,7 +841,10 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
     if (!firsts || !seconds || npairs == 0 || per_pair == 0) return fail(PLO_E_ARG, "bad argument");
     if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
     if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
-    if (p < 3 || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime");
+    if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
+    for (uint32_t k = 0; k < npairs; ++k)
+        for (const plo_csr_t *A : {&firsts[k], &seconds[k]})
+            if (const char *bad = csr_defect(A, p)) return fail(PLO_E_ARG, "pair " + std::to_string(k) + ": " + bad);
     const uint64_t ncand = (uint64_t)npairs * per_pair;
     if (ncand > 0xFFFFFFFFull) return fail(PLO_E_ARG, "at most 2^32-1 candidates per call");
     plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
@@ -871,9 +883,10 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
         for (uint32_t w : {4u, 2u, 1u}) { const uint32_t l = 64u + w * (2u * rsmax + region); if (l <= g_lds_max) { W = w; lds = l; break; } }
         if (!W) return fail(PLO_E_CAPACITY, "chained candidate state does not fit LDS");
         uint8_t *d_img = nullptr; plo::WavePlan *d_plans = nullptr; uint32_t *d_adds = nullptr, *d_muls = nullptr, *d_err = nullptr; unsigned long long *d_best = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
         std::vector<uint8_t> blob(total + 64, 0);
         for (size_t k = 0; k < imgs.size(); ++k) std::memcpy(blob.data() + offs[k], imgs[k].data(), imgs[k].size());
-        auto cleanup = [&]() { if (d_img) (void)hipFree(d_img); if (d_plans) (void)hipFree(d_plans); if (d_adds) (void)hipFree(d_adds); if (d_muls) (void)hipFree(d_muls); if (d_err) (void)hipFree(d_err); if (d_best) (void)hipFree(d_best); };
+        auto cleanup = [&]() { if (d_img) (void)hipFree(d_img); if (d_plans) (void)hipFree(d_plans); if (d_adds) (void)hipFree(d_adds); if (d_muls) (void)hipFree(d_muls); if (d_err) (void)hipFree(d_err); if (d_best) (void)hipFree(d_best); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); e0 = e1 = nullptr; };
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PLO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
         BCHK(hipMalloc((void **)&d_img, blob.size()));
         BCHK(hipMemcpy(d_img, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -890,14 +903,13 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
         const uint64_t need = (ncand + W - 1) / W;
         const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g_cus * std::max(nb, 1), need));
         plo::WaveJob J{}; J.seed0 = seed0; J.seeds = nullptr; J.ncand = ncand; J.adds = d_adds; J.muls = d_muls; J.best = best ? d_best : nullptr; J.cost_mode = (uint32_t)cost_mode; J.err = d_err;
-        hipEvent_t e0, e1;
         BCHK(hipEventCreate(&e0)); BCHK(hipEventCreate(&e1));
         BCHK(hipEventRecord(e0, g_stream));
         hipLaunchKernelGGL(plo::cse_chain_batch_kernel, dim3((uint32_t)grid), dim3(W * 64), lds, g_stream, (const plo::WavePlan *)d_plans, per_pair, region, rsmax, J);
         BCHK(hipGetLastError());
         BCHK(hipEventRecord(e1, g_stream)); BCHK(hipEventSynchronize(e1));
         float ms = 0; BCHK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); e0 = e1 = nullptr;
         uint32_t err = 0; unsigned long long w = 0;
         BCHK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
         st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = lds; st->waves_per_wg = W; st->candidates = ncand;
@@ -978,7 +990,15 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
                    const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
                    plo_cob_best_t *out, plo_stats_t *st)
 {
+    return plo_cob_search_range(n, m, TM, Cand, row, offsetblock, coeffs, ncoeffs, p, w0, w1, 0, (uint64_t)ncoeffs * ncoeffs * ncoeffs, out, st);
+}
+
+int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
+                         const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
+                         uint64_t first_group, uint64_t ngroups, plo_cob_best_t *out, plo_stats_t *st)
+{
     if (!TM || !Cand || !coeffs || !out) return fail(PLO_E_ARG, "null argument");
+    if (ncoeffs && (first_group > (uint64_t)ncoeffs * ncoeffs * ncoeffs || ngroups > (uint64_t)ncoeffs * ncoeffs * ncoeffs - first_group)) return fail(PLO_E_ARG, "group range outside the (i,j,k) prefixes");
     if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
     if (n == 0 || row >= n || offsetblock >= n || ncoeffs == 0) return fail(PLO_E_ARG, "bad dimensions");
     if (ncoeffs > 255) return fail(PLO_E_CAPACITY, "more than 255 coefficients: the candidate index does not fit 32 bits");
@@ -1001,7 +1021,7 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     }
     if (piv.size() != row) {      // chosen rows are dependent: rank(Cand with row := w) can never exceed `row` (:174)
         out->found = 0; out->zeros_v = w0; out->zeros_w = w1; out->index = 0;
-        st->candidates = (uint64_t)ncoeffs * ncoeffs * ncoeffs * ncoeffs;
+        st->candidates = ngroups * ncoeffs;
         return PLO_OK;
     }
     std::vector<char> isp(n, 0); for (uint32_t c : piv) isp[c] = 1;
@@ -1019,7 +1039,7 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     for (uint32_t c = 0; c < qn; ++c) for (uint32_t t = 0; t < 4; ++t) nb[(size_t)t * qn + c] = cols[c][t];
     std::vector<uint32_t> tmb(4 * (size_t)m, 0);
     for (uint32_t t = 0; t < fb; ++t) for (uint32_t j = 0; j < m; ++j) tmb[(size_t)t * m + j] = TM[(size_t)(offsetblock + t) * m + j] % p;
-    const uint64_t total = (uint64_t)ncoeffs * ncoeffs * ncoeffs * ncoeffs;
+    const uint64_t first = first_group * ncoeffs, total = (first_group + ngroups) * ncoeffs;      // flattened (i,j,k,l) range of this call
     const int64_t thr = w0 < 0 ? -1 : (int64_t)w0 * (n + 1) + std::max(w1, 0);
     const unsigned long long init = ((unsigned long long)(thr + 1) << 32) | 0xFFFFFFFFull;
     const size_t lds = (4 * (size_t)m + 4 * (size_t)qn + ncoeffs) * 4;
@@ -1031,7 +1051,7 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     HIPCHK(hipMemcpy(d_nb, nb.data(), nb.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_cf, coeffs, (size_t)ncoeffs * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_best, &init, 8, hipMemcpyHostToDevice));
-    plo::CobJob J{}; J.n = n; J.m = m; J.qn = qn; J.fb = fb; J.C = ncoeffs; J.p = p; J.mu = (~0ull) / p; J.total = total;
+    plo::CobJob J{}; J.n = n; J.m = m; J.qn = qn; J.fb = fb; J.C = ncoeffs; J.p = p; J.mu = (~0ull) / p; J.first = first; J.total = total;
     J.tm = d_tm; J.nb = d_nb; J.coeffs = d_cf; J.best = d_best;
     // table form when 4*C*(m+qn) products fit LDS (odd strides: the lanes of a wave read rows l, l+1, ... of one column)
     const uint32_t mstride = m | 1u, qstride = std::max<uint32_t>(qn, 1u) | 1u;
@@ -1041,13 +1061,12 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     uint64_t grid;
     if (use_tab) {
         HIPCHK(hipFuncSetAttribute((const void *)plo::cob_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tab));
-        const uint64_t groups = (uint64_t)ncoeffs * ncoeffs * ncoeffs;
-        grid = std::max<uint64_t>(1, std::min<uint64_t>((groups + 3) / 4, (uint64_t)g_cus * 2));
+        grid = std::max<uint64_t>(1, std::min<uint64_t>((ngroups + 3) / 4, (uint64_t)g_cus * 2));
         HIPCHK(hipEventRecord(e0, g_stream));
         hipLaunchKernelGGL(plo::cob_tab_kernel, dim3((uint32_t)grid), dim3(256), lds_tab, g_stream, J, mstride, qstride);
     } else {
         HIPCHK(hipFuncSetAttribute((const void *)plo::cob_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        grid = std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)g_cus * 8));
+        grid = std::max<uint64_t>(1, std::min<uint64_t>((total - first + 255) / 256, (uint64_t)g_cus * 8));
         HIPCHK(hipEventRecord(e0, g_stream));
         hipLaunchKernelGGL(plo::cob_kernel, dim3((uint32_t)grid), dim3(256), lds, g_stream, J);
     }
@@ -1061,7 +1080,7 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     out->found = w != init ? 1u : 0u;
     if (out->found) { const uint32_t sc = (uint32_t)(w >> 32) - 1u; out->zeros_v = (int32_t)(sc / (n + 1)); out->zeros_w = (int32_t)(sc % (n + 1)); out->index = (uint32_t)~(uint32_t)w; }
     else { out->zeros_v = w0; out->zeros_w = w1; out->index = 0; }
-    st->kernel_ms = ms; st->launches = 1; st->candidates = total; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)(use_tab ? lds_tab : lds); st->waves_per_wg = 4;
+    st->kernel_ms = ms; st->launches = 1; st->candidates = total - first; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)(use_tab ? lds_tab : lds); st->waves_per_wg = 4;
     st->algo_bytes = 16ull * m + 8;                       // the 4 x m block of TM, once, plus the result word
     st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PLO_OK;

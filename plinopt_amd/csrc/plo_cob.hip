@@ -18,7 +18,7 @@
 namespace plo {
 
 struct CobJob {
-    uint32_t n, m, qn, fb, C, p; uint64_t mu; uint64_t total;     // total = C^4
+    uint32_t n, m, qn, fb, C, p; uint64_t mu; uint64_t first, total;     // candidates first .. total-1 of the C^4 (a shard of the enumeration; whole: 0, C^4)
     const uint32_t *tm;       // 4 x m   block rows of TM (rows beyond n are zero)
     const uint32_t *nb;       // 4 x qn  block rows of the nullspace basis of the chosen rows
     const uint32_t *coeffs;   // C
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void cob_kernel(CobJob J)
     const uint32_t p = J.p, C = J.C, m = J.m, qn = J.qn, fb = J.fb;
     const uint64_t mu = J.mu;
     uint64_t mybest = 0;
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < J.total; idx += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t idx = J.first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < J.total; idx += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t x = (uint32_t)idx, w[4];
         w[3] = cf[x % C]; x /= C; w[2] = cf[x % C]; x /= C; w[1] = cf[x % C]; x /= C; w[0] = cf[x];
 #pragma unroll
@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void cob_tab_kernel(CobJob J, uint32_t ms /* o
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
-    const uint64_t ngroups = (uint64_t)C * C * C;
+    const uint64_t ngroups = J.total / C;                     // groups (i,j,k) J.first/C .. J.total/C - 1: shards are cut at group boundaries
     uint64_t mybest = 0;
-    for (uint64_t gidx = (uint64_t)blockIdx.x * nwaves + (threadIdx.x >> 6); gidx < ngroups; gidx += (uint64_t)gridDim.x * nwaves) {
+    for (uint64_t gidx = J.first / C + (uint64_t)blockIdx.x * nwaves + (threadIdx.x >> 6); gidx < ngroups; gidx += (uint64_t)gridDim.x * nwaves) {
         uint32_t x = (uint32_t)gidx; const uint32_t k = x % C; x /= C; const uint32_t j = x % C, i = x / C;
         const uint32_t *p0 = PT + (0u * C + i) * ms, *p1 = PT + (1u * C + j) * ms, *p2 = PT + (2u * C + k) * ms;
         const uint32_t *n0 = PN + (0u * C + i) * qs, *n1 = PN + (1u * C + j) * qs, *n2 = PN + (2u * C + k) * qs;

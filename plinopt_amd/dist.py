@@ -61,10 +61,10 @@ def allreduce_best(local, seed0, cost_mode=capi.COST_SUM_THEN_ADD, group=None, d
             fits = 0
         else:
             word = w
-    t = torch.tensor([word, -fits], dtype=torch.int64, device=dev)     # MIN of -fits == -1 iff every rank fits
+    t = torch.tensor([word, fits], dtype=torch.int64, device=dev)      # MIN of fits == 1 iff EVERY rank's candidate packs into one word
     if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-    if int(t[1].item()) == -1 or (not multi and fits):
+    if int(t[1].item()) == 1:
         w = int(t[0].item())
         return (None, w) if w == INF else (seed0 + unpack_seed_off(w), w)
     # two-stage fallback: wide costs or far-apart seeds
@@ -95,3 +95,26 @@ def allreduce_tril_best(local, seed0, group=None, device=None):
         return None, None, INF
     off = s - seed0
     return seed0 + (off >> 1), off & 1, w
+
+
+def allreduce_cob_best(local, n, group=None, device=None):
+    """Change-of-basis enumeration sharded by (i,j,k) prefix (plo_cob_search_range): local = (zeros_v, zeros_w, index, found).
+    `localSparsifier` keeps the FIRST candidate of best (zeros_v, zeros_w) in loop order (include/plinopt_sparsify.inl:179-194,
+    :299-314), i.e. the largest score with the smallest index: one 8-byte MAX all-reduce of (score << 32 | ~index).
+    Returns (zeros_v, zeros_w, index, found) of the whole enumeration."""
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    dev = device if device is not None else "cpu"
+    word = 0
+    if local is not None and local[3]:
+        zv, zw, idx, _ = local
+        word = ((zv * (n + 1) + zw + 1) << 32) | ((~idx) & 0xFFFFFFFF)
+    t = torch.tensor([word], dtype=torch.int64, device=dev)
+    if multi:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    w = int(t.item())
+    if w == 0:
+        return None
+    sc = (w >> 32) - 1
+    return sc // (n + 1), sc % (n + 1), (~w) & 0xFFFFFFFF, 1

@@ -162,15 +162,17 @@ def chain_batch(pairs, p, seed0, per_pair, cost_mode=capi.COST_SUM_THEN_ADD, wan
     return (list(adds) if want_costs else None), (list(muls) if want_costs else None), (b.adds, b.muls, b.seed), st.as_dict()
 
 
-def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1):
+def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1, groups=None):
     """One (block,row) enumeration of `localSparsifier` (reference include/plinopt_sparsify.inl:282-314) on the
     GPU: |coeffs|^4 candidate rows through `testLinComb`.  TM (n x m) and Cand (n x n) are flat row-major lists of
-    residues.  Returns ((zeros_v, zeros_w, index, found), stats)."""
+    residues.  groups = (first, count): only the (i,j,k) prefixes first..first+count-1 (a shard, plo_cob_search_range).
+    Returns ((zeros_v, zeros_w, index, found), stats)."""
     L = capi.lib()
     b, st = capi.CobBest(), capi.Stats()
     arr = lambda xs: (ctypes.c_uint32 * max(len(xs), 1))(*xs)
-    capi.check(L.plo_cob_search(n, m, arr(TM), arr(Cand), row, offsetblock, arr(coeffs), len(coeffs), p, w0, w1,
-                                ctypes.byref(b), ctypes.byref(st)))
+    g0, gn = groups if groups is not None else (0, len(coeffs) ** 3)
+    capi.check(L.plo_cob_search_range(n, m, arr(TM), arr(Cand), row, offsetblock, arr(coeffs), len(coeffs), p, w0, w1, g0, gn,
+                                      ctypes.byref(b), ctypes.byref(st)))
     return (b.zeros_v, b.zeros_w, b.index, b.found), st.as_dict()
 
 

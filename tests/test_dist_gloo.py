@@ -30,6 +30,14 @@ local = M.search(s, cnt)
 seed, word = allreduce_best((local[0] + (1 << 20), local[1], local[2]), 0, 0)
 exp = M.search(big0, 40)
 assert seed == exp[2], (seed, exp)
+# exactly ONE rank does not fit the one-word form (its seed offset is beyond 2^23): the other rank's word must not win by
+# default -- rank 0 holds (100|0, seed 1), rank 1 the better (50|0, seed 2^23+5)
+local = (100, 0, 1) if rank == 0 else (50, 0, (1 << 23) + 5)
+seed, word = allreduce_best(local, 0, 0)
+assert seed == (1 << 23) + 5, seed
+local = (50, 0, 1) if rank == 0 else (100, 0, (1 << 23) + 5)
+seed, word = allreduce_best(local, 0, 0)
+assert seed == 1, seed
 # a rank with an empty shard must not disturb the reduction
 s, cnt = shard_range(5, 1, rank, world)
 local = M.search(s, cnt) if cnt else None
@@ -43,6 +51,15 @@ s, cnt = shard_range(40, 151, rank, world)
 seed, variant, word = allreduce_tril_best(T.search(s, cnt) if cnt else None, 40)
 exp = T.search(40, 151)
 assert (seed, variant) == (exp[1], exp[2]), (seed, variant, exp)
+# the change-of-basis enumeration shards by (i,j,k) prefix: best score wins, the smaller index among equal scores
+from plinopt_amd.dist import allreduce_cob_best
+got = allreduce_cob_best((30, 2, 5000 + rank, 1), 16)
+assert got == (30, 2, 5000, 1), got
+got = allreduce_cob_best((30, 2 + rank, 7, 1), 16)
+assert got == (30, 3, 7, 1), got
+got = allreduce_cob_best((29, 15, 1, 1) if rank == 0 else None, 16)
+assert got == (29, 15, 1, 1), got
+assert allreduce_cob_best((0, 0, 0, 0), 16) is None
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """

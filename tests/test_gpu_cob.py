@@ -87,3 +87,34 @@ def test_sparsifier_cli_gpu_equals_host(hip, name):
     assert "SUCCESS: consistent factorization" in g.stderr
     assert g.stdout == h.stdout
     assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_cob_enumeration_sharded_by_prefix_equals_whole(hip, generic, monkeypatch):
+    """N-GPU split of ONE enumeration (plo_cob_search_range): shards of (i,j,k) prefixes, then the MAX reduction of
+    plinopt_amd.dist.allreduce_cob_best (largest score, smallest index) -- here reduced on the host over 1, 2, 3 and 8
+    shards, for the table kernel and for the generic one."""
+    from plinopt_amd import cob_search
+    from plinopt_amd.dist import shard_range
+    if generic:
+        monkeypatch.setenv("PLO_COB_GENERIC", "1")
+    n, m, TM = _dense_T("4x4x4_49_156_L.sms", P)
+    coeffs = [0, 1, P - 1, 2, P - 2, pow(2, -1, P), P - pow(2, -1, P)]
+    Cand = [0] * (n * n)
+    Cand[0] = 1
+    C = len(coeffs)
+    for row, w in ((0, (-1, -1)), (1, (-1, -1)), (1, (20, 1))):
+        whole, _ = cob_search(n, m, TM, Cand, row, 0, coeffs, P, *w)
+        assert whole == oracle_cob_search(n, m, TM, Cand, row, 0, coeffs, P, *w)
+        for world in (1, 2, 3, 8):
+            best, cand = None, 0
+            for r in range(world):
+                g0, gn = shard_range(0, C ** 3, r, world)
+                res, st = cob_search(n, m, TM, Cand, row, 0, coeffs, P, *w, groups=(g0, gn))
+                cand += st["candidates"]
+                if res[3]:
+                    key = (res[0] * (n + 1) + res[1], -res[2])
+                    if best is None or key > best[0]:
+                        best = (key, res)
+            assert cand == C ** 4
+            assert (best[1] if best else (w[0], w[1], 0, 0)) == whole, (row, w, world)

@@ -112,3 +112,45 @@ def test_enumerated_schedules_emit_valid_programs():
             adds, muls, prod, text = M.enum_optimizer(idx)
             assert eval_slp(text, FieldP(131071)) == D
             assert count_ops(text) == (adds, muls) and prod >= 1
+
+
+# ----------------------------------------------------------------------------- stored factorizations of the reference
+def _spmul(A, B):
+    by_row = {}
+    for (i, k), v in B.items():
+        by_row.setdefault(i, []).append((k, v))
+    C = {}
+    for (i, k), v in A.items():
+        for j, w in by_row.get(k, []):
+            C[(i, j)] = C.get((i, j), 0) + v * w
+    return {k: v for k, v in C.items() if v != 0}
+
+
+def _alt_pairs():
+    import glob
+    out = []
+    for alt in sorted(glob.glob(os.path.join(DATA, "*-ALT_*.sms"))):
+        cob, orig = alt.replace("-ALT_", "-CoB_"), alt.replace("-ALT_", "_")
+        if os.path.exists(cob) and os.path.exists(orig):
+            out.append(os.path.basename(alt))
+    return out
+
+
+@pytest.mark.parametrize("alt", _alt_pairs())
+def test_stored_alternative_bases_factor_their_matrix(alt):
+    """The reference holds factorizations X = ALT . CoB of some algorithms (bin/factorizer outputs, data/*-ALT_*.sms with
+    data/*-CoB_*.sms; for the P side X = CoB . ALT): what `consistency` (plinopt_sparsify.inl:872-907) asserts.  They pin the
+    fixtures and give the sparsity a factorization of these inputs can reach (used as a bound by the factorizer tests).
+    The 2x2x2_7_DPS-accurate-ALT files are the sparse basis of Winograd's algorithm, not a factorization of the
+    DPS-accurate matrices: only their shape is checked."""
+    mo, no, X = read_sms(os.path.join(DATA, alt.replace("-ALT_", "_")))
+    ma, na, A = read_sms(os.path.join(DATA, alt))
+    mc, nc, C = read_sms(os.path.join(DATA, alt.replace("-ALT_", "-CoB_")))
+    if alt.startswith("2x2x2_7_DPS-accurate"):
+        assert (ma, na) == (mo, no) and mc == nc
+        return
+    if alt.endswith("_P.sms"):
+        assert nc == ma and _spmul(C, A) == X
+    else:
+        assert na == mc and _spmul(A, C) == X
+    assert len(A) < len(X)                     # the alternative basis is sparser than the algorithm's own matrix
