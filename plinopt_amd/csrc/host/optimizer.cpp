@@ -504,6 +504,49 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         std::clog << "# -K/-G/-A/-N skipped: host elimination of a " << lM.rowdim() << 'x' << lM.coldim() << " matrix is not attempted (use -D)" << std::endl;
         tryAB = tryKernel = tryLU = allkernels = false;
     }
+    // --gpu N, N >= 2: the direct method's seed range in N contiguous shards, one forked child and one device per shard,
+    // minimum under (cmpOpCount, seed) in the parent -- before anything in this process touches the HIP runtime.
+    struct { bool done = false; Ops ops; uint64_t seed = 0; } sharded;
+    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0) {
+        const bool host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob: every shard on the host engine
+        std::vector<uint32_t> rp(1, 0), cc, vv;
+        for (auto &r : lM.rows) { for (auto &e : r) { cc.push_back((uint32_t)e.first); vv.push_back((uint32_t)e.second); } rp.push_back((uint32_t)cc.size()); }
+        auto shard = [&](int, int device, uint64_t s0, uint64_t cnt) {
+            ShardOut o{};
+            if (cnt == 0) { o.ok = 1; o.a = o.b = 0xFFFFFFFFu; return o; }
+            if (host_engine) {
+#ifdef _OPENMP
+                omp_set_num_threads(1);                                                // a forked child keeps to its own thread
+#endif
+                Ops b; uint64_t bs = 0;
+                if (host_search(f, lM, s0, (size_t)cnt, b, bs)) { o.ok = 1; o.a = (uint32_t)b.first; o.b = (uint32_t)b.second; o.seed = bs; o.candidates = cnt; }
+                return o;
+            }
+            HipLib L;
+            if (!L.load(argv0) || L.init(device) != PLO_OK) { snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error ? L.last_error() : "library missing"); return o; }
+            plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
+            plo_best_t b{}; plo_stats_t st{};
+            const int rc = L.cse_search(&A, q, s0, cnt, PLO_COST_SUM_THEN_ADD, &b, &st);
+            if (rc != PLO_OK) { snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error()); return o; }
+            o.ok = 1; o.a = b.adds; o.b = b.muls; o.seed = b.seed; o.candidates = st.candidates; o.kernel_ms = st.kernel_ms;
+            L.shutdown();
+            return o;
+        };
+        std::vector<ShardOut> outs;
+        if (!forked_shards(gpu, seed0, loops, shard, outs)) {
+            for (auto &o : outs) if (!o.ok) ++g_failures, std::cerr << "# \033[1;31mERROR: shard failed: " << o.msg << "\033[0m" << std::endl;
+            return 2;
+        }
+        bool have = false; uint64_t total = 0; double kmax = 0;
+        for (auto &o : outs) {
+            total += o.candidates; kmax = std::max(kmax, o.kernel_ms);
+            if (o.a == 0xFFFFFFFFu && o.b == 0xFFFFFFFFu) continue;
+            const Ops ops{o.a, o.b};
+            if (!have || cmp_op_count(ops, sharded.ops) || (!cmp_op_count(sharded.ops, ops) && o.seed < sharded.seed)) { sharded.ops = ops; sharded.seed = o.seed; have = true; }
+        }
+        sharded.done = have;
+        if (verbose > 0) std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one GPU each)") << ": " << total << " candidates, slowest kernel " << kmax << " ms" << std::endl;
+    }
     if (tryAB) {                                                                      // :1436-1440 (inner dimension = column count)
         try { ab_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
         catch (const std::exception &e) { std::clog << "# -A skipped: " << e.what() << std::endl; }
@@ -511,7 +554,8 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
     if (tryDirect) {
         Ops dops; uint64_t seed = 0; bool have = false;
         bool on_gpu = false;
-        if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+        if (sharded.done) { on_gpu = true; dops = sharded.ops; seed = sharded.seed; have = loops > 0; }
+        if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0 && !sharded.done) {
             on_gpu = true;
             HipLib L;
             if (!L.load(argv0)) return 2;
@@ -596,7 +640,7 @@ int main(int argc, char **argv)
                       << "  -D/-K/-G: direct/kernel/LU methods (default is all)\n"
                       << "  -q #: search modulo (default is Rationals, on the host)\n"
                       << "  -O #: randomized search with that many loops (default " << loops << " loops)\n"
-                      << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only\n"
+                      << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only, N >= 2 = the seeds of -D in N shards, one GPU each\n"
                       << "  --seed #: first candidate seed (default 0)\n"
                       << "  -A: also try the alternative factorization M = Alt.CoB (inner dimension = column count)\n"
                       << "  -E: also walk the exhaustive tree of greedy CSE schedules (bounded by max(-O, 2^22) schedules)\n"

@@ -14,6 +14,8 @@
 #define PLO_HOST_HPP
 
 #include <algorithm>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <array>
 #include <cstdint>
 #include <cstdlib>
@@ -771,5 +773,57 @@ inline bool cmp_op_count(std::pair<size_t, size_t> a, std::pair<size_t, size_t> 
     return as < bs || (as == bs && a.first < b.first);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Seed shards over several GPUs of one node from a command-line tool: one forked child per device (`--gpu N`, N >= 2).
+// The candidates of a restart loop are independent (reference: iterations of `#pragma omp parallel for`,
+// include/plinopt_optimize.inl:1204-1205, plinopt_inplace.inl:837-838), so rank r takes the r-th contiguous block of
+// the seed range and the parent keeps the minimum under the tools' total order (cost, seed): the winner is the one a
+// single device finds.  Children are forked BEFORE this process touches the HIP runtime (a runtime does not survive
+// fork) and each opens its own device; results come back over a pipe as plain structs.
+// PLO_GPU_DEVICES="0,0,1": device ordinal per shard (default: shard r on device r) -- lets a one-GPU box run N shards.
+struct ShardOut { int32_t ok; uint32_t a, b, c; uint64_t seed; uint64_t variant; uint64_t candidates; double kernel_ms; char msg[192]; };
+inline void shard_block(uint64_t seed0, uint64_t n, int rank, int world, uint64_t &s, uint64_t &cnt) {
+    const uint64_t q = n / (uint64_t)world, r = n % (uint64_t)world;
+    s = seed0 + (uint64_t)rank * q + std::min<uint64_t>((uint64_t)rank, r); cnt = q + ((uint64_t)rank < r ? 1 : 0);
+}
+inline int shard_device(int rank) {
+    if (const char *e = getenv("PLO_GPU_DEVICES")) {
+        std::string t(e); size_t pos = 0; int k = 0;
+        while (pos <= t.size()) { size_t c = t.find(',', pos); if (c == std::string::npos) c = t.size(); if (k == rank) return atoi(t.substr(pos, c - pos).c_str()); pos = c + 1; ++k; }
+    }
+    return rank;
+}
+// fn(rank, device, first seed, count) -> ShardOut, run in a child process per shard; returns false when a child failed
+template <class Fn> bool forked_shards(int world, uint64_t seed0, uint64_t n, Fn fn, std::vector<ShardOut> &out) {
+    out.assign((size_t)world, ShardOut{});
+    std::vector<int> fds((size_t)world, -1); std::vector<pid_t> pids((size_t)world, -1);
+    for (int r = 0; r < world; ++r) {
+        int pfd[2]; if (pipe(pfd) != 0) return false;
+        std::cout.flush(); std::clog.flush();
+        const pid_t pid = fork();
+        if (pid < 0) return false;
+        if (pid == 0) {
+            close(pfd[0]);
+            uint64_t s, cnt; shard_block(seed0, n, r, world, s, cnt);
+            ShardOut o{};
+            try { o = fn(r, shard_device(r), s, cnt); } catch (const std::exception &e) { o.ok = 0; snprintf(o.msg, sizeof o.msg, "%s", e.what()); }
+            ssize_t w = write(pfd[1], &o, sizeof o); (void)w;
+            close(pfd[1]);
+            _exit(0);
+        }
+        close(pfd[1]); fds[(size_t)r] = pfd[0]; pids[(size_t)r] = pid;
+    }
+    bool good = true;
+    for (int r = 0; r < world; ++r) {
+        size_t got = 0; char *dst = (char *)&out[(size_t)r];
+        while (got < sizeof(ShardOut)) { ssize_t k = read(fds[(size_t)r], dst + got, sizeof(ShardOut) - got); if (k <= 0) break; got += (size_t)k; }
+        close(fds[(size_t)r]);
+        int status = 0; waitpid(pids[(size_t)r], &status, 0);
+        if (got != sizeof(ShardOut) || !WIFEXITED(status) || WEXITSTATUS(status) != 0) { out[(size_t)r].ok = 0; if (!out[(size_t)r].msg[0]) snprintf(out[(size_t)r].msg, sizeof out[(size_t)r].msg, "shard process died"); }
+        if (!out[(size_t)r].ok) good = false;
+    }
+    return good;
+}
 } // namespace plo
 #endif

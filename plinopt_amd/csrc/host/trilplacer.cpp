@@ -61,7 +61,7 @@ int main(int argc, char **argv) {
     size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; std::vector<std::string> files;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
-        if (a == "-h") { std::clog << "Usage: " << argv[0] << " L.sms R.sms P.sms [-O #] [--seed s] [--gpu 0|1]\n"; return 0; }
+        if (a == "-h") { std::clog << "Usage: " << argv[0] << " L.sms R.sms P.sms [-O #] [--seed s] [--gpu 0|1|N: N >= 2 shards the restarts over N GPUs]\n"; return 0; }
         else if (a == "-O" && i + 1 < argc) loops = (size_t)atoll(argv[++i]);
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
@@ -82,40 +82,81 @@ int main(int argc, char **argv) {
         bool on_gpu = false; double kms = 0;
         if (loops > 0) {
             ICsr ca = icsr(A), cb = icsr(B), ct = icsr(T);
-            if (gpu && ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full) {
+            const bool device_ok = ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full;
+            using Key = std::tuple<size_t, size_t, uint64_t, int>;      // (ADD, SCA, seed, variant): the order of :893-897 made total
+            // restarts s0 .. s0+cnt-1 on one device (plo_tril_search); throws on failure
+            auto gpu_search = [&](int device, uint64_t s0, uint64_t cnt, plo_tril_best_t &r, plo_stats_t &st) {
                 HipTril L;
-                if (!L.load()) return 2;                                  // no silent fallback: --gpu 0 selects the host loop
-                if (L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m\n"; return 2; }
+                if (!L.load()) throw std::runtime_error("cannot load libplinopt_hip.so");        // no silent fallback: --gpu 0 selects the host loop
+                if (L.init(device) != PLO_OK) throw std::runtime_error(L.last_error());
                 plo_icsr_t a{(uint32_t)A.rowdim(), (uint32_t)A.coldim(), ca.rp.data(), ca.col.data(), ca.val.data()};
                 plo_icsr_t b{(uint32_t)B.rowdim(), (uint32_t)B.coldim(), cb.rp.data(), cb.col.data(), cb.val.data()};
                 plo_icsr_t t{(uint32_t)T.rowdim(), (uint32_t)T.coldim(), ct.rp.data(), ct.col.data(), ct.val.data()};
                 plo_tril_plan_t *plan = nullptr;
-                if (L.create(&a, &b, &t, &plan) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m\n"; return 2; }
-                plo_tril_best_t r{}; plo_stats_t st{};
-                if (L.search(plan, seed0, loops, &r, &st) != PLO_OK) { std::cerr << "# \033[1;31mERROR: " << L.last_error() << "\033[0m\n"; L.destroy(plan); return 2; }
+                if (L.create(&a, &b, &t, &plan) != PLO_OK) throw std::runtime_error(L.last_error());
+                const int rc = L.search(plan, s0, cnt, &r, &st);
+                const std::string msg = rc != PLO_OK ? L.last_error() : "";
                 L.destroy(plan);
-                on_gpu = true; kms = st.kernel_ms;
-                const Tricount g{r.add, r.sca, r.mul};
-                if (better(g, best)) { best = g; bseed = r.seed; bvar = (int)r.variant; }
-            } else {
-                if (gpu) std::clog << "# matrices are not +-1 without empty rows: host search" << std::endl;
-                // best of the loop under (ADD, SCA, seed, variant), then strictly better than the unpermuted program
-                using Key = std::tuple<size_t, size_t, uint64_t, int>;
+                if (rc != PLO_OK) throw std::runtime_error(msg);
+            };
+            // the same restarts on the host: best of the loop under Key
+            auto host_loop = [&](uint64_t s0, uint64_t cnt) {
                 Key lb{~(size_t)0, ~(size_t)0, 0, 0};
                 #pragma omp parallel
                 {
                     Key tb = lb;
                     #pragma omp for schedule(dynamic, 16)
-                    for (long long k = 0; k < (long long)loops; ++k) {
-                        TrilCandidate c = tril_candidate(A, B, T, seed0 + (uint64_t)k, -1);
-                        for (int v = 0; v < 2; ++v) tb = std::min(tb, Key{c.ops[v][0], c.ops[v][1], seed0 + (uint64_t)k, v});
+                    for (long long k = 0; k < (long long)cnt; ++k) {
+                        TrilCandidate c = tril_candidate(A, B, T, s0 + (uint64_t)k, -1);
+                        for (int v = 0; v < 2; ++v) tb = std::min(tb, Key{c.ops[v][0], c.ops[v][1], s0 + (uint64_t)k, v});
                     }
                     #pragma omp critical
                     lb = std::min(lb, tb);
                 }
-                const Tricount g{std::get<0>(lb), std::get<1>(lb), A.rowdim()};
-                if (better(g, best)) { best = g; bseed = std::get<2>(lb); bvar = std::get<3>(lb); }
-            }
+                return lb;
+            };
+            try {
+                if (gpu >= 2 && (device_ok || (getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host"))) {
+                    // --gpu N: N contiguous seed shards, one forked child and one device each; minimum under Key in the parent
+                    const bool host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob
+                    auto shard = [&](int, int device, uint64_t s0, uint64_t cnt) {
+                        ShardOut o{};
+                        if (cnt == 0) { o.ok = 1; o.a = o.b = 0xFFFFFFFFu; return o; }
+                        if (host_engine) {
+#ifdef _OPENMP
+                            omp_set_num_threads(1);
+#endif
+                            const Key k = host_loop(s0, cnt);
+                            o.ok = 1; o.a = (uint32_t)std::get<0>(k); o.b = (uint32_t)std::get<1>(k); o.c = (uint32_t)A.rowdim(); o.seed = std::get<2>(k); o.variant = (uint64_t)std::get<3>(k); o.candidates = cnt;
+                            return o;
+                        }
+                        plo_tril_best_t r{}; plo_stats_t st{};
+                        gpu_search(device, s0, cnt, r, st);
+                        o.ok = 1; o.a = r.add; o.b = r.sca; o.c = r.mul; o.seed = r.seed; o.variant = r.variant; o.candidates = cnt; o.kernel_ms = st.kernel_ms;
+                        return o;
+                    };
+                    std::vector<ShardOut> outs;
+                    if (!forked_shards(gpu, seed0, loops, shard, outs)) { for (auto &o : outs) if (!o.ok) std::cerr << "# \033[1;31mERROR: shard failed: " << o.msg << "\033[0m\n"; return 2; }
+                    Key lb{~(size_t)0, ~(size_t)0, 0, 0}; uint32_t mul = (uint32_t)A.rowdim();
+                    for (auto &o : outs) { if (o.a == 0xFFFFFFFFu && o.b == 0xFFFFFFFFu) continue; const Key k{o.a, o.b, o.seed, (int)o.variant}; if (k < lb) { lb = k; mul = o.c; } kms = std::max(kms, o.kernel_ms); }
+                    on_gpu = !host_engine;
+                    std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one GPU each)") << std::endl;
+                    const Tricount g{std::get<0>(lb), std::get<1>(lb), mul};
+                    if (better(g, best)) { best = g; bseed = std::get<2>(lb); bvar = std::get<3>(lb); }
+                } else if (gpu && device_ok) {
+                    plo_tril_best_t r{}; plo_stats_t st{};
+                    gpu_search(0, seed0, loops, r, st);
+                    on_gpu = true; kms = st.kernel_ms;
+                    const Tricount g{r.add, r.sca, r.mul};
+                    if (better(g, best)) { best = g; bseed = r.seed; bvar = (int)r.variant; }
+                } else {
+                    if (gpu) std::clog << "# matrices are not +-1 without empty rows: host search" << std::endl;
+                    // best of the loop under (ADD, SCA, seed, variant), then strictly better than the unpermuted program
+                    const Key lb = host_loop(seed0, loops);
+                    const Tricount g{std::get<0>(lb), std::get<1>(lb), A.rowdim()};
+                    if (better(g, best)) { best = g; bseed = std::get<2>(lb); bvar = std::get<3>(lb); }
+                }
+            } catch (const std::exception &e) { std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m\n"; return 2; }
         }
         // replay of the winner for the text
         std::string text;

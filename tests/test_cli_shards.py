@@ -1,0 +1,77 @@
+"""`--gpu N` (N >= 2) of bin/optimizer and bin/trilplacer: the restarts in N contiguous seed shards, one forked child per
+shard, minimum under the tools' total order in the parent (plo_host.hpp `forked_shards`).  The winner and the printed
+program must be those of the unsharded search (reference: the iterations of `#pragma omp parallel for` are independent,
+include/plinopt_optimize.inl:1204-1238, plinopt_inplace.inl:837-924).  CPU: every shard on the host engine
+(PLO_SHARD_ENGINE=host); GPU (-m gpu): every shard on device 0 of the box (PLO_GPU_DEVICES=0,0,...)."""
+import os
+import subprocess
+
+import pytest
+
+from plo_testlib import DATA, ROOT
+
+P = 131071
+OPT = os.path.join(ROOT, "bin", "optimizer")
+TRIL = os.path.join(ROOT, "bin", "trilplacer")
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
+    return r.returncode, r.stdout, r.stderr
+
+
+def _found(err, tag):
+    return [ln for ln in err.splitlines() if ln.startswith(tag)]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _tools():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+
+
+@pytest.mark.parametrize("name,loops", [("4x4x4_49_156_L.sms", 301), ("2x2x2_7_Winograd_L.sms", 7), ("4x4x4_48_rational_P.sms", 64)])
+@pytest.mark.parametrize("world", [2, 5])
+def test_optimizer_shards_equal_one_process(name, loops, world):
+    path = os.path.join(DATA, name)
+    rc0, out0, err0 = _run([OPT, "-q", str(P), "-D", "-O", str(loops), "--seed", "11", "--gpu", "0", path])
+    rcn, outn, errn = _run([OPT, "-q", str(P), "-D", "-O", str(loops), "--seed", "11", "--gpu", str(world), path], {"PLO_SHARD_ENGINE": "host"})
+    assert rc0 == 0 and rcn == 0, err0 + errn
+    assert out0 == outn and _found(err0, "# Found D") == _found(errn, "# Found D")
+    assert ("# %d shards (host engine): %d candidates" % (world, loops)) in errn
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_trilplacer_shards_equal_one_process(world):
+    files = [os.path.join(DATA, "4x4x4_49_156" + x) for x in ("_L.sms", "_R.sms", "_P.sms")]
+    rc0, out0, err0 = _run([TRIL] + files + ["-O", "150", "--seed", "9", "--gpu", "0"])
+    rcn, outn, errn = _run([TRIL] + files + ["-O", "150", "--seed", "9", "--gpu", str(world)], {"PLO_SHARD_ENGINE": "host"})
+    assert rc0 == 0 and rcn == 0, err0 + errn
+    assert out0 == outn and _found(err0, "# Found") == _found(errn, "# Found")
+
+
+def test_a_failing_shard_is_an_error():
+    """a shard that cannot open its device (no GPU in the CPU test container) fails the run: exit status 2, no program"""
+    path = os.path.join(DATA, "2x2x2_7_Winograd_L.sms")
+    rc, out, err = _run([OPT, "-q", str(P), "-D", "-O", "8", "--gpu", "2", path], {"PLINOPT_HIP_LIB": "/nonexistent/libplinopt_hip.so", "PLO_GPU_DEVICES": "97,98"})
+    assert rc == 2 and "shard failed" in err and out == ""
+
+
+@pytest.mark.gpu
+def test_optimizer_two_shards_on_the_gpu(hip):
+    path = os.path.join(DATA, "4x4x4_49_156_L.sms")
+    rc1, out1, err1 = _run([OPT, "-q", str(P), "-D", "-O", "20001", "--seed", "3", path])
+    rc2, out2, err2 = _run([OPT, "-q", str(P), "-D", "-O", "20001", "--seed", "3", "--gpu", "2", path], {"PLO_GPU_DEVICES": "0,0"})
+    assert rc1 == 0 and rc2 == 0, err1 + err2
+    assert out1 == out2 and _found(err1, "# Found D") == _found(err2, "# Found D")
+    assert "# 2 shards (one GPU each): 20001 candidates" in err2
+
+
+@pytest.mark.gpu
+def test_trilplacer_two_shards_on_the_gpu(hip):
+    files = [os.path.join(DATA, "4x4x4_49_156" + x) for x in ("_L.sms", "_R.sms", "_P.sms")]
+    rc1, out1, err1 = _run([TRIL] + files + ["-O", "3001", "--seed", "9"])
+    rc2, out2, err2 = _run([TRIL] + files + ["-O", "3001", "--seed", "9", "--gpu", "2"], {"PLO_GPU_DEVICES": "0,0"})
+    assert rc1 == 0 and rc2 == 0, err1 + err2
+    assert out1 == out2 and _found(err1, "# Found") == _found(err2, "# Found")

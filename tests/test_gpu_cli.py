@@ -109,19 +109,22 @@ def test_ab_method_on_gpu_equals_host_search(name):
 
 @pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "2x2x2_7_Winograd_L.sms"])
 def test_kernel_method_on_gpu_equals_host_search(name):
-    """-K: decompositions on the host (one per block of 16 seeds), the two Optimizer calls of every restart on the GPU
-    (batched chained-candidate kernel: all decompositions in one launch, matrices with emptied rows); same winner and program as the host loop."""
+    """-K: one nullspace decomposition per restart (reference include/plinopt_optimize.inl:1299-1340), made on the host; the
+    two Optimizer calls of every restart on the GPU (batched chained-candidate kernel: all decompositions of a batch in one
+    launch, matrices with emptied rows); same winner and program as the host loop.  --kernel-block 16 shares one
+    decomposition between 16 restarts."""
     path = os.path.join(DATA, name)
-    rc, out, err = run([OPT, "-q", str(P), "--only", "K", "-O", "2000", path])
-    assert rc == 0, err
-    rc0, out0, err0 = run([OPT, "-q", str(P), "--only", "K", "-O", "2000", "--gpu", "0", path])
-    assert rc0 == 0, err0
-    pat = r"# Found K: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\+(\d+), (\d+) dependent rows\)"
-    g, g0 = re.search(pat, err), re.search(pat, err0)
-    assert g and g0 and g.groups() == g0.groups(), (err, err0)
-    assert "# GPU (K): 2000 candidates on 125 decompositions" in err and out == out0
-    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
-    assert rc == 0 and "SUCCESS" in err2, err2
+    for extra, ndec in (([], 2000), (["--kernel-block", "16"], 125)):
+        rc, out, err = run([OPT, "-q", str(P), "--only", "K", "-O", "2000", path] + extra)
+        assert rc == 0, err
+        rc0, out0, err0 = run([OPT, "-q", str(P), "--only", "K", "-O", "2000", "--gpu", "0", path] + extra)
+        assert rc0 == 0, err0
+        pat = r"# Found K: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\+(\d+), (\d+) dependent rows\)"
+        g, g0 = re.search(pat, err), re.search(pat, err0)
+        assert g and g0 and g.groups() == g0.groups(), (err, err0)
+        assert ("# GPU (K): 2000 candidates on %d decompositions" % ndec) in err and out == out0
+        rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+        assert rc == 0 and "SUCCESS" in err2, err2
 
 
 @pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "2x2x2_7_Winograd_P.sms", "2x2x2_7_DPS-accurate_L.sms"])

@@ -248,7 +248,7 @@ def test_kernel_method_programs_verify(name, field):
     """-K (KernelOptimiser / nullspacedecomp, plinopt_optimize.inl:689-884, :1288-1353) with the build's decomposition rule:
     a greedy row basis in a random order, the other rows as combinations of the basis outputs, some of them kept direct.
     `--only K` prints that program, which must compute the matrix with exactly the reported operation count; 600
-    restarts = 38 decompositions."""
+    restarts = 600 decompositions (one per restart, as the reference)."""
     path = os.path.join(DATA, name)
     q = ["-q", str(P), "--gpu", "0"] if field == "p" else []
     rc, out, err = run([OPT, "--only", "K", "-O", "600"] + q + [path])
