@@ -326,3 +326,60 @@ def test_direct_search_against_every_stored_program():
         assert found <= naive and found <= 2 * stored, (name, stored, found, naive)
         if name.startswith("4x4x4_49_156"):
             assert found <= stored * 1.08, (name, stored, found)
+
+
+# ----------------------------------------------------------------------------- compacter (post-pass on the winner)
+CMP = os.path.join(ROOT, "bin", "compacter")
+
+
+def _ops(err):
+    mm = re.search(r"SUCCESS: correct SLP for \S+ \(\S+\) : (\d+),(\d+) ", err)
+    return (int(mm.group(1)), int(mm.group(2))) if mm else None
+
+
+@pytest.mark.parametrize("q", [None, 7])
+def test_fdt_pipeline_optimizer_compacter_checker(q):
+    """bin/FDT.sh:58-62: `optimizer -O 10 [-q 7] file | compacter -s | SLPchecker [-q 7] -M file` on every data matrix the
+    reference's own driver takes (no -X_ placeholders, no 32x32x32; three inputs have a denominator divisible by 7).
+    The compacted program computes the matrix, has no more operations and fewer words than the optimizer's."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = [f for f in sorted(glob.glob(os.path.join(DATA, "*.sms"))) if "-X_" not in f and "32x32x32" not in f]
+    qa = ["-q", str(q)] if q else []
+    skip7 = ("2x2x2_7_DPS-integral-12.0662_P", "2x2x2_7_DPS-integral-12.0662_R", "4o4o8_Toom5_P")
+
+    def one(f):
+        if q == 7 and any(s in f for s in skip7):
+            return None
+        rc, prog, err = run([OPT, "-O", "10", "--gpu", "0"] + qa + [f])
+        assert rc == 0, (f, err)
+        rc, _, e0 = run([CHK] + qa + ["-M", f], stdin=prog)
+        assert rc == 0 and "SUCCESS" in e0, (f, e0)
+        rc, comp, ec = run([CMP, "-s"], stdin=prog)
+        assert rc == 0, (f, ec)
+        rc, _, e1 = run([CHK] + qa + ["-M", f], stdin=comp)
+        assert rc == 0 and "SUCCESS" in e1, (f, e1, comp)
+        b, a = _ops(e0), _ops(e1)
+        assert a[0] <= b[0] and a[1] <= b[1], (f, b, a)
+        mm = re.search(r"# \S*?(\d+)\telements\tinstead of (\d+)", ec)
+        assert int(mm.group(1)) <= int(mm.group(2))
+        return int(mm.group(2)) - int(mm.group(1))
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        saved = [s for s in ex.map(one, files) if s is not None]
+    assert len(saved) >= 140 and sum(1 for s in saved if s > 0) >= 0.9 * len(saved)     # the `t#:=i#;` preamble alone goes away
+
+
+def test_compacter_rewrites():
+    """the four rewrites on hand-made programs: copies, dead code, single uses (signs folded, parentheses only where a
+    product or quotient needs them), leading minus; -n keeps singly used variables; values unchanged (SLPchecker)."""
+    src = ("t0:=i0;\nt1:=i1;\nt2:=i2;\nd0:=t0*5;\nx0:=t0-t1;\nx1:=-t1+t2;\nx2:=x0*3;\nc0:=4/5;\nc1:=2/3;\nc2:=7;\nx3:=t2*c0;\n"
+           "o0:=t2-x1;\no1:=x2+x3;\no2:=t0/c1;\no3:=-t1+t0;\no4:=t0*c2+t1*c2;\n")
+    rc, out, err = run([CMP, "-s"], stdin=src)
+    assert rc == 0, err
+    assert out == "o0:=i2+i1-i2;\no1:=(i0-i1)*3+i2*(4/5);\no2:=i0/(2/3);\no3:=i0-i1;\no4:=i0*7+i1*7;\n", out
+    rc, outn, _ = run([CMP, "-n"], stdin=src)
+    assert "x0:=i0-i1;" in outn and "d0" not in outn and "t0" not in outn
+    for prog in (src, out, outn):
+        rc, sms, e = run([CHK], stdin=prog)
+        assert rc == 0
+        assert sms == run([CHK], stdin=src)[1]
