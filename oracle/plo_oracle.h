@@ -106,6 +106,15 @@ int plo_oracle_tril_program(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_
                             uint64_t seed, int variant, uint32_t *ops6, char **text);
 int plo_oracle_tril_search(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T),
                            uint64_t seed0, uint64_t nseeds, uint32_t *best_ops3, uint64_t *best_seed, uint32_t *best_variant);
+/* The same with `expanded` (trilplacer -e, src/trilplacer.cpp:114-137): the c program is TransposedDoubleAlgorithm
+ * (plinopt_inplace.inl:507-598) on DoubleExpand(T) (:676-716, built inside: 2m rows, nT+1 columns), every AXPY adds the
+ * double-size product to two entries of c (MULTD, plinopt_inplace.h:111) and the AXPY count is halved (:799). */
+int plo_oracle_tril_cost_many_x(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T), int expanded,
+                                const uint64_t *seeds, uint64_t seed0, uint64_t nseeds, uint32_t *ops6);
+int plo_oracle_tril_program_x(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T), int expanded,
+                              uint64_t seed, int variant, uint32_t *ops6, char **text);
+int plo_oracle_tril_search_x(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T), int expanded,
+                             uint64_t seed0, uint64_t nseeds, uint32_t *best_ops3, uint64_t *best_seed, uint32_t *best_variant);
 
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);

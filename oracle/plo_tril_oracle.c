@@ -8,6 +8,7 @@
  *   simplify                          :243-311
  *   pushvariables                     :322-393
  *   LinearAlgorithm                   :400-502
+ *   TransposedDoubleAlgorithm         :507-598   (`trilplacer -e`; DoubleExpand :676-716 done on the fly)
  *   TriLinearProgram                  :732-806   (text: Atom operator<< :43-78, macros plinopt_inplace.h:90-112)
  *   SearchTriLinearAlgorithm          :812-929   (one restart = one candidate seed here)
  * over the rationals (int64 numerator/denominator, overflow-checked).
@@ -223,6 +224,63 @@ static void linear_algorithm(prog *P, const mat *M, const uint32_t *perm, const 
     complexity(P, ops);
 }
 
+/* TransposedDoubleAlgorithm :507-598 on TT = DoubleExpand(T) (:676-716: row 2l of TT is row l of T, row 2l+1 the same
+ * entries one column to the right; TT has n+1 columns).  Rows through perm/sign as in SearchTriLinearAlgorithm :846-883:
+ * row ll of the permuted TT = sign[ll>>1] * TT[2*perm[ll>>1] + (ll&1)]. */
+static int notabsone(rat a) { return !risone(a) && !rismone(a); }
+static void transposed_double_algorithm(prog *P, const mat *T, const uint32_t *perm, const int8_t *sgn, char variable, uint32_t ops[3]) {
+    ent *L = (ent *)malloc((T->n + 1) * sizeof(ent));
+    const rat zero = {0, 1};
+    /* One trip per PAIR of rows (2l, 2l+1) of TT: the trip works on the block <<a|c>,<0|a>> of :519-531, whose lower row is
+     * the upper one moved one column to the right, and emits the two barriers that one MULTD consumes.  The reference's
+     * loop header (:515) reads `++l`: taken literally every odd row would be worked on a second time as an upper row, the
+     * program would hold 4m barriers for m AXPYs and the synchronisation loop of TriLinearProgram (:756-783) could not end
+     * (it cannot pass a barrier of c once the barriers of a are used up).  Stepping by two is what the block structure,
+     * MULTD and the Maple check (:1047-1061) describe; the tests hold the programs to that check. */
+    for (uint32_t ll = 0; ll < 2u * T->m; ll += 2) {
+        const uint32_t l = ll >> 1, sh = 0, r = perm ? perm[l] : l;
+        size_t len = 0;
+        for (uint32_t e = T->rp[r]; e < T->rp[r + 1]; ++e) {
+            rat v = rmake(T->num[e], T->den ? T->den[e] : 1);
+            if (sgn && sgn[l] < 0) v = rneg(v);
+            L[len].col = T->col[e] + sh; L[len].v = v; ++len;
+        }
+        if (len > 0) {
+            const uint32_t i = L[0].col, cindex = i + 1;                      /* matrix <<a|c>,<0|a>> */
+            const rat a = L[0].v, y = rinv(a);
+            rat c = zero, z = zero;
+            if (len > 1 && L[1].col == cindex) { c = L[1].v; z = rneg(rmul(rmul(y, c), y)); }   /* z = - a^-1 c a^-1 */
+            if (notabsone(y)) ppush(P, variable, cindex, '*', y, -1);
+            if (!riszero(z)) ppush(P, variable, cindex, moneop('+', y), z, (long)i);
+            if (notabsone(y)) ppush(P, variable, i, '*', y, -1);
+            for (size_t k = 1; k < len; ++k) {
+                if (L[k].col != cindex) ppush(P, variable, L[k].col, moneop('-', y), L[k].v, (long)i);
+                ppush(P, variable, L[k].col + 1, moneop('-', y), L[k].v, (long)cindex);
+            }
+            ppush(P, variable, i, ' ', a, -1);
+            ppush(P, variable, cindex, ' ', a, -1);
+            for (size_t k = 1; k < len; ++k) {
+                if (L[k].col != cindex) ppush(P, variable, L[k].col, moneop('+', a), L[k].v, (long)i);
+                ppush(P, variable, L[k].col + 1, moneop('+', a), L[k].v, (long)cindex);
+            }
+            if (notabsone(a)) ppush(P, variable, cindex, '*', a, -1);
+            if (!riszero(c)) ppush(P, variable, cindex, moneop('+', a), c, (long)i);
+            if (notabsone(a)) ppush(P, variable, i, '*', a, -1);
+        } else {
+            ppush(P, ' ', ll, ' ', zero, -1);
+        }
+    }
+    free(L);
+    {   /* remove_if(isMulDivOne) :586-587 */
+        size_t w = 0;
+        for (size_t k = 0; k < P->n; ++k) if (!(is_muldiv(P->a[k].ope) && risone(P->a[k].val))) P->a[w++] = P->a[k];
+        P->n = w;
+    }
+    int simp;
+    do { pushvariables(P, (size_t)T->n + 1); simp = simplify(P, 1); } while (simp);
+    complexity(P, ops);
+}
+
 /* ------------------------------------------------------------------- text */
 typedef struct { char *s; size_t n, cap; } sbuf;
 static void sput(sbuf *b, const char *fmt, ...) {
@@ -255,14 +313,15 @@ static void put_atom(sbuf *b, const atom *p) {
     sput(b, ";\n");
 }
 
-/* :732-806 (not expanded) */
+/* :732-806; expanded (`-e`): the c program is TransposedDoubleAlgorithm on DoubleExpand(T), an AXPY takes two barriers of c (MULTD) */
 static void trilinear_program(sbuf *out, const mat *A, const mat *B, const mat *T, const uint32_t *perm, const int8_t *sa,
-                              const int8_t *sb, const int8_t *st, int oriented, uint32_t *rng, uint32_t nops[3]) {
+                              const int8_t *sb, const int8_t *st, int oriented, int expanded, uint32_t *rng, uint32_t nops[3]) {
     prog pa = {0, 0, 0}, pb = {0, 0, 0}, pc = {0, 0, 0};
     uint32_t oa[3], ob[3], oc[3];
     linear_algorithm(&pa, A, perm, sa, 'a', 0, oriented, rng, oa);
     linear_algorithm(&pb, B, perm, sb, 'b', 0, oriented, rng, ob);
-    linear_algorithm(&pc, T, perm, st, 'c', 1, oriented, rng, oc);
+    if (expanded) transposed_double_algorithm(&pc, T, perm, st, 'c', oc);
+    else linear_algorithm(&pc, T, perm, st, 'c', 1, oriented, rng, oc);
     if (out) {
         sput(out, "# Found %u|%u|%u for a\n# Found %u|%u|%u for b\n# Found %u|%u|%u for c\n", oa[0], oa[1], oa[2], ob[0], ob[1], ob[2], oc[0], oc[1], oc[2]);
         size_t ia = 0, ib = 0, ic = 0;
@@ -270,8 +329,16 @@ static void trilinear_program(sbuf *out, const mat *A, const mat *B, const mat *
             for (; ia < pa.n && pa.a[ia].ope != ' '; ++ia) put_atom(out, &pa.a[ia]);
             for (; ib < pb.n && pb.a[ib].ope != ' '; ++ib) put_atom(out, &pb.a[ib]);
             for (; ic < pc.n && pc.a[ic].ope != ' '; ++ic) put_atom(out, &pc.a[ic]);
-            if (ia < pa.n && ib < pb.n && ic < pc.n) {       /* MUL macro, plinopt_inplace.h:108 */
+            if (ia < pa.n && ib < pb.n && ic < pc.n) {       /* MUL / MULTD macros, plinopt_inplace.h:108-111 */
                 const atom *c = &pc.a[ic];
+                if (expanded) {
+                    const atom *c2 = ic + 1 < pc.n ? &pc.a[ic + 1] : c;
+                    sput(out, "%c%u:=%c%u %c (%c%u * %c%u)*low; ### AXPY low  ###\n", c->var, c->src, c->var, c->src, moneop('+', c->val),
+                         pa.a[ia].var, pa.a[ia].src, pb.a[ib].var, pb.a[ib].src);
+                    sput(out, "%c%u:=%c%u %c (%c%u * %c%u)*hig; ### AXPY high ###\n", c2->var, c2->src, c2->var, c2->src, moneop('+', c->val),
+                         pa.a[ia].var, pa.a[ia].src, pb.a[ib].var, pb.a[ib].src);
+                    ++ic;
+                } else
                 sput(out, "%c%u:=%c%u %c %c%u * %c%u; ### AXPY ###\n", c->var, c->src, c->var, c->src, moneop('+', c->val),
                      pa.a[ia].var, pa.a[ia].src, pb.a[ib].var, pb.a[ib].src);
                 ++ia; ++ib; ++ic;
@@ -281,13 +348,14 @@ static void trilinear_program(sbuf *out, const mat *A, const mat *B, const mat *
         for (; ib < pb.n; ++ib) put_atom(out, &pb.a[ib]);
         for (; ia < pa.n; ++ia) put_atom(out, &pa.a[ia]);
     }
+    if (expanded) oc[2] >>= 1;                                   /* :799: MUL2D is counted twice */
     nops[0] = oa[0] + ob[0] + oc[0]; nops[1] = oa[1] + ob[1] + oc[1]; nops[2] = (oa[2] + ob[2] + oc[2]) / 3u;
     free(pa.a); free(pb.a); free(pc.a);
 }
 
 /* one restart of :837-924: permutation, coherent negations, oriented then unoriented program.
  * seed == PLO_TRIL_BASE (all ones): the unpermuted oriented program of :829 only (variant 1 = copy of variant 0). */
-static int tril_candidate(const mat *A, const mat *B, const mat *T, uint64_t seed, uint32_t ops[6], int want_variant, char **text) {
+static int tril_candidate(const mat *A, const mat *B, const mat *T, int expanded, uint64_t seed, uint32_t ops[6], int want_variant, char **text) {
     const uint32_t m = A->m;
     uint32_t rng = plo_oracle_rng_state0(seed);
     uint32_t *perm = (uint32_t *)malloc(m * sizeof(uint32_t));
@@ -305,9 +373,9 @@ static int tril_candidate(const mat *A, const mat *B, const mat *T, uint64_t see
     }
     g_overflow = 0;
     sbuf b0 = {0, 0, 0}, b1 = {0, 0, 0};
-    trilinear_program(text && (want_variant == 0 || base) ? &b0 : NULL, A, B, T, perm, sa, sb, st, 1, &rng, ops);
+    trilinear_program(text && (want_variant == 0 || base) ? &b0 : NULL, A, B, T, perm, sa, sb, st, 1, expanded, &rng, ops);
     if (base) { ops[3] = ops[0]; ops[4] = ops[1]; ops[5] = ops[2]; }
-    else trilinear_program(text && want_variant == 1 ? &b1 : NULL, A, B, T, perm, sa, sb, st, 0, &rng, ops + 3);
+    else trilinear_program(text && want_variant == 1 ? &b1 : NULL, A, B, T, perm, sa, sb, st, 0, expanded, &rng, ops + 3);
     if (text) { *text = want_variant == 0 || base ? b0.s : b1.s; if (!*text) { *text = (char *)malloc(1); (*text)[0] = 0; } }
     free(perm); free(sa); free(sb); free(st);
     return g_overflow ? -3 : 0;
@@ -316,39 +384,33 @@ static int tril_candidate(const mat *A, const mat *B, const mat *T, uint64_t see
 static int check_mats(const mat *A, const mat *B, const mat *T) { return (A->m == B->m && A->m == T->m && A->m > 0) ? 0 : -1; }
 
 #define MAT(x_) { m, n##x_, rp##x_, col##x_, num##x_, den##x_ }
-int plo_oracle_tril_cost_many(uint32_t m,
-                              uint32_t nA, const uint32_t *rpA, const uint32_t *colA, const int64_t *numA, const int64_t *denA,
-                              uint32_t nB, const uint32_t *rpB, const uint32_t *colB, const int64_t *numB, const int64_t *denB,
-                              uint32_t nT, const uint32_t *rpT, const uint32_t *colT, const int64_t *numT, const int64_t *denT,
-                              const uint64_t *seeds, uint64_t seed0, uint64_t nseeds, uint32_t *ops6, int nthreads) {
+#define TRIL_PARAMS uint32_t m, \
+    uint32_t nA, const uint32_t *rpA, const uint32_t *colA, const int64_t *numA, const int64_t *denA, \
+    uint32_t nB, const uint32_t *rpB, const uint32_t *colB, const int64_t *numB, const int64_t *denB, \
+    uint32_t nT, const uint32_t *rpT, const uint32_t *colT, const int64_t *numT, const int64_t *denT
+#define TRIL_PASS m, nA, rpA, colA, numA, denA, nB, rpB, colB, numB, denB, nT, rpT, colT, numT, denT
+
+/* expanded != 0: `trilplacer -e` (T is the m-row matrix; its double expansion is built inside) */
+int plo_oracle_tril_cost_many_x(TRIL_PARAMS, int expanded, const uint64_t *seeds, uint64_t seed0, uint64_t nseeds, uint32_t *ops6) {
     const mat A = MAT(A), B = MAT(B), T = MAT(T);
     if (check_mats(&A, &B, &T)) return -1;
-    int rc = 0;
-    (void)nthreads;                         /* g_overflow is a plain global: keep the checker serial */
-    for (uint64_t k = 0; k < nseeds; ++k) { int r = tril_candidate(&A, &B, &T, seeds ? seeds[k] : seed0 + k, ops6 + 6 * k, 0, NULL); if (r) rc = r; }
+    int rc = 0;                             /* g_overflow is a plain global: the checker is serial */
+    for (uint64_t k = 0; k < nseeds; ++k) { int r = tril_candidate(&A, &B, &T, expanded, seeds ? seeds[k] : seed0 + k, ops6 + 6 * k, 0, NULL); if (r) rc = r; }
     return rc;
 }
-int plo_oracle_tril_program(uint32_t m,
-                            uint32_t nA, const uint32_t *rpA, const uint32_t *colA, const int64_t *numA, const int64_t *denA,
-                            uint32_t nB, const uint32_t *rpB, const uint32_t *colB, const int64_t *numB, const int64_t *denB,
-                            uint32_t nT, const uint32_t *rpT, const uint32_t *colT, const int64_t *numT, const int64_t *denT,
-                            uint64_t seed, int variant, uint32_t *ops6, char **text) {
+int plo_oracle_tril_program_x(TRIL_PARAMS, int expanded, uint64_t seed, int variant, uint32_t *ops6, char **text) {
     const mat A = MAT(A), B = MAT(B), T = MAT(T);
     if (check_mats(&A, &B, &T)) return -1;
-    return tril_candidate(&A, &B, &T, seed, ops6, variant, text);
+    return tril_candidate(&A, &B, &T, expanded, seed, ops6, variant, text);
 }
 /* best over [seed0, seed0+nseeds) x {oriented, unoriented} under (ADD, SCA, seed, variant); :893-923 */
-int plo_oracle_tril_search(uint32_t m,
-                           uint32_t nA, const uint32_t *rpA, const uint32_t *colA, const int64_t *numA, const int64_t *denA,
-                           uint32_t nB, const uint32_t *rpB, const uint32_t *colB, const int64_t *numB, const int64_t *denB,
-                           uint32_t nT, const uint32_t *rpT, const uint32_t *colT, const int64_t *numT, const int64_t *denT,
-                           uint64_t seed0, uint64_t nseeds, uint32_t *best_ops3, uint64_t *best_seed, uint32_t *best_variant) {
+int plo_oracle_tril_search_x(TRIL_PARAMS, int expanded, uint64_t seed0, uint64_t nseeds, uint32_t *best_ops3, uint64_t *best_seed, uint32_t *best_variant) {
     const mat A = MAT(A), B = MAT(B), T = MAT(T);
     if (check_mats(&A, &B, &T)) return -1;
     int have = 0;
     for (uint64_t k = 0; k < nseeds; ++k) {
         uint32_t o[6];
-        int r = tril_candidate(&A, &B, &T, seed0 + k, o, 0, NULL);
+        int r = tril_candidate(&A, &B, &T, expanded, seed0 + k, o, 0, NULL);
         if (r) return r;
         for (uint32_t v = 0; v < 2; ++v) {
             const uint32_t *q = o + 3 * v;
@@ -358,4 +420,12 @@ int plo_oracle_tril_search(uint32_t m,
         }
     }
     return have ? 0 : -1;
+}
+int plo_oracle_tril_cost_many(TRIL_PARAMS, const uint64_t *seeds, uint64_t seed0, uint64_t nseeds, uint32_t *ops6, int nthreads) {
+    (void)nthreads;
+    return plo_oracle_tril_cost_many_x(TRIL_PASS, 0, seeds, seed0, nseeds, ops6);
+}
+int plo_oracle_tril_program(TRIL_PARAMS, uint64_t seed, int variant, uint32_t *ops6, char **text) { return plo_oracle_tril_program_x(TRIL_PASS, 0, seed, variant, ops6, text); }
+int plo_oracle_tril_search(TRIL_PARAMS, uint64_t seed0, uint64_t nseeds, uint32_t *best_ops3, uint64_t *best_seed, uint32_t *best_variant) {
+    return plo_oracle_tril_search_x(TRIL_PASS, 0, seed0, nseeds, best_ops3, best_seed, best_variant);
 }

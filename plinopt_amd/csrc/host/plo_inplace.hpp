@@ -7,7 +7,8 @@
 //
 // Follows reference include/plinopt_inplace.inl: Atom/cumulate :15-124, complexity
 // :133-144, orientindex/nextindex :179-236, simplify :243-311, pushvariables
-// :322-393, LinearAlgorithm :400-502, TriLinearProgram :732-806,
+// :322-393, LinearAlgorithm :400-502, TransposedDoubleAlgorithm :507-598 (-e),
+// DoubleExpand :676-716, TriLinearProgram :732-806,
 // SearchTriLinearAlgorithm :812-929; output syntax plinopt_inplace.h:101-112.
 // Random choices: the per-candidate stream of include/plinopt_hip.h.
 // ==========================================================================
@@ -147,6 +148,47 @@ inline Tricount in_linear(InplaceProgram &P, const InRows &R, char variable, boo
     return P.complexity();
 }
 
+// TransposedDoubleAlgorithm :507-598 on TT = DoubleExpand(T) (:676-716: row 2l of TT is row l of T, row 2l+1 the same entries
+// one column to the right; TT has one more column), built on the fly.  One trip per pair of rows (2l, 2l+1) = one block
+// <<a|c>,<0|a>> and the two barriers of one MULTD (the reference's loop header reads `++l`, which would work on every odd
+// row again as an upper row and leave barriers that the synchronisation loop of TriLinearProgram cannot pass: see
+// oracle/plo_tril_oracle.c).
+inline Tricount in_transposed_double(InplaceProgram &P, const InRows &R, char variable) {
+    QField Q;
+    const QMat &M = *R.M;
+    auto mone = [&](char op, const Rat &v) { return Q.isMOne(v) ? in_swap(op) : op; };
+    auto notabsone = [&](const Rat &v) { return !Q.isOne(v) && !Q.isMOne(v); };
+    for (size_t l = 0; l < M.rowdim(); ++l) {
+        std::vector<std::pair<size_t, Rat>> L = M.rows[(*R.perm)[l]];
+        if ((*R.sgn)[l] < 0) for (auto &e : L) e.second = Q.neg(e.second);
+        if (L.empty()) { P.at.push_back({' ', 2 * l, ' ', Rat(0), -1}); continue; }
+        const size_t i = L[0].first, cindex = i + 1;
+        const Rat a = L[0].second, y = Q.inv(a);
+        Rat c(0), z(0);
+        if (L.size() > 1 && L[1].first == cindex) { c = L[1].second; z = Q.neg(Q.mul(Q.mul(y, c), y)); }
+        if (notabsone(y)) P.at.push_back({variable, cindex, '*', y, -1});
+        if (!Q.isZero(z)) P.at.push_back({variable, cindex, mone('+', y), z, (long)i});
+        if (notabsone(y)) P.at.push_back({variable, i, '*', y, -1});
+        for (size_t k = 1; k < L.size(); ++k) {
+            if (L[k].first != cindex) P.at.push_back({variable, L[k].first, mone('-', y), L[k].second, (long)i});
+            P.at.push_back({variable, L[k].first + 1, mone('-', y), L[k].second, (long)cindex});
+        }
+        P.at.push_back({variable, i, ' ', a, -1});
+        P.at.push_back({variable, cindex, ' ', a, -1});
+        for (size_t k = 1; k < L.size(); ++k) {
+            if (L[k].first != cindex) P.at.push_back({variable, L[k].first, mone('+', a), L[k].second, (long)i});
+            P.at.push_back({variable, L[k].first + 1, mone('+', a), L[k].second, (long)cindex});
+        }
+        if (notabsone(a)) P.at.push_back({variable, cindex, '*', a, -1});
+        if (!Q.isZero(c)) P.at.push_back({variable, cindex, mone('+', a), c, (long)i});
+        if (notabsone(a)) P.at.push_back({variable, i, '*', a, -1});
+    }
+    P.at.erase(std::remove_if(P.at.begin(), P.at.end(), [&](const InAtom &a) { return in_muldiv(a.ope) && Q.isOne(a.val); }), P.at.end());
+    bool simp;
+    do { P.pushvariables(M.coldim() + 1); simp = P.simplify(true); } while (simp);
+    return P.complexity();
+}
+
 inline void in_print_atom(std::ostream &os, const InAtom &p) {
     QField Q; size_t dummy = 0;
     const bool sca = in_muldiv(p.ope);
@@ -165,7 +207,7 @@ struct TrilCandidate {
 };
 
 // one restart (:837-924): both variants; text only for `want` (0, 1, or -1 none)
-inline TrilCandidate tril_candidate(const QMat &A, const QMat &B, const QMat &T, uint64_t seed, int want) {
+inline TrilCandidate tril_candidate(const QMat &A, const QMat &B, const QMat &T, uint64_t seed, int want, bool expanded = false) {
     const size_t m = A.rowdim();
     TrilCandidate C; C.perm.resize(m); C.sa.assign(m, 1); C.sb.assign(m, 1); C.st.assign(m, 1);
     for (size_t i = 0; i < m; ++i) C.perm[i] = (uint32_t)i;
@@ -181,12 +223,14 @@ inline TrilCandidate tril_candidate(const QMat &A, const QMat &B, const QMat &T,
         InplaceProgram pa, pb, pc;
         const Tricount oa = in_linear(pa, InRows{&A, &C.perm, &C.sa}, 'a', false, variant == 0, rng);
         const Tricount ob = in_linear(pb, InRows{&B, &C.perm, &C.sb}, 'b', false, variant == 0, rng);
-        const Tricount oc = in_linear(pc, InRows{&T, &C.perm, &C.st}, 'c', true, variant == 0, rng);
+        Tricount oc = expanded ? in_transposed_double(pc, InRows{&T, &C.perm, &C.st}, 'c') : in_linear(pc, InRows{&T, &C.perm, &C.st}, 'c', true, variant == 0, rng);
+        const Tricount oc_print = oc;
+        if (expanded) oc[2] >>= 1;                                   // :799: MUL2D is counted twice
         C.ops[variant] = {oa[0] + ob[0] + oc[0], oa[1] + ob[1] + oc[1], (oa[2] + ob[2] + oc[2]) / 3};
         if (want == variant || (base && want >= 0)) {
             std::ostringstream os;
             auto tri = [&](const Tricount &t) { os << t[0] << '|' << t[1] << '|' << t[2]; };
-            os << "# Found "; tri(oa); os << " for a\n# Found "; tri(ob); os << " for b\n# Found "; tri(oc); os << " for c\n";
+            os << "# Found "; tri(oa); os << " for a\n# Found "; tri(ob); os << " for b\n# Found "; tri(oc_print); os << " for c\n";
             size_t ia = 0, ib = 0, ic = 0;
             while (ic < pc.at.size()) {
                 for (; ia < pa.at.size() && pa.at[ia].ope != ' '; ++ia) in_print_atom(os, pa.at[ia]);
@@ -194,6 +238,14 @@ inline TrilCandidate tril_candidate(const QMat &A, const QMat &B, const QMat &T,
                 for (; ic < pc.at.size() && pc.at[ic].ope != ' '; ++ic) in_print_atom(os, pc.at[ic]);
                 if (ia < pa.at.size() && ib < pb.at.size() && ic < pc.at.size()) {
                     const InAtom &c = pc.at[ic];
+                    if (expanded) {                                   // MULTD, plinopt_inplace.h:111
+                        const InAtom &c2 = ic + 1 < pc.at.size() ? pc.at[ic + 1] : c;
+                        os << c.var << c.src << ":=" << c.var << c.src << ' ' << (Q.isMOne(c.val) ? '-' : '+') << " (" << pa.at[ia].var << pa.at[ia].src << " * "
+                           << pb.at[ib].var << pb.at[ib].src << ")*low; ### AXPY low  ###\n";
+                        os << c2.var << c2.src << ":=" << c2.var << c2.src << ' ' << (Q.isMOne(c.val) ? '-' : '+') << " (" << pa.at[ia].var << pa.at[ia].src << " * "
+                           << pb.at[ib].var << pb.at[ib].src << ")*hig; ### AXPY high ###\n";
+                        ++ic;
+                    } else
                     os << c.var << c.src << ":=" << c.var << c.src << ' ' << (Q.isMOne(c.val) ? '-' : '+') << ' ' << pa.at[ia].var << pa.at[ia].src << " * "
                        << pb.at[ib].var << pb.at[ib].src << "; ### AXPY ###\n";
                     ++ia; ++ib; ++ic;

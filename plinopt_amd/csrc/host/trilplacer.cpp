@@ -1,12 +1,12 @@
 // ==========================================================================
 // bin/trilplacer -- in-place trilinear programs (reference src/trilplacer.cpp:60-190):
-//   trilplacer L.sms R.sms P.sms [-O #] [--seed s] [--gpu 0|1]
+//   trilplacer L.sms R.sms P.sms [-e] [-m] [-O #] [--seed s] [--gpu 0|1|N]
 // stdout = the program (a_i, b_j restored, c_k += the bilinear map), clog = '#' statistics
 // ("ADD / SCA / AXPY" as the reference :170-180).  The restart loop of
 // SearchTriLinearAlgorithm (include/plinopt_inplace.inl:837-924) runs on the GPU through
 // plo_tril_search of libplinopt_hip.so when the three matrices are +-1 matrices without
 // empty rows; the winner is replayed on the host to print it.  Other inputs, or --gpu 0,
-// use the host loop (OpenMP).  -e (double expansion) is not built.
+// use the host loop (OpenMP).  -e: the expanded variant (TransposedDoubleAlgorithm on DoubleExpand(P^T)).
 // ==========================================================================
 #include "plo_inplace.hpp"
 #include "../../../include/plinopt_hip.h"
@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
 #ifdef _OPENMP
     if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
 #endif
-    size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; std::vector<std::string> files;
+    size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; bool expanded = false; std::vector<std::string> files;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
         if (a == "-h") { std::clog << "Usage: " << argv[0] << " L.sms R.sms P.sms [-O #] [--seed s] [--gpu 0|1|N: N >= 2 shards the restarts over N GPUs]\n"; return 0; }
@@ -66,7 +66,7 @@ int main(int argc, char **argv) {
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
         else if (a == "-m") { }        // reference: selects the Maple check of an INPLACE_CHECKER build (src/trilplacer.cpp:79,155); nothing to do here
-        else if (a == "-e") { std::cerr << "# \033[1;31mERROR: -e (double expansion) is not built\033[0m\n"; return 2; }
+        else if (a == "-e") expanded = true;           // src/trilplacer.cpp:80,114-137: double-size products, two entries of c per AXPY
         else files.push_back(a);
     }
     if (files.size() != 3) { std::cerr << "# \033[1;31mERROR: three matrices needed (L R P)\033[0m\n"; return -1; }
@@ -76,13 +76,13 @@ int main(int argc, char **argv) {
         const QMat &A = M[0], &B = M[1]; QMat T = transpose(M[2]);
         if (A.rowdim() != B.rowdim() || A.rowdim() != T.rowdim()) { std::cerr << "Incorrect dimensions\n"; return 1; }
         const auto t0 = std::chrono::steady_clock::now();
-        TrilCandidate basec = tril_candidate(A, B, T, ~0ull, 0);
+        TrilCandidate basec = tril_candidate(A, B, T, ~0ull, 0, expanded);
         Tricount best = basec.ops[0]; uint64_t bseed = ~0ull; int bvar = 0;
         std::clog << "# Oriented number of operations: " << best[0] << '|' << best[1] << '|' << best[2] << std::endl;
         bool on_gpu = false; double kms = 0;
         if (loops > 0) {
             ICsr ca = icsr(A), cb = icsr(B), ct = icsr(T);
-            const bool device_ok = ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full;
+            const bool device_ok = ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full && !expanded;   // (-e: host loop until the kernel variant is in)
             using Key = std::tuple<size_t, size_t, uint64_t, int>;      // (ADD, SCA, seed, variant): the order of :893-897 made total
             // restarts s0 .. s0+cnt-1 on one device (plo_tril_search); throws on failure
             auto gpu_search = [&](int device, uint64_t s0, uint64_t cnt, plo_tril_best_t &r, plo_stats_t &st) {
@@ -107,7 +107,7 @@ int main(int argc, char **argv) {
                     Key tb = lb;
                     #pragma omp for schedule(dynamic, 16)
                     for (long long k = 0; k < (long long)cnt; ++k) {
-                        TrilCandidate c = tril_candidate(A, B, T, s0 + (uint64_t)k, -1);
+                        TrilCandidate c = tril_candidate(A, B, T, s0 + (uint64_t)k, -1, expanded);
                         for (int v = 0; v < 2; ++v) tb = std::min(tb, Key{c.ops[v][0], c.ops[v][1], s0 + (uint64_t)k, v});
                     }
                     #pragma omp critical
@@ -162,7 +162,7 @@ int main(int argc, char **argv) {
         std::string text;
         if (bseed == ~0ull) text = basec.text[0];
         else {
-            TrilCandidate w = tril_candidate(A, B, T, bseed, bvar);
+            TrilCandidate w = tril_candidate(A, B, T, bseed, bvar, expanded);
             if (w.ops[bvar] != best) { std::cerr << "# \033[1;31mERROR: replay of seed " << bseed << " gives " << w.ops[bvar][0] << '|' << w.ops[bvar][1] << ", search said " << best[0] << '|' << best[1] << "\033[0m\n"; return 3; }
             text = w.text[bvar];
             std::clog << "# Found " << (bvar ? "unoriented" : "oriented") << " [seed " << bseed << "], operations: " << best[0] << '|' << best[1] << '|' << best[2] << std::endl;
@@ -170,7 +170,7 @@ int main(int argc, char **argv) {
         std::cout << text << std::flush;
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::clog << std::string(40, '#') << std::endl;
-        std::clog << "# \033[1;32m" << best[0] << "\tADD\033[0m\n# \033[1;32m" << best[1] << "\tSCA\033[0m\n# \033[1;32m" << best[2] << "\tAXPY\033[0m\n";
+        std::clog << "# \033[1;32m" << best[0] << "\tADD\033[0m\n# \033[1;32m" << best[1] << "\tSCA\033[0m\n# \033[1;32m" << best[2] << (expanded ? "\tAXPY (double size)\033[0m\n" : "\tAXPY\033[0m\n");
         std::clog << std::string(40, '#') << std::endl;
         std::clog << "# " << loops << " restarts on " << (on_gpu ? "GPU" : "host") << " in " << dt << " s";
         if (on_gpu) std::clog << " (kernel " << kms << " ms)";

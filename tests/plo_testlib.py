@@ -447,34 +447,68 @@ class OracleTril:
             out += [ctypes.c_uint32(n), a[0], a[1], a[2], a[3]]
         return out
 
-    def cost_many(self, seeds=None, seed0=0, nseeds=0):
-        """-> list of ((ADD,SCA,MUL) oriented, (ADD,SCA,MUL) unoriented)"""
+    def cost_many(self, seeds=None, seed0=0, nseeds=0, expanded=False):
+        """-> list of ((ADD,SCA,MUL) oriented, (ADD,SCA,MUL) unoriented); expanded: `trilplacer -e`"""
         if seeds is not None:
             nseeds = len(seeds); sp = _arr(seeds, ctypes.c_uint64)
         else:
             sp = None
         ops = (ctypes.c_uint32 * (6 * max(nseeds, 1)))()
-        rc = oracle().plo_oracle_tril_cost_many(*self._args(), sp, seed0, nseeds, ops, 1)
+        rc = oracle().plo_oracle_tril_cost_many_x(*self._args(), ctypes.c_int(int(expanded)), sp, ctypes.c_uint64(seed0), ctypes.c_uint64(nseeds), ops)
         assert rc == 0, rc
         return [(tuple(ops[6 * k:6 * k + 3]), tuple(ops[6 * k + 3:6 * k + 6])) for k in range(nseeds)]
 
-    def program(self, seed, variant):
+    def program(self, seed, variant, expanded=False):
         ops = (ctypes.c_uint32 * 6)()
         txt = ctypes.c_void_p()
-        rc = oracle().plo_oracle_tril_program(*self._args(), seed, variant, ops, ctypes.byref(txt))
+        rc = oracle().plo_oracle_tril_program_x(*self._args(), ctypes.c_int(int(expanded)), ctypes.c_uint64(seed), ctypes.c_int(variant), ops, ctypes.byref(txt))
         assert rc == 0, rc
         text = ctypes.string_at(txt).decode()
         oracle().plo_oracle_free(txt)
         return tuple(ops[3 * variant:3 * variant + 3]), text
 
-    def search(self, seed0, nseeds):
+    def search(self, seed0, nseeds, expanded=False):
         best = (ctypes.c_uint32 * 3)(); bs = ctypes.c_uint64(); bv = ctypes.c_uint32()
-        rc = oracle().plo_oracle_tril_search(*self._args(), seed0, nseeds, best, ctypes.byref(bs), ctypes.byref(bv))
+        rc = oracle().plo_oracle_tril_search_x(*self._args(), ctypes.c_int(int(expanded)), ctypes.c_uint64(seed0), ctypes.c_uint64(nseeds), best, ctypes.byref(bs), ctypes.byref(bv))
         assert rc == 0, rc
         return tuple(best), bs.value, bv.value
 
 
 _INPL_LINE = re.compile(r"^([a-z])(\d+):=(.*?);")
+
+
+class LowHigh:
+    """A value p + l*low + h*hig with symbolic low/hig: what an entry of c holds in a `trilplacer -e` program (the
+    double-size products are split into a low and a high half, reference plinopt_inplace.h:111, checker :1047)."""
+
+    def __init__(self, p, l=0, h=0):
+        self.v = (Fraction(p), Fraction(l), Fraction(h))
+
+    def _w(self, o):
+        return o.v if isinstance(o, LowHigh) else (Fraction(o), Fraction(0), Fraction(0))
+
+    def __add__(self, o):
+        return LowHigh(*(x + y for x, y in zip(self.v, self._w(o))))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return LowHigh(*(x - y for x, y in zip(self.v, self._w(o))))
+
+    def __neg__(self):
+        return LowHigh(*(-x for x in self.v))
+
+    def __mul__(self, f):
+        return LowHigh(*(x * f for x in self.v))
+
+    def __truediv__(self, f):
+        return LowHigh(*(x / f for x in self.v))
+
+    def __eq__(self, o):
+        return self.v == self._w(o)
+
+    def __repr__(self):
+        return "LowHigh%r" % (self.v,)
 
 
 def run_inplace_program(text, a, b, c):
@@ -502,6 +536,16 @@ def run_inplace_program(text, a, b, c):
         mm = _INPL_LINE.match(line)
         assert mm, line
         var, idx, rhs = mm.group(1), int(mm.group(2)), mm.group(3).strip()
+        if " * " in rhs and (rhs.endswith(")*low") or rhs.endswith(")*hig")):      # -e: c:=c +/- (a * b)*low|hig; two lines = one AXPY
+            mq = re.match(r"^([a-z])(\d+) ([+-]) \(([a-z])(\d+) \* ([a-z])(\d+)\)\*(low|hig)$", rhs)
+            assert mq and mq.group(1) == var and int(mq.group(2)) == idx, line
+            prod = env[mq.group(4)][int(mq.group(5))] * env[mq.group(6)][int(mq.group(7))]
+            if mq.group(3) == "-":
+                prod = -prod
+            env[var][idx] = env[var][idx] + (LowHigh(0, prod, 0) if mq.group(8) == "low" else LowHigh(0, 0, prod))
+            if mq.group(8) == "low":
+                nmul += 1
+            continue
         if " * " in rhs:                                    # AXPY: c:=c +/- a * b
             mq = re.match(r"^([a-z])(\d+) ([+-]) ([a-z])(\d+) \* ([a-z])(\d+)$", rhs)
             assert mq and mq.group(1) == var and int(mq.group(2)) == idx, line

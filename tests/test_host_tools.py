@@ -221,6 +221,29 @@ def test_trilplacer_host_search_equals_oracle_and_program_runs_in_place(name):
     check_program(T, r.stdout, want, random.Random(11))
 
 
+@pytest.mark.parametrize("name", TRIL_CASES)
+def test_trilplacer_expanded_host_search_equals_oracle(name):
+    """bin/trilplacer -e --gpu 0 (README: `trilplacer data/1o1o2_3_Karatsuba_{L,R,P}.sms -e`): the host loop picks the
+    oracle's argmin of the expanded programs, prints the oracle's text for that (seed, variant), and the program passes
+    the double-size in-place check."""
+    import random
+    from plo_testlib import TRIL_BASE_SEED, OracleTril
+    from test_tril_oracle import check_expanded_program
+    files = [os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")]
+    T = OracleTril.from_sms(*files)
+    n = 40
+    r = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-e", "--gpu", "0", "-O", str(n), "--seed", "7"] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ops, seed, var = T.search(7, n, expanded=True)
+    (base, _), = T.cost_many(seeds=[TRIL_BASE_SEED], expanded=True)
+    better = (ops[0], ops[1]) < (base[0], base[1])
+    want = ops if better else base
+    got = tuple(int(x) for x in re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", r.stderr))
+    assert got == want and "AXPY (double size)" in r.stderr, (got, want, r.stderr)
+    assert r.stdout == T.program(seed if better else TRIL_BASE_SEED, var if better else 0, expanded=True)[1]
+    check_expanded_program(T, r.stdout, want, random.Random(13))
+
+
 @pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "4x4x4_49_156_L.sms", "4x4x4_49_156_R.sms", "3x3x6_40_L.sms",
                                   "4x4x4_48_rational_L.sms", "2x2x2_7_DPS-accurate_L.sms", "cyclic.sms"])
 @pytest.mark.parametrize("field", ["Q", "p"])
