@@ -172,6 +172,10 @@ typedef struct { uint32_t m, n; const uint32_t *rowptr; const uint32_t *col; con
 typedef struct { uint32_t add, sca, mul; uint32_t variant; uint64_t seed; } plo_tril_best_t;
 typedef struct plo_tril_plan plo_tril_plan_t;
 int  plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, plo_tril_plan_t **plan);
+/* expanded != 0: `trilplacer -e` (src/trilplacer.cpp:80,114-137): the program of T is TransposedDoubleAlgorithm
+ * (include/plinopt_inplace.inl:507-598) on DoubleExpand(T) (:676-716, built on the device from the m-row T); a candidate
+ * returns (ADD, SCA) of that variant and MUL = m double-size AXPYs (:799). */
+int  plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, int expanded, plo_tril_plan_t **plan);
 void plo_tril_plan_destroy(plo_tril_plan_t *plan);
 /* ops6[6k..6k+5] = ADD,SCA,MUL of variant 0 then of variant 1 for candidate k (seeds[k], or seed0+k when seeds==NULL) */
 int  plo_tril_cost_many(plo_tril_plan_t *plan, const uint64_t *seeds, uint64_t seed0, uint64_t n, uint32_t *ops6, plo_stats_t *stats);

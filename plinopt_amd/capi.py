@@ -23,7 +23,7 @@ EXPORTS = [
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch",
     "plo_cse_enum_cost_many_plan", "plo_cse_enum_search_plan",
     "plo_cob_search", "plo_cob_search_range",
-    "plo_tril_plan_create", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
+    "plo_tril_plan_create", "plo_tril_plan_create_x", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
     "plo_pack_cost",
 ]
 
@@ -118,6 +118,7 @@ def lib():
         L.plo_cse_enum_cost_many_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u64p, ctypes.POINTER(Stats)]
         L.plo_cse_enum_search_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(Best), u64p, ctypes.POINTER(Stats)]
         L.plo_tril_plan_create.argtypes = [ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_tril_plan_create_x.argtypes = [ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.plo_tril_plan_destroy.argtypes = [ctypes.c_void_p]
         L.plo_tril_plan_destroy.restype = None
         L.plo_tril_cost_many.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, ctypes.POINTER(Stats)]

@@ -24,7 +24,7 @@ namespace {
 struct HipTril {
     void *h = nullptr;
     decltype(&plo_init) init = nullptr; decltype(&plo_last_error) last_error = nullptr;
-    decltype(&plo_tril_plan_create) create = nullptr; decltype(&plo_tril_plan_destroy) destroy = nullptr; decltype(&plo_tril_search) search = nullptr;
+    decltype(&plo_tril_plan_create_x) create = nullptr; decltype(&plo_tril_plan_destroy) destroy = nullptr; decltype(&plo_tril_search) search = nullptr;
     bool load() {
         std::vector<std::string> cand;
         if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
@@ -34,7 +34,7 @@ struct HipTril {
         for (auto &c : cand) { h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
         if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
         init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
-        create = (decltype(create))dlsym(h, "plo_tril_plan_create"); destroy = (decltype(destroy))dlsym(h, "plo_tril_plan_destroy");
+        create = (decltype(create))dlsym(h, "plo_tril_plan_create_x"); destroy = (decltype(destroy))dlsym(h, "plo_tril_plan_destroy");
         search = (decltype(search))dlsym(h, "plo_tril_search");
         return init && last_error && create && destroy && search;
     }
@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
         bool on_gpu = false; double kms = 0;
         if (loops > 0) {
             ICsr ca = icsr(A), cb = icsr(B), ct = icsr(T);
-            const bool device_ok = ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full && !expanded;   // (-e: host loop until the kernel variant is in)
+            const bool device_ok = ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full;
             using Key = std::tuple<size_t, size_t, uint64_t, int>;      // (ADD, SCA, seed, variant): the order of :893-897 made total
             // restarts s0 .. s0+cnt-1 on one device (plo_tril_search); throws on failure
             auto gpu_search = [&](int device, uint64_t s0, uint64_t cnt, plo_tril_best_t &r, plo_stats_t &st) {
@@ -93,7 +93,7 @@ int main(int argc, char **argv) {
                 plo_icsr_t b{(uint32_t)B.rowdim(), (uint32_t)B.coldim(), cb.rp.data(), cb.col.data(), cb.val.data()};
                 plo_icsr_t t{(uint32_t)T.rowdim(), (uint32_t)T.coldim(), ct.rp.data(), ct.col.data(), ct.val.data()};
                 plo_tril_plan_t *plan = nullptr;
-                if (L.create(&a, &b, &t, &plan) != PLO_OK) throw std::runtime_error(L.last_error());
+                if (L.create(&a, &b, &t, expanded ? 1 : 0, &plan) != PLO_OK) throw std::runtime_error(L.last_error());
                 const int rc = L.search(plan, s0, cnt, &r, &st);
                 const std::string msg = rc != PLO_OK ? L.last_error() : "";
                 L.destroy(plan);

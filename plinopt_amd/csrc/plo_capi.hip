@@ -1123,7 +1123,9 @@ int tril_launch(plo_tril_plan *pl, plo::TrilJob J, plo_stats_t *st) {
 
 extern "C" {
 
-int plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, plo_tril_plan_t **plan)
+int plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, plo_tril_plan_t **plan) { return plo_tril_plan_create_x(A, B, T, 0, plan); }
+
+int plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, int expanded, plo_tril_plan_t **plan)
 {
     if (g_device < 0) return fail(PLO_E_HIP, "plo_init was not called (or found no HIP device)");
     if (!A || !B || !T || !plan) return fail(PLO_E_ARG, "null argument");
@@ -1145,6 +1147,8 @@ int plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_ics
             }
         }
         cap = std::max(cap, 2u * nnz + 3u * M->m);
+        if (expanded && M == T) cap = std::max(cap, 4u * nnz + 2u * M->m);        // TransposedDoubleAlgorithm: 4(len-1)+2 atoms per row
+        if (expanded && M == T && M->n >= 65535u) return fail(PLO_E_CAPACITY, "one more variable of c than 16 bits hold");
         bytes += round_up((M->m + 1) * 2, 16) + round_up(nnz * 2, 16) + round_up(nnz, 16);
         algo += 2ull * (M->m + 1) + 3ull * nnz;                 // the CSR image of the three matrices, once per candidate
     }
@@ -1163,7 +1167,7 @@ int plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_ics
         for (uint32_t i = 0; i <= M->m; ++i) rp[i] = (uint16_t)M->rowptr[i];
         for (uint32_t e = 0; e < nnz; ++e) { cl[e] = (uint16_t)M->col[e]; vl[e] = (int8_t)M->val[e]; }
     }
-    pl->P.cap = cap;
+    pl->P.cap = cap; pl->P.expanded = expanded ? 1u : 0u;
     pl->P.lds_per_wave = round_up(8u * cap + 2u * ((A->m + 1u) & ~1u) + A->m, 16);
     pl->algo_bytes = algo;
     pl->waves_per_wg = 4;

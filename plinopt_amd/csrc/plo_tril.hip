@@ -6,7 +6,8 @@
 // and coherent row negations of (A, B, T), then the oriented and the unoriented
 // in-place program (LinearAlgorithm :400-502 on A, B and, transposed, on T) and
 // their (ADD, SCA) counts (complexity :133-144).  Counts only: the host replays the
-// winning seed to print the program.
+// winning seed to print the program.  `trilplacer -e`: the program of T is
+// TransposedDoubleAlgorithm (:507-598) on the double expansion of T (t_double).
 //
 // One wavefront per candidate.  The atom list of the program being built lives in
 // LDS, one 8-byte word per atom (src, des, val, ope); the control flow is wave
@@ -28,7 +29,7 @@
 namespace plo {
 
 struct TrilMat { uint32_t m, n, nnz; const uint16_t *rp; const uint16_t *col; const int8_t *val; };
-struct TrilPlan { TrilMat M[3]; uint32_t cap; uint32_t lds_per_wave; };
+struct TrilPlan { TrilMat M[3]; uint32_t cap; uint32_t lds_per_wave; uint32_t expanded; };   // expanded: `trilplacer -e`
 struct TrilJob {
     uint64_t seed0; const uint64_t *seeds; uint64_t ncand;
     uint32_t *ops;               // 6 per candidate: ADD,SCA,MUL oriented then unoriented (may be null)
@@ -272,6 +273,63 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
     ops[0] = a; ops[1] = s; ops[2] = mu;
 }
 
+// `trilplacer -e`: TransposedDoubleAlgorithm (:507-598) on DoubleExpand(T) (:676-716) for +-1 matrices.  Row l of T stands
+// for the pair of rows (2l, 2l+1) of the expanded matrix -- the block <<a|c>,<0|a>> on the variables i = first column and
+// i+1 -- and gives 2(len-1) atoms, the two barriers of one double-size AXPY, and 2(len-1) atoms again (one trip per pair
+// of expanded rows: see oracle/plo_tril_oracle.c).  a = +-1, so y = 1/a = a, z = -c and no scaling atom exists.  No random
+// draw: the first entry is the pivot.
+__device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, uint32_t lane,
+                         uint32_t ops[3], uint32_t cap, uint32_t *errw) {
+    P.n = 0;
+    for (uint32_t l = 0; l < M.m; ++l) {
+        const uint32_t r = perm[l], b = M.rp[r], len = (uint32_t)M.rp[r + 1u] - b;
+        if (len == 0 || len > 64u) { if (lane == 0) atomicMax(errw, (uint32_t)TERR_ROW); return; }
+        if (P.n + 4u * len > cap) { if (lane == 0) atomicMax(errw, (uint32_t)TERR_CAP); return; }
+        const bool neg = (sgn[l] >> sbit) & 1u;
+        int c = -1, v = 0;
+        if (lane < len) { c = M.col[b + lane]; v = M.val[b + lane]; if (neg) v = -v; }
+        const int i = __builtin_amdgcn_readlane(c, 0), a = __builtin_amdgcn_readlane(v, 0), ci = i + 1;
+        const int c1 = __builtin_amdgcn_readlane(c, 1), v1 = __builtin_amdgcn_readlane(v, 1);
+        const bool has_c = len > 1u && c1 == ci;                                                      // :524-529
+        const uint32_t base = P.n, bar = base + 2u * (len - 1u), base2 = bar + 2u;
+        const uint32_t o1 = a == -1 ? T_ADD : T_SUB;           // MONEOP('-', y), y = a
+        const uint32_t o2 = a == -1 ? T_SUB : T_ADD;           // MONEOP('+', a) (and MONEOP('+', y))
+        if (lane >= 1u && lane < len) {
+            if (has_c && lane == 1u) {
+                P.at[base + 1u] = ta_make((uint32_t)(c + 1), ci, v, o1);                               // :541-542 (the entry at i+1 only moves to i+2)
+                P.at[base2] = ta_make((uint32_t)(c + 1), ci, v, o2);                                   // :556-557
+            } else {
+                const uint32_t off = 2u * lane - 2u, off2 = has_c ? 2u * lane - 3u : 2u * lane - 2u;
+                P.at[base + off] = ta_make((uint32_t)c, i, v, o1);                                     // :537-540
+                P.at[base + off + 1u] = ta_make((uint32_t)(c + 1), ci, v, o1);                         // :541-542
+                P.at[base2 + off2] = ta_make((uint32_t)c, i, v, o2);                                   // :552-555
+                P.at[base2 + off2 + 1u] = ta_make((uint32_t)(c + 1), ci, v, o2);                       // :556-557
+            }
+        }
+        if (lane == 0) {
+            if (has_c) {
+                P.at[base] = ta_make((uint32_t)ci, i, -v1, o2);                                        // :532-533: z = -c
+                P.at[base2 + 2u * (len - 1u) - 1u] = ta_make((uint32_t)ci, i, v1, o2);                 // :563-564
+            }
+            P.at[bar] = ta_make((uint32_t)i, -1, a, T_BAR);                                            // :546-548
+            P.at[bar + 1u] = ta_make((uint32_t)ci, -1, a, T_BAR);
+        }
+        P.n = base + 4u * (len - 1u) + 2u;
+        TW_SYNC();
+    }
+    bool simp;
+    do { t_pushvariables(P, M.n + 1u, lane); simp = t_simplify(P, true, lane); } while (simp);
+    uint32_t ad = 0, sc = 0, mu = 0;                                                                   // :133-144
+    for (uint32_t k = lane; k < P.n; k += 64u) {
+        const uint64_t at = P.at[k]; const uint32_t o = ta_ope(at); const int v = ta_val(at);
+        if (t_as(o)) { ++ad; if (v != 1 && v != -1) ++sc; }
+        if (t_md(o)) ++sc;
+        if (o == T_BAR) ++mu;
+    }
+    for (int off = 32; off > 0; off >>= 1) { ad += __shfl_xor(ad, off); sc += __shfl_xor(sc, off); mu += __shfl_xor(mu, off); }
+    ops[0] = ad; ops[1] = sc; ops[2] = mu >> 1;                                                        // :799: a double-size AXPY holds two barriers
+}
+
 __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tdyn[];
@@ -309,7 +367,8 @@ __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
             if (basec && variant == 1u) { tot[3] = tot[0]; tot[4] = tot[1]; tot[5] = tot[2]; break; }
             for (uint32_t w = 0; w < 3u; ++w) {
                 uint32_t o[3] = {0, 0, 0};
-                t_linear(G, P.M[w], perm, sgn, w, w == 2u, variant == 0u, rng, lane, o, cap, J.err);
+                if (w == 2u && P.expanded) t_double(G, P.M[2], perm, sgn, 2u, lane, o, cap, J.err);
+                else t_linear(G, P.M[w], perm, sgn, w, w == 2u, variant == 0u, rng, lane, o, cap, J.err);
                 tot[3u * variant] += o[0]; tot[3u * variant + 1u] += o[1]; tot[3u * variant + 2u] += o[2];
             }
             tot[3u * variant + 2u] /= 3u;                                                            // :801-803

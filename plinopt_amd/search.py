@@ -185,7 +185,8 @@ class TrilPlan:
     `cost_many` returns, per seed, ((ADD,SCA,MUL) oriented, (ADD,SCA,MUL) unoriented); `search` the best
     (ADD, SCA, MUL, seed, variant) under the reference's order (:893-897), ties to the smaller (seed, variant)."""
 
-    def __init__(self, m, mats, device=None):
+    def __init__(self, m, mats, device=None, expanded=False):
+        """expanded: `trilplacer -e` (TransposedDoubleAlgorithm on the double expansion of T)"""
         L = capi.lib()
         if device is not None:
             capi.check(L.plo_init(device))
@@ -196,7 +197,7 @@ class TrilPlan:
             self._keep.append(a)
             cs.append(capi.ICSR(m, n, a[0], a[1], a[2]))
         self._h = ctypes.c_void_p()
-        capi.check(L.plo_tril_plan_create(ctypes.byref(cs[0]), ctypes.byref(cs[1]), ctypes.byref(cs[2]), ctypes.byref(self._h)))
+        capi.check(L.plo_tril_plan_create_x(ctypes.byref(cs[0]), ctypes.byref(cs[1]), ctypes.byref(cs[2]), int(bool(expanded)), ctypes.byref(self._h)))
         self.last_stats = None
 
     def __del__(self):

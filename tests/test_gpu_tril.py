@@ -69,3 +69,35 @@ def test_ten_thousand_seeds_on_config4(hip):
     n = 10000
     assert G.cost_many(seed0=2 * 10 ** 9, n=n) == O.cost_many(seed0=2 * 10 ** 9, nseeds=n)
     assert G.search(2 * 10 ** 9, n) == O.search(2 * 10 ** 9, n)
+
+
+# ----------------------------------------------------------------------------- trilplacer -e
+@pytest.mark.parametrize("name", UNIT)
+def test_expanded_cost_many_bit_exact(hip, name):
+    """`trilplacer -e`: the c program is TransposedDoubleAlgorithm on DoubleExpand(T) (plinopt_inplace.inl:507-598, :676-716;
+    plo_tril_plan_create_x with expanded = 1): (ADD, SCA, MUL) of both variants per seed against the oracle, whose
+    expanded programs pass the double-size in-place check (tests/test_tril_oracle.py)."""
+    from plinopt_amd import TrilPlan
+    O = OracleTril.from_sms(*(os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")))
+    G = TrilPlan(O.m, [(n, rp, col, [int(x) for x in num]) for n, (rp, col, num, den) in zip(O.dims, O.csr)], expanded=True)
+    n = 32 if O.m > 30 else 64
+    seeds = [TRIL_BASE_SEED, 0, 1, 2**40 + 7] + list(range(2000, 2000 + n))
+    assert G.cost_many(seeds=seeds) == O.cost_many(seeds=seeds, expanded=True)
+
+
+def test_expanded_search_same_argmin_and_cli(hip):
+    import re
+    import subprocess
+    from plinopt_amd import TrilPlan
+    from plo_testlib import ROOT
+    name = "4x4x4_49_156"
+    files = [os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")]
+    O = OracleTril.from_sms(*files)
+    G = TrilPlan(O.m, [(n, rp, col, [int(x) for x in num]) for n, (rp, col, num, den) in zip(O.dims, O.csr)], expanded=True)
+    assert G.search(700, 400) == O.search(700, 400, expanded=True)
+    # bin/trilplacer -e: GPU search, host replay; same winner and text as the host loop
+    g = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-e", "-O", "400", "--seed", "700"] + files, capture_output=True, text=True, timeout=300)
+    h = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-e", "-O", "400", "--seed", "700", "--gpu", "0"] + files, capture_output=True, text=True, timeout=300)
+    assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
+    assert "restarts on GPU" in g.stderr and g.stdout == h.stdout
+    assert re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", g.stderr) == re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", h.stderr)
