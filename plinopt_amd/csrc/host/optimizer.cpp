@@ -177,9 +177,9 @@ template <class F> std::string ab_text(const F &f, const ABFactors<F> &ab, uint6
 
 // ABOptimiser :1114-1186 for the inner dimension coldim(M).  Returns false when the method could not run.
 template <class F> bool ab_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
-                                  int verbose, Ops &gops, std::string &gtext, const char *argv0) {
+                                  int verbose, Ops &gops, std::string &gtext, const char *argv0, size_t innerdim = 0) {
     if (lM.rowdim() < lM.coldim()) { std::clog << "# -A skipped: fewer rows than columns" << std::endl; return false; }
-    const ABFactors<F> ab = ab_factorize(f, lM, 1 + (loops >> 3), seed0);                                   // :1129-1130
+    const ABFactors<F> ab = ab_factorize(f, lM, 1 + (loops >> 3), seed0, innerdim);                         // :1129-1130
     uint64_t seed = 0; Ops best; bool have = false;
     if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
         HipLib L;
@@ -548,8 +548,12 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         if (verbose > 0) std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one GPU each)") << ": " << total << " candidates, slowest kernel " << kmax << " ms" << std::endl;
     }
     if (tryAB) {                                                                      // :1436-1440 (inner dimension = column count)
-        try { ab_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
-        catch (const std::exception &e) { std::clog << "# -A skipped: " << e.what() << std::endl; }
+        // every inner dimension from the column count to the row count - 1 (:1437-1439); a square matrix has the identity factorization only
+        const size_t id0 = lM.coldim(), id1 = std::max<size_t>(lM.rowdim(), id0 + 1);
+        for (size_t id = id0; id < id1; ++id) {
+            try { ab_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0, id); }
+            catch (const std::exception &e) { std::clog << "# -A skipped: " << e.what() << std::endl; }
+        }
     }
     if (tryDirect) {
         Ops dops; uint64_t seed = 0; bool have = false;
@@ -642,7 +646,7 @@ int main(int argc, char **argv)
                       << "  -O #: randomized search with that many loops (default " << loops << " loops)\n"
                       << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only, N >= 2 = the seeds of -D in N shards, one GPU each\n"
                       << "  --seed #: first candidate seed (default 0)\n"
-                      << "  -A: also try the alternative factorization M = Alt.CoB (inner dimension = column count)\n"
+                      << "  -A: also try the alternative factorizations M = Alt.CoB, every inner dimension from the column count to the row count - 1\n"
                       << "  -E: also walk the exhaustive tree of greedy CSE schedules (bounded by max(-O, 2^22) schedules)\n"
                       << "  --only D|K|G|A|E|N: run exactly that method\n"
                       << "  --kernel-block #: restarts per nullspace decomposition of -K (default 1: one decomposition per restart, as the reference)\n"

@@ -619,55 +619,65 @@ template <class F> LUFactors<F> sparse_lu(const F &f, const SparseMat<typename F
 
 // --------------------------------------------------------------------- -A: M = Alt . CoB
 // backSolver / Factorizer (reference include/plinopt_sparsify.inl:756-867, :924-984) for the inner dimension
-// k = coldim(M) (ABOptimiser's first value, plinopt_optimize.inl:1437-1439): a random order of the rows (the build's
-// per-candidate stream; the reference uses LinBox's Permutation::random), the first n independent rows in that order
-// become CoB (n x n, invertible), Alt = M . CoB^{-1} (the chosen rows are unit rows).  Larger inner dimensions need an
-// underdetermined solve whose particular solution is LinBox's (unpinned): not built.
+// backSolver (reference include/plinopt_sparsify.inl:756-867) for an inner dimension k, n = coldim(M) <= k <= rowdim(M)
+// (ABOptimiser tries every k in [n, m), plinopt_optimize.inl:1437-1439): a random order of the rows (the build's
+// per-candidate stream; the reference uses LinBox's Permutation::random), the first n independent rows in that order are
+// swapped to the front as :784-799 does, the next k-n rows of the resulting order join them (:802-804): these k rows are
+// CoB (k x n) and unit rows of Alt (m x k, :842); every other row is solved for, x . CoB = row (:845-851).  For k > n the
+// system is underdetermined and the reference takes whatever particular solution LinBox's QLUP solve returns (its pivoting
+// is not in the tree); here the solution is the one supported on the n independent rows (the added rows get coefficient 0).
 template <class F> struct ABFactors {
     SparseMat<typename F::Elt> Alt, CoB;
     std::array<size_t, 3> score{0, 0, 0};     // nnz(Alt), non +-1 entries of Alt, nnz(CoB): tricOpCount :911-920
     bool identity = false;
 };
-template <class F> bool ab_backsolve(const F &f, const SparseMat<typename F::Elt> &M, uint64_t seed, ABFactors<F> &out) {
+template <class F> bool ab_backsolve(const F &f, const SparseMat<typename F::Elt> &M, uint64_t seed, ABFactors<F> &out, size_t innerdim = 0) {
     using E = typename F::Elt;
-    const size_t m = M.rowdim(), n = M.coldim();
+    const size_t m = M.rowdim(), n = M.coldim(), kdim = innerdim ? innerdim : n;
+    if (kdim < n || kdim > m) return false;
     std::vector<size_t> ord(m);
     for (size_t i = 0; i < m; ++i) ord[i] = i;
     CandRng rng(seed);
     for (size_t i = m; i > 1; --i) std::swap(ord[i - 1], ord[rng.next() % (uint32_t)i]);
-    // greedy row basis in that order; E keeps the echelon rows together with the combination of basis rows they are
-    std::vector<std::vector<E>> ech, comb; std::vector<size_t> piv, chosen;
+    // greedy row basis in that order; ech keeps the echelon rows together with the combination of basis rows they are
+    std::vector<std::vector<E>> ech, comb; std::vector<size_t> piv;
     auto dense_row = [&](size_t r) { std::vector<E> v(n, f.zero()); for (auto &e : M.rows[r]) v[e.first] = e.second; return v; };
-    for (size_t t = 0; t < m && chosen.size() < n; ++t) {
-        std::vector<E> v = dense_row(ord[t]), c(n, f.zero());
-        for (size_t k = 0; k < ech.size(); ++k) {
-            const E x = v[piv[k]];
-            if (f.isZero(x)) continue;
-            for (size_t j = 0; j < n; ++j) v[j] = f.add(v[j], f.neg(f.mul(x, ech[k][j])));
-            for (size_t j = 0; j < n; ++j) c[j] = f.add(c[j], f.neg(f.mul(x, comb[k][j])));
+    size_t nb = 0;
+    for (size_t i = 0; i < n; ++i) {                              // :784-799: position i takes the first later row that raises the rank
+        bool got = false;
+        for (size_t j = i; j < m && !got; ++j) {
+            std::vector<E> v = dense_row(ord[j]), c(n, f.zero());
+            for (size_t k = 0; k < ech.size(); ++k) {
+                const E x = v[piv[k]];
+                if (f.isZero(x)) continue;
+                for (size_t q = 0; q < n; ++q) v[q] = f.add(v[q], f.neg(f.mul(x, ech[k][q])));
+                for (size_t q = 0; q < n; ++q) c[q] = f.add(c[q], f.neg(f.mul(x, comb[k][q])));
+            }
+            size_t pc = n;
+            for (size_t q = 0; q < n; ++q) if (!f.isZero(v[q])) { pc = q; break; }
+            if (pc == n) continue;                                // dependent on the rows chosen so far
+            const E iv = f.inv(v[pc]);
+            c[i] = f.add(c[i], f.one());                          // this row itself is basis row number i
+            for (size_t q = 0; q < n; ++q) { v[q] = f.mul(v[q], iv); c[q] = f.mul(c[q], iv); }
+            ech.push_back(v); comb.push_back(c); piv.push_back(pc);
+            std::swap(ord[i], ord[j]); got = true; ++nb;
         }
-        size_t pc = n;
-        for (size_t j = 0; j < n; ++j) if (!f.isZero(v[j])) { pc = j; break; }
-        if (pc == n) continue;                                   // dependent on the rows chosen so far
-        const E iv = f.inv(v[pc]);
-        c[chosen.size()] = f.add(c[chosen.size()], f.one());     // this row itself is basis row number |chosen|
-        for (size_t j = 0; j < n; ++j) { v[j] = f.mul(v[j], iv); c[j] = f.mul(c[j], iv); }
-        ech.push_back(v); comb.push_back(c); piv.push_back(pc); chosen.push_back(ord[t]);
+        if (!got) break;
     }
-    if (chosen.size() < n) return false;                         // rank < n: no square change of basis
-    // x . CoB = row  <=>  reduce the row with the echelon rows, accumulating the combination of basis rows
-    out.CoB = SparseMat<E>(n, n); out.Alt = SparseMat<E>(m, n);
-    for (size_t k = 0; k < n; ++k) out.CoB.rows[k] = M.rows[chosen[k]];
-    for (size_t i = 0; i < m; ++i) {
+    if (nb < n) return false;                                     // rank < n: no change of basis of full column rank
+    out.CoB = SparseMat<E>(kdim, n); out.Alt = SparseMat<E>(m, kdim);
+    for (size_t k = 0; k < kdim; ++k) { out.CoB.rows[k] = M.rows[ord[k]]; out.Alt.rows[ord[k]].emplace_back(k, f.one()); }   // :802-804, :842
+    for (size_t t = kdim; t < m; ++t) {                           // x . CoB = row, supported on the n independent rows
+        const size_t i = ord[t];
         std::vector<E> v = dense_row(i), x(n, f.zero());
         for (size_t k = 0; k < n; ++k) {
             const E y = v[piv[k]];
             if (f.isZero(y)) continue;
-            for (size_t j = 0; j < n; ++j) v[j] = f.add(v[j], f.neg(f.mul(y, ech[k][j])));
-            for (size_t j = 0; j < n; ++j) x[j] = f.add(x[j], f.mul(y, comb[k][j]));
+            for (size_t q = 0; q < n; ++q) v[q] = f.add(v[q], f.neg(f.mul(y, ech[k][q])));
+            for (size_t q = 0; q < n; ++q) x[q] = f.add(x[q], f.mul(y, comb[k][q]));
         }
-        for (size_t j = 0; j < n; ++j) if (!f.isZero(v[j])) return false;      // cannot happen at full column rank
-        for (size_t j = 0; j < n; ++j) if (!f.isZero(x[j])) out.Alt.rows[i].emplace_back(j, x[j]);
+        for (size_t q = 0; q < n; ++q) if (!f.isZero(v[q])) return false;      // cannot happen at full column rank
+        for (size_t q = 0; q < n; ++q) if (!f.isZero(x[q])) out.Alt.rows[i].emplace_back(q, x[q]);
     }
     size_t nz = 0, nu = 0, nc = 0;
     for (auto &r : out.Alt.rows) for (auto &e : r) { ++nz; if (!absOne(f, e.second)) ++nu; }
@@ -676,16 +686,17 @@ template <class F> bool ab_backsolve(const F &f, const SparseMat<typename F::Elt
     return true;
 }
 // Factorizer :924-984: best of `loops` back-solves (seeds seed0 ...), starting from (Alt, CoB) = (M, identity)
-template <class F> ABFactors<F> ab_factorize(const F &f, const SparseMat<typename F::Elt> &M, size_t loops, uint64_t seed0) {
+template <class F> ABFactors<F> ab_factorize(const F &f, const SparseMat<typename F::Elt> &M, size_t loops, uint64_t seed0, size_t innerdim = 0) {
     using E = typename F::Elt;
-    const size_t m = M.rowdim(), n = M.coldim();
+    const size_t m = M.rowdim(), n = M.coldim(), kdim = innerdim ? innerdim : n;
     ABFactors<F> best;
     if (m == n) {                                                // :945-951 identity factorization
         best.CoB = M; best.Alt = SparseMat<E>(m, n); best.identity = true;
         for (size_t i = 0; i < m; ++i) best.Alt.rows[i].emplace_back(i, f.one());
         return best;
     }
-    best.Alt = M; best.CoB = SparseMat<E>(n, n);
+    best.Alt = SparseMat<E>(m, kdim); for (size_t i = 0; i < m; ++i) best.Alt.rows[i] = M.rows[i];     // :953-955: (M | 0) . (I ; 0)
+    best.CoB = SparseMat<E>(kdim, n);
     for (size_t i = 0; i < n; ++i) best.CoB.rows[i].emplace_back(i, f.one());
     size_t nz = 0, nu = 0;
     for (auto &r : M.rows) for (auto &e : r) { ++nz; if (!absOne(f, e.second)) ++nu; }
@@ -695,7 +706,7 @@ template <class F> ABFactors<F> ab_factorize(const F &f, const SparseMat<typenam
 #pragma omp parallel for schedule(dynamic, 16)
     for (long long i = 0; i < (long long)loops; ++i) {
         ABFactors<F> c;
-        if (!ab_backsolve(f, M, seed0 + (uint64_t)i, c)) continue;
+        if (!ab_backsolve(f, M, seed0 + (uint64_t)i, c, kdim)) continue;
 #pragma omp critical
         if (c.score < best.score || (c.score == best.score && bi != loops && (size_t)i < bi)) { best = c; bi = (size_t)i; }
     }

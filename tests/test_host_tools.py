@@ -406,3 +406,72 @@ def test_compacter_rewrites():
         rc, sms, e = run([CHK], stdin=prog)
         assert rc == 0
         assert sms == run([CHK], stdin=src)[1]
+
+
+# ----------------------------------------------------------------------------- factorizer
+FCT = os.path.join(ROOT, "bin", "factorizer")
+
+
+def test_factorizer_on_every_tall_matrix():
+    """bin/FDT.sh:68-76: for every data matrix with at least as many rows as columns, `factorizer -q 7 file` and
+    `factorizer file` must print SUCCESS (M == Alt . CoB, plinopt_sparsify.inl:872-907); Alt is never denser than M."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = []
+    for f in sorted(glob.glob(os.path.join(DATA, "*.sms"))):
+        if "-X_" in f or "32x32x32" in f:
+            continue
+        m, n = [int(x) for x in next(l for l in open(f) if l.strip() and not l.startswith("#")).split()[:2]]
+        if m >= n:
+            files.append(f)
+    assert len(files) >= 60
+    skip7 = ("2x2x2_7_DPS-integral-12.0662_P", "2x2x2_7_DPS-integral-12.0662_R", "4o4o8_Toom5_P")
+
+    def one(f):
+        out = []
+        for q in ([], ["-q", "7"]):
+            if q and any(s in f for s in skip7):
+                continue
+            rc, _, err = run([FCT, "-O", "10"] + q + [f])
+            assert rc == 0 and "SUCCESS: consistent factorization" in err and "ERROR" not in err, (f, q, err)
+            mm = re.search(r"with (\d+) non-zeroes \((\d+) alt\.\) instead of (\d+)", err)
+            assert int(mm.group(1)) <= int(mm.group(3)), (f, q, err)
+            out.append(1)
+        return len(out)
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        assert sum(ex.map(one, files)) >= 2 * len(files) - 3
+
+
+@pytest.mark.parametrize("name", ["3x4x7_63_rational", "4x4x4_48_accurate", "4x4x4_48_rational"])
+@pytest.mark.parametrize("side", ["L", "R"])
+def test_factorizer_reaches_the_stored_alternative_bases(name, side):
+    """The reference holds factorizer outputs (data/*-ALT_*.sms with *-CoB_*.sms, inner dimension = rows - 1, pinned in
+    tests/test_oracle_golden.py).  `bin/factorizer -k <that dimension>` on the same matrix finds an alternative matrix at
+    least as sparse (the sparsest possible here: one entry per row plus the one solved row), its factorization is
+    consistent, and the printed CoB times the printed Alt is the input (checked again in Python)."""
+    from fractions import Fraction
+    from plo_testlib import read_sms
+    from test_oracle_golden import _spmul
+    orig = os.path.join(DATA, "%s_%s.sms" % (name, side))
+    ma, na, A = read_sms(os.path.join(DATA, "%s-ALT_%s.sms" % (name, side)))
+    rc, cob, err = run([FCT, "-k", str(na), "-O", "300", "-S", orig])
+    assert rc == 0 and "SUCCESS: consistent factorization" in err, err
+    mm = re.search(r"with (\d+) non-zeroes \((\d+) alt\.\) instead of (\d+)", err)
+    assert int(mm.group(1)) <= len(A), (mm.groups(), len(A))
+    # the two printed matrices (CoB on stdout, Alt on the log stream, SMS format) multiply back to the input
+    def parse(txt):
+        lines = [l for l in txt.splitlines() if l.strip() and not l.startswith("#")]
+        m, n = int(lines[0].split()[0]), int(lines[0].split()[1])
+        ent = {}
+        for l in lines[1:]:
+            i, j, v = l.split()
+            if i == "0":
+                break
+            ent[(int(i) - 1, int(j) - 1)] = Fraction(v)
+        return m, n, ent
+    alt_txt = err[err.index("residuum profile"):]
+    alt_txt = alt_txt[alt_txt.index("\n") + 1:]
+    mc, nc, C = parse(cob)
+    mA, nA, Al = parse(alt_txt)
+    mo, no, X = read_sms(orig)
+    assert (mA, nA, mc, nc) == (mo, na, na, no) and _spmul(Al, C) == X
