@@ -61,6 +61,9 @@ typedef struct {
 #define PLO_COST_SUM_THEN_ADD 0   /* default cmpOpCount            */
 #define PLO_COST_ADD_THEN_MUL 1   /* -DOPTIMIZE_ADDITIONS           */
 #define PLO_COST_SUM          2   /* -DOPTIMIZE_SUMS                */
+#define PLO_COST_RECSUB       3   /* schedule enumeration only: RecSub's order (:958-959) on RecSub's own counts (:950-951):
+                                   * additions, then the multiplications BEFORE ProgramGen (multipliers emitted + non +-1
+                                   * entries left); plo_best_t.muls then holds that count */
 
 typedef struct plo_plan plo_plan_t;   /* a matrix prepared and resident in HBM */
 

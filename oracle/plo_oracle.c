@@ -626,3 +626,103 @@ int plo_oracle_enum_cost_many(uint32_t m, uint32_t n, const uint32_t *rowptr, co
     }
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Literal RecSub / RecOptimizer (plinopt_optimize.inl:889-1013) with their own accounting: the counts start from naiveOps
+ * (:992) and every step subtracts the savings returned by RemOneCSE with updateAPM = false (:60-194: one addition per row
+ * that held the pair, minus one for the new temporary; one multiplication per row whose entry in the second column of the
+ * oriented pair was not +-1, minus one when a new multiplier is emitted); a subtree replaces the best one when it has
+ * fewer additions, or as many and fewer multiplications (:958-959).  RecSub loops over every pair INSTANCE of every row
+ * whose triple has frequency > 1 (:936-939), so a triple is tried once per row that holds it; the restatement does the
+ * same (serially: the first strictly better subtree in loop order wins).  Then RecOptimizer: muls minus the non +-1 entries
+ * left (:1001-1003), ProgramGen (:1011), result (adds of RecSub, muls after ProgramGen) (:1012).
+ * Only for toy inputs: the tree is exponential. */
+typedef struct { mat_t M; mults_t mu; long adds, muls; } rs_state;
+static void rs_copy(rs_state *d, const rs_state *s) {
+    mat_init(&d->M, s->M.nrows, s->M.ncols, s->M.p);
+    for (int i = 0; i < s->M.nrows; i++) for (int k = 0; k < s->M.r[i].n; k++) row_push(&d->M.r[i], s->M.r[i].e[k].col, s->M.r[i].e[k].val);
+    d->mu.m = NULL; d->mu.n = d->mu.cap = 0;
+    for (int k = 0; k < s->mu.n; k++) mults_push(&d->mu, s->mu.m[k].idx, s->mu.m[k].col, s->mu.m[k].val);
+    d->adds = s->adds; d->muls = s->muls;
+}
+static void rs_free(rs_state *s) { mat_free(&s->M); free(s->mu.m); }
+/* RemOneCSE, updateAPM = false (:60-110, :148-194): returns the savings through sa / sm */
+static void rs_rem_one_cse(rs_state *S, const tri_t *cse, trivec_t *AllPairs, long *sa, long *sm) {
+    mat_t *lM = &S->M; const uint32_t p = lM->p; const uint32_t lm = (uint32_t)lM->ncols;
+    long savedadds = 0, savedmuls = 0;
+    uint32_t count0 = 0, count1 = 0;
+    for (int i = 0; i < lM->nrows; i++) for (int k = 0; k < lM->r[i].n; k++) {
+        const ent_t *e = &lM->r[i].e[k];
+        if (e->col == cse->a && f_absone(e->val, p)) ++count0;
+        if (e->col == cse->b && f_absone(e->val, p)) ++count1;
+    }
+    tri_t lcse;
+    if (count0 < count1) { lcse.a = cse->b; lcse.b = cse->a; lcse.r = f_inv(cse->r, p); } else lcse = *cse;
+    for (int i = 0; i < lM->nrows; i++) {
+        if (!tv_has(&AllPairs[i], cse)) continue;
+        row_t *row = &lM->r[i]; uint32_t coeff = 0;
+        for (int k = 0; k < row->n; k++) if (row->e[k].col == lcse.a) { coeff = row->e[k].val; row_erase(row, k); ++savedadds; break; }
+        for (int k = 0; k < row->n; k++) if (row->e[k].col == lcse.b) { if (!f_absone(row->e[k].val, p)) ++savedmuls; row_erase(row, k); row_push(row, lm, coeff); break; }
+    }
+    const uint32_t asgs = f_abs(lcse.r, p); uint32_t rindex = lm; long moremul = 0;
+    if (!f_absone(asgs, p)) {
+        for (int k = 0; k < S->mu.n; k++) if (S->mu.m[k].col == lcse.b && S->mu.m[k].val == asgs) { rindex = S->mu.m[k].idx; break; }
+        if (rindex == lm) { moremul = 1; mults_push(&S->mu, lm, lcse.b, asgs); }
+    }
+    savedmuls -= moremul;
+    --savedadds;
+    lM->ncols = (int)lm + 1;
+    *sa = savedadds; *sm = savedmuls;
+}
+static uint64_t g_rs_nodes;
+static void rs_recsub(rs_state *S) {
+    mat_t *M = &S->M; const uint32_t p = M->p;
+    trivec_t *AllPairs = (trivec_t *)calloc(M->nrows ? M->nrows : 1, sizeof(trivec_t));
+    pmap_t PairMap = { 0, 0, 0 };
+    for (int i = 0; i < M->nrows; i++) listpairs(&AllPairs[i], &M->r[i], p);
+    for (int i = 0; i < M->nrows; i++) for (int k = 0; k < AllPairs[i].n; k++) pm_inc(&PairMap, &AllPairs[i].t[k]);
+    uint32_t maxfrq = 0;
+    for (int k = 0; k < PairMap.n; k++) if (PairMap.e[k].cnt > maxfrq) maxfrq = PairMap.e[k].cnt;
+    if (PairMap.n && maxfrq <= 1) goto done;                          /* :920-922 */
+    {
+        rs_state best; rs_copy(&best, S);                             /* bestadds(nbadd), bestmuls(nbmul), bestM = Mat :930-933 */
+        for (int i = 0; i < M->nrows; i++)
+            for (int k = 0; k < AllPairs[i].n; k++) {
+                const tri_t *cse = &AllPairs[i].t[k];
+                int pos; if (!pm_find(&PairMap, cse, &pos) || PairMap.e[pos].cnt <= 1) continue;    /* :939 */
+                rs_state L; rs_copy(&L, S);
+                long sa, sm; rs_rem_one_cse(&L, cse, AllPairs, &sa, &sm);
+                L.adds = S->adds - sa; L.muls = S->muls - sm;         /* :950-951 */
+                ++g_rs_nodes;
+                rs_recsub(&L);
+                if (L.adds < best.adds || (L.adds == best.adds && L.muls < best.muls)) { rs_free(&best); best = L; }   /* :958-964 */
+                else rs_free(&L);
+            }
+        rs_free(S); *S = best;                                        /* :970-973 */
+    }
+done:
+    for (int i = 0; i < M->nrows; i++) free(AllPairs[i].t);
+    free(AllPairs); free(PairMap.e);
+}
+/* best (adds, muls before ProgramGen) of RecSub's tree, the final (adds, muls) of RecOptimizer, and the tree nodes visited */
+int plo_oracle_recsub(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                      uint32_t *adds, uint32_t *muls_recsub, uint32_t *muls_final, uint64_t *nodes) {
+    if (p < 2) return -1;
+    cand_t C; cand_load(&C, m, n, rowptr, col, val, p, 0, "otri", 0);
+    rs_state S; S.M = C.M; S.mu.m = NULL; S.mu.n = S.mu.cap = 0; S.adds = 0; S.muls = 0;
+    for (int i = 0; i < S.M.nrows; i++) {                             /* naiveOps, plinopt_library.inl:227-235 */
+        if (S.M.r[i].n > 1) S.adds += S.M.r[i].n - 1;
+        for (int k = 0; k < S.M.r[i].n; k++) if (!f_absone(S.M.r[i].e[k].val, p)) ++S.muls;
+    }
+    g_rs_nodes = 0;
+    rs_recsub(&S);
+    long already = S.muls;
+    for (int i = 0; i < S.M.nrows; i++) for (int k = 0; k < S.M.r[i].n; k++) if (!f_absone(S.M.r[i].e[k].val, p)) --already;   /* :1001-1003 */
+    *adds = (uint32_t)S.adds; *muls_recsub = (uint32_t)S.muls;
+    C.M = S.M; free(C.multiples.m); C.multiples = S.mu; C.nbadd = 0; C.nbmul = (uint32_t)already;
+    program_gen(&C);                                                  /* :1011: addcount is dropped, muls accumulate */
+    *muls_final = C.nbmul; if (nodes) *nodes = g_rs_nodes;
+    cand_free(&C);
+    return 0;
+}

@@ -116,6 +116,13 @@ int plo_oracle_tril_program_x(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PL
 int plo_oracle_tril_search_x(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO_TRIL_ARGS(T), int expanded,
                              uint64_t seed0, uint64_t nseeds, uint32_t *best_ops3, uint64_t *best_seed, uint32_t *best_variant);
 
+/* Literal RecSub / RecOptimizer (plinopt_optimize.inl:889-1013) with their savings accounting, for toy inputs (the tree is
+ * exponential): *adds and *muls_recsub = the best (additions, multiplications) RecSub reports (:958-959 order; the
+ * multiplications count every non +-1 entry left as one), *muls_final = the multiplications RecOptimizer returns after
+ * ProgramGen (:1012), *nodes = RemOneCSE calls made. */
+int plo_oracle_recsub(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                      uint32_t *adds, uint32_t *muls_recsub, uint32_t *muls_final, uint64_t *nodes);
+
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);
 

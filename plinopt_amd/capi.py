@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PLO_HIP_LIB") or os.path.join(_HERE, "libplinopt_hip.
 
 PLO_OK = 0
 PLO_E_ARG, PLO_E_HIP, PLO_E_CAPACITY, PLO_E_UNSUPPORTED, PLO_E_INTERNAL = -1, -2, -3, -4, -5
-COST_SUM_THEN_ADD, COST_ADD_THEN_MUL, COST_SUM = 0, 1, 2
+COST_SUM_THEN_ADD, COST_ADD_THEN_MUL, COST_SUM, COST_RECSUB = 0, 1, 2, 3
 PLAN_HBM = 1
 
 # every symbol include/plinopt_hip.h declares

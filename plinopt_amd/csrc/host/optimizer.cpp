@@ -420,11 +420,12 @@ template <class F> bool allkernels_method(const F &f, const SparseMat<typename F
 }
 
 // program text of one schedule of the exhaustive CSE tree
-template <class F> std::string schedule_text(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t index, Ops &ops, uint64_t &prod) {
+template <class F> std::string schedule_text(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t index, Ops &ops, uint64_t &prod, size_t *recsub_muls = nullptr) {
     std::ostringstream os;
     input2temps(os, lM, 'i', 't');                                                                         // :1265
     Replay<F> R(f, lM, 0, os, 'o', 't', 'r'); R.set_schedule(index);
     ops = R.optimizer(); prod = R.eprod;
+    if (recsub_muls) *recsub_muls = R.recsub_muls;
     return os.str();
 }
 
@@ -433,9 +434,11 @@ template <class F> std::string schedule_text(const F &f, const SparseMat<typenam
 // by schedule index (include/plinopt_hip.h): ranges 0..N-1 with N growing to the largest radix product seen; exhaustive
 // when N reaches it, otherwise stopped at `budget` schedules (the reference has no bound and no termination on anything
 // but toy inputs).  Returns false when the method could not run.
+bool g_recsub_order = false;   // --recsub: choose the schedule as RecSub does (:950-959): additions, then ITS multiplication count (before ProgramGen)
 template <class F> bool exhaustive_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t budget, int gpu, uint32_t q,
                                           int verbose, Ops &gops, std::string &gtext, const char *argv0) {
     Ops best; uint64_t bidx = 0, maxprod = 1, done = 0; bool have = false, on_gpu = false; double kms = 0;
+    // `best` holds the SELECTION key: (adds, muls of the program), or with --recsub (adds, RecSub's multiplication count)
     auto better = [](const Ops &a, const Ops &b) { return cmp_op_count(a, b, 1); };
     HipLib L; plo_plan_t *plan = nullptr;
     std::vector<uint32_t> rp, cc, vv;
@@ -452,14 +455,15 @@ template <class F> bool exhaustive_method(const F &f, const SparseMat<typename F
         Ops rb; uint64_t ri = 0, rp_ = 1; bool rh = false;
         if (on_gpu) {
             plo_best_t b{}; plo_stats_t st{}; uint64_t mp = 0;
-            if (L.enum_search(plan, done, cnt, PLO_COST_ADD_THEN_MUL, &b, &mp, &st) != PLO_OK) {
+            if (L.enum_search(plan, done, cnt, g_recsub_order ? PLO_COST_RECSUB : PLO_COST_ADD_THEN_MUL, &b, &mp, &st) != PLO_OK) {
                 std::clog << "# -E skipped: " << L.last_error() << std::endl; L.plan_destroy(plan); return false;
             }
             rb = {b.adds, b.muls}; ri = b.seed; rp_ = mp; rh = true; kms += st.kernel_ms;
         } else {
 #pragma omp parallel for schedule(dynamic, 8)
             for (long long k = 0; k < (long long)cnt; ++k) {
-                Ops ops; uint64_t pr = 1; (void)schedule_text(f, lM, done + (uint64_t)k, ops, pr);
+                Ops ops; uint64_t pr = 1; size_t rm = 0; (void)schedule_text(f, lM, done + (uint64_t)k, ops, pr, &rm);
+                if (g_recsub_order) ops.second = rm;
 #pragma omp critical
                 { const uint64_t ix = done + (uint64_t)k; if (!rh || better(ops, rb) || (!better(rb, ops) && ix < ri)) { rb = ops; ri = ix; rh = true; } rp_ = std::max(rp_, pr); }
             }
@@ -471,19 +475,23 @@ template <class F> bool exhaustive_method(const F &f, const SparseMat<typename F
     }
     if (on_gpu) L.plan_destroy(plan);
     if (!have) return false;
-    Ops rops; uint64_t pr = 1; std::string t = schedule_text(f, lM, bidx, rops, pr);
+    Ops rops; uint64_t pr = 1; size_t rm = 0; std::string t = schedule_text(f, lM, bidx, rops, pr, &rm);
+    const Ops prog = rops;                                   // what the printed program costs
+    if (g_recsub_order) rops.second = rm;
     if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -E replay of schedule " << bidx << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
     const bool complete = maxprod <= done;
     if (verbose > 0) {
-        std::clog << "# Found E: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[schedule " << bidx << "] ("
+        if (g_recsub_order) std::clog << "# RecSub accounting: " << best.first << '|' << best.second << " (additions | multiplications before ProgramGen); program " << prog.first << '|' << prog.second << std::endl;
+        std::clog << "# Found E: " << prog.first << '|' << prog.second << " instead of " << gops.first << '|' << gops.second << "\t[schedule " << bidx << "] ("
                   << done << (complete ? " schedules: the whole tree" : " schedules of a tree of at least ") ;
         if (!complete) std::clog << maxprod;
         std::clog << (on_gpu ? ", GPU" : ", host");
         if (on_gpu) std::clog << " kernel " << kms << " ms";
         std::clog << ')' << std::endl;
     }
-    if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                              // :1270-1274
-    else std::clog << "# \033[1;36mNo greedy CSE schedule has less additions.\033[0m" << std::endl;       // :1275-1278
+    if (cmp_op_count(prog, gops)) { gops = prog; gtext = t; }                                              // :1270-1274
+    else if (complete) std::clog << "# \033[1;36mNo greedy CSE schedule has less additions.\033[0m" << std::endl;       // :1275-1278
+    if (!complete) std::clog << "# \033[1;36m-E stopped after " << done << " schedules of a tree of at least " << maxprod << ": the result is the best of those only.\033[0m" << std::endl;
     return true;
 }
 
@@ -647,7 +655,9 @@ int main(int argc, char **argv)
                       << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only, N >= 2 = the seeds of -D in N shards, one GPU each\n"
                       << "  --seed #: first candidate seed (default 0)\n"
                       << "  -A: also try the alternative factorizations M = Alt.CoB, every inner dimension from the column count to the row count - 1\n"
-                      << "  -E: also walk the exhaustive tree of greedy CSE schedules (bounded by max(-O, 2^22) schedules)\n"
+                      << "  -E: also walk the exhaustive tree of greedy CSE schedules (bounded by max(-O, 2^22) schedules; every DISTINCT triple of\n"
+                      << "      frequency > 1 is a child, once -- the reference tries it once per row holding it); best by additions then multiplications\n"
+                      << "      of the printed program, or with --recsub by RecSub's own counts (multiplications before ProgramGen)\n"
                       << "  --only D|K|G|A|E|N: run exactly that method\n"
                       << "  --kernel-block #: restarts per nullspace decomposition of -K (default 1: one decomposition per restart, as the reference)\n"
                       << "  -M/-P: also print the matrix (Maple / pretty) on the log stream\n";
@@ -669,6 +679,7 @@ int main(int argc, char **argv)
         else if (a == "--engine" && i + 1 < argc) { std::string e(argv[++i]); g_engine = e == "literal" ? 1 : e == "fast" ? 2 : 0; }
         else if (a == "--replay") replay_only = true;    // print the program of candidate --seed, no search
         else if (a == "--kernel-block" && i + 1 < argc) g_kernel_block = std::max<uint64_t>(1, strtoull(argv[++i], nullptr, 10));
+        else if (a == "--recsub") g_recsub_order = true;
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing
         else filename = a;
     }

@@ -547,7 +547,14 @@ public:
     Replay(const F &ff, const Mat &A, CandRng &shared, std::ostream &os, char o, char t, char r)
         : f(ff), M(A), own_rng(0), rng(shared), out(os), ouv(o), tev(t), rav(r) {}
     // Optimizer(), include/plinopt_optimize.inl:616-631
-    std::pair<size_t, size_t> optimizer() { while (one_sub()) {} program_gen(); return {nbadd, nbmul}; }
+    // RecSub's own multiplication count of this schedule (reference include/plinopt_optimize.inl:950-951): naiveOps minus
+    // the savings of the steps = the multipliers emitted so far plus every non +-1 entry left, before ProgramGen factors them
+    size_t recsub_muls = 0;
+    std::pair<size_t, size_t> optimizer() {
+        while (one_sub()) {}
+        recsub_muls = nbmul; for (auto &r : M.rows) for (auto &e : r) if (!absOne(f, e.second)) ++recsub_muls;
+        program_gen(); return {nbadd, nbmul};
+    }
     // the fallback of OptMethods :1473-1485: ProgramGen on the untouched matrix
     std::pair<size_t, size_t> direct() { program_gen(); return {nbadd, nbmul}; }
 };

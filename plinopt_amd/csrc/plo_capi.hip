@@ -761,7 +761,7 @@ int plo_cse_enum_cost_many_plan(plo_plan_t *pl, uint64_t first, uint64_t n, uint
 int plo_cse_enum_search_plan(plo_plan_t *pl, uint64_t first, uint64_t count, int cost_mode, plo_best_t *out, uint64_t *maxprod, plo_stats_t *st)
 {
     if (!pl || !out || !maxprod) return fail(PLO_E_ARG, "null argument");
-    if (cost_mode != PLO_COST_SUM_THEN_ADD && cost_mode != PLO_COST_ADD_THEN_MUL) return fail(PLO_E_ARG, "cost mode 0 or 1");
+    if (cost_mode != PLO_COST_SUM_THEN_ADD && cost_mode != PLO_COST_ADD_THEN_MUL && cost_mode != PLO_COST_RECSUB) return fail(PLO_E_ARG, "cost mode 0, 1 or 3");
     if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
     if (pl->big) return fail(PLO_E_UNSUPPORTED, "schedule enumeration is for matrices of the LDS-resident kernel (the tree of anything larger cannot be walked)");
     plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};

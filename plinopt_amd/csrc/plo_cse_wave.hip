@@ -398,7 +398,7 @@ __device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const u
 // frequency, one draw of the stream.  Enumeration (-E, RecSub :889-982 explores every pair of frequency > 1): all triples
 // of frequency > 1 are the children, the candidate's index is read in the mixed radix of its own path (digit = rem mod T,
 // rem /= T); prod = product of the radices (saturating): indices 0..N-1 cover the whole tree once N >= max prod.
-struct PickState { uint32_t rng; uint32_t enumerate; uint64_t rem, prod; };
+struct PickState { uint32_t rng; uint32_t enumerate; uint64_t rem, prod; uint32_t recsub_muls; };   // recsub_muls: RecSub's multiplication count of the schedule (:950-951), set by run_candidate
 
 // One candidate.  Returns packed (adds<<32 | muls); sets *errw on failure.
 template <bool UNIT>
@@ -578,8 +578,14 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         uint32_t acc = 0;
         for (uint32_t i = lane; i < P.m; i += 64u) { uint32_t ln = len[i]; acc += ln > 1u ? ln - 1u : 0u; }
         nbadd += wave_sum(acc);
+        ps.recsub_muls = 0u;
     } else {
         PLO_WAVE_SYNC();
+        {   // RecSub counts, per schedule, the multipliers emitted so far plus one multiplication per non +-1 entry left (:950-951, :1001-1003)
+            uint32_t nu = 0;
+            for (uint32_t i = lane; i < P.m; i += 64u) { const uint32_t b0 = rs[i], ln = len[i]; for (uint32_t k = 0; k < ln; ++k) { const uint32_t v = val[b0 + k]; nu += (v != 1u && v != p - 1u) ? 1u : 0u; } }
+            ps.recsub_muls = nbmul + wave_sum(nu);
+        }
         return program_gen_general(P, reg, rs, lane, ncols, nmult, nbadd, nbmul, errw);
     }
     return ((uint64_t)nbadd << 32) | nbmul;
@@ -589,6 +595,7 @@ __device__ __forceinline__ uint32_t cost_key32(uint32_t a, uint32_t mu_, uint32_
     switch (mode) {
     case 1: return (a << 16) | mu_;              // adds, then muls
     case 2: return (a + mu_) << 16;              // sum only
+    case 3: return (a << 16) | mu_;              // RecSub's order: adds, then ITS multiplication count (the caller passes it as mu_)
     default: return ((a + mu_) << 16) | a;       // sum, then adds
     }
 }
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(256) void cse_wave_kernel(WavePlan P, WaveJob J)
         for (uint32_t i = lane; i < tw; i += 64u) ((uint64_t *)reg)[i] = P.tmpl[i];     // matrix image -> LDS
         PLO_WAVE_SYNC();
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), J.enumerate, seed, 1ull};
+        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), J.enumerate, seed, 1ull, 0u};
         const uint64_t res = run_candidate<UNIT>(P, reg, rs, ps, lane, J.err);
         if (J.enumerate && lane == 0) { if (J.prods) J.prods[c] = ps.prod; if (J.prodmax) atomicMax(J.prodmax, (unsigned long long)ps.prod); }
         const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256) void cse_wave_kernel(WavePlan P, WaveJob J)
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
         }
-        const uint64_t packed = ((uint64_t)cost_key32(a, mu_, J.cost_mode) << 32) | (uint32_t)c;
+        const uint64_t packed = ((uint64_t)cost_key32(a, J.cost_mode == 3u ? ps.recsub_muls : mu_, J.cost_mode) << 32) | (uint32_t)c;
         best = packed < best ? packed : best;
         PLO_WAVE_SYNC();
     }
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(256) void cse_chain_kernel(WavePlan P1, WavePlan P2
     const uint64_t stride = (uint64_t)gridDim.x * nwaves;
     for (uint64_t c = (uint64_t)blockIdx.x * nwaves + wave; c < J.ncand; c += stride) {
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull};
+        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull, 0u};
         for (uint32_t i = lane; i < tw1; i += 64u) ((uint64_t *)reg)[i] = P1.tmpl[i];
         PLO_WAVE_SYNC();
         const uint64_t r1 = P1.unit ? run_candidate<true>(P1, reg, rs1, ps, lane, J.err) : run_candidate<false>(P1, reg, rs1, ps, lane, J.err);
@@ -703,7 +710,7 @@ __global__ __launch_bounds__(256) void cse_chain_batch_kernel(const WavePlan *pl
         const uint64_t q = c / per;
         const WavePlan &P1 = plans[2u * q], &P2 = plans[2u * q + 1u];
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull};
+        PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull, 0u};
         const uint32_t tw1 = P1.tmpl_bytes >> 3, tw2 = P2.tmpl_bytes >> 3, rw1 = P1.rs_bytes >> 3, rw2 = P2.rs_bytes >> 3;
         for (uint32_t i = lane; i < rw1; i += 64u) ((uint64_t *)rs1)[i] = P1.tmpl[tw1 + i];
         for (uint32_t i = lane; i < rw2; i += 64u) ((uint64_t *)rs2)[i] = P2.tmpl[tw2 + i];

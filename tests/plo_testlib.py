@@ -350,6 +350,14 @@ class OracleMatrix:
         assert rc == 0
         return a.value, mu.value, s.value
 
+    def recsub(self):
+        """literal RecSub / RecOptimizer (plinopt_optimize.inl:889-1013): (adds, muls before ProgramGen, muls after, nodes)"""
+        a, mr, mf, nd = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        rc = oracle().plo_oracle_recsub(self.m, self.n, _arr(self.rowptr), _arr(self.col), _arr(self.val), self.p,
+                                        ctypes.byref(a), ctypes.byref(mr), ctypes.byref(mf), ctypes.byref(nd))
+        assert rc == 0
+        return a.value, mr.value, mf.value, nd.value
+
     def enum_optimizer(self, index, letters=b"otri"):
         """one schedule of RecSub's tree (-E): -> (adds, muls, radix product, text)"""
         a = ctypes.c_uint32(); mu = ctypes.c_uint32(); pr = ctypes.c_uint64(); txt = ctypes.c_void_p()

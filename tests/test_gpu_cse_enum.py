@@ -51,3 +51,25 @@ def test_enumeration_is_refused_for_hbm_plans(hip):
     with pytest.raises(capi.PloError) as e:
         plan.enum_search(0, 10)
     assert e.value.code == capi.PLO_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms", "2x2x2_7_DPS-accurate_P.sms", "2x2x2_7_DPS-accurate_R.sms"])
+def test_recsub_accounting_on_gpu_equals_literal_recsub(hip, name):
+    """PLO_COST_RECSUB: the enumeration chooses by (additions, multiplications before ProgramGen) = RecSub's own counts
+    (reference include/plinopt_optimize.inl:950-959); the minimum over the whole tree equals the literal recursive
+    restatement of the oracle."""
+    import ctypes
+    from plinopt_amd import CSEPlan, capi
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    adds, muls_r, _, _ = M.recsub()
+    plan = CSEPlan(M.m, M.n, M.rowptr, M.col, M.val, P)
+    L = capi.lib()
+    n, best = 1, None
+    while True:
+        b, st, mp = capi.Best(), capi.Stats(), ctypes.c_uint64()
+        capi.check(L.plo_cse_enum_search_plan(plan._h, 0, n, capi.COST_RECSUB, ctypes.byref(b), ctypes.byref(mp), ctypes.byref(st)))
+        best = (b.adds, b.muls)
+        if mp.value <= n:
+            break
+        n = mp.value
+    assert best == (adds, muls_r), (best, adds, muls_r, n)

@@ -475,3 +475,28 @@ def test_factorizer_reaches_the_stored_alternative_bases(name, side):
     mA, nA, Al = parse(alt_txt)
     mo, no, X = read_sms(orig)
     assert (mA, nA, mc, nc) == (mo, na, na, no) and _spmul(Al, C) == X
+
+
+# ----------------------------------------------------------------------------- -E with RecSub's own accounting
+RECSUB_TOYS = ["2x2x2_7_Winograd_L.sms", "2x2x2_7_Winograd_P.sms", "2x2x2_7_DPS-accurate_L.sms", "2x2x2_7_DPS-accurate_P.sms", "2x2x2_7_DPS-accurate_R.sms"]
+
+
+@pytest.mark.parametrize("name", RECSUB_TOYS)
+def test_exhaustive_method_with_recsub_accounting_equals_literal_recsub(name):
+    """`bin/optimizer --only E --recsub`: the schedule tree walked by index, chosen as RecSub chooses (additions, then its
+    own multiplication count: naiveOps minus the savings of the steps, plinopt_optimize.inl:950-959) gives the values of the
+    LITERAL recursive restatement in the oracle (every pair instance of every row is a child there, :936-939: the same set
+    of schedules, walked with repetitions).  The additions also equal those of the printed program (the savings
+    accounting and Optimizer's count are the same number)."""
+    from plo_testlib import OracleMatrix
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    adds, muls_r, muls_final, nodes = M.recsub()
+    rc, out, err = run([OPT, "-q", str(P), "--only", "E", "--recsub", "--gpu", "0", path])
+    assert rc == 0, err
+    mm = re.search(r"# RecSub accounting: (\d+)\|(\d+) .*program (\d+)\|(\d+)", err)
+    assert mm, err
+    assert (int(mm.group(1)), int(mm.group(2))) == (adds, muls_r), (mm.groups(), adds, muls_r)
+    assert int(mm.group(3)) == adds and "the whole tree" in err and nodes >= 3
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2
