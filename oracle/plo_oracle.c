@@ -726,3 +726,87 @@ int plo_oracle_recsub(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint
     cand_free(&C);
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * One restart of KernelOptimiser (plinopt_optimize.inl:1299-1340) with the BUILD's decomposition rule -- LinBox's pivoting
+ * (InPlaceLinearPivoting :742) is not in the reference tree, so nullspacedecomp :689-884 is restated here with the rule
+ * the product documents (plinopt_amd/csrc/host/plo_host.hpp `kernel_decomp`), by a different route than the product's
+ * (every dependent row is solved for from scratch against the basis, no running combinations):
+ *   stream of the seed: Fisher-Yates order of the rows (the reference shuffles, :705-713); greedy row basis in that order;
+ *   a dependent row d is the unique combination x_d of the basis rows; NotIndep = next() mod #dependent (:792-795) of them,
+ *   the LAST in the order, stay in the directly computed part; the others are emptied in Free and computed by Dep
+ *   (row j = x_{dep[j]} on the basis rows):   o := Free . i ;  x := Dep . o ;  o_{dep[j]} := x_j           (:836-872)
+ * then Optimizer on Free and on Dep with ONE stream restarted from the seed (plo_oracle_chain).
+ * Returns 0, -2 for a zero dimensional kernel (:883), -1 on bad input. */
+static void kd_solve(uint32_t *x, const uint32_t *Bt /* n x r, column j = basis row j */, uint32_t n, uint32_t r, const uint32_t *row, uint32_t p) {
+    /* Gauss-Jordan on [Bt | row^T]: r unknowns, n equations, consistent with a unique solution */
+    uint32_t *A = (uint32_t *)malloc((size_t)n * (r + 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; i++) { for (uint32_t j = 0; j < r; j++) A[(size_t)i * (r + 1) + j] = Bt[(size_t)i * r + j]; A[(size_t)i * (r + 1) + r] = row[i]; }
+    uint32_t *where = (uint32_t *)malloc(r * sizeof(uint32_t)); uint32_t rr = 0;
+    for (uint32_t c = 0; c < r; c++) {
+        uint32_t q = rr; while (q < n && A[(size_t)q * (r + 1) + c] == 0) q++;
+        if (q == n) abort();                                       /* the basis rows are independent */
+        for (uint32_t j = 0; j <= r; j++) { uint32_t t = A[(size_t)q * (r + 1) + j]; A[(size_t)q * (r + 1) + j] = A[(size_t)rr * (r + 1) + j]; A[(size_t)rr * (r + 1) + j] = t; }
+        const uint32_t iv = f_inv(A[(size_t)rr * (r + 1) + c], p);
+        for (uint32_t j = 0; j <= r; j++) A[(size_t)rr * (r + 1) + j] = f_mul(A[(size_t)rr * (r + 1) + j], iv, p);
+        for (uint32_t i = 0; i < n; i++) if (i != rr && A[(size_t)i * (r + 1) + c]) {
+            const uint32_t l = A[(size_t)i * (r + 1) + c];
+            for (uint32_t j = 0; j <= r; j++) A[(size_t)i * (r + 1) + j] = (uint32_t)(((uint64_t)A[(size_t)i * (r + 1) + j] + (uint64_t)f_neg(f_mul(l, A[(size_t)rr * (r + 1) + j], p), p)) % p);
+        }
+        where[c] = rr++;
+    }
+    for (uint32_t c = 0; c < r; c++) x[c] = A[(size_t)where[c] * (r + 1) + r];
+    free(A); free(where);
+}
+static uint32_t kd_rank_with(const uint32_t *rows /* k dense rows */, uint32_t k, uint32_t n, uint32_t p) { return rank_mod((uint32_t *)rows, k, n, p); }
+int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p, uint64_t seed,
+                              uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep) {
+    if (p < 2 || m == 0) return -1;
+    uint32_t rng = plo_oracle_rng_state0(seed);
+    uint32_t *ord = (uint32_t *)malloc(m * sizeof(uint32_t));
+    for (uint32_t i = 0; i < m; i++) ord[i] = i;
+    for (uint32_t i = m; i > 1; --i) { uint32_t j = plo_oracle_rng_next(&rng) % i; uint32_t t = ord[i - 1]; ord[i - 1] = ord[j]; ord[j] = t; }
+    /* greedy basis: a row joins when it raises the rank of the chosen rows (rank by elimination of a copy, as testLinComb does) */
+    uint32_t *basis = (uint32_t *)malloc(m * sizeof(uint32_t)), *deps = (uint32_t *)malloc(m * sizeof(uint32_t)); uint32_t r = 0, nd = 0;
+    uint32_t *stack = (uint32_t *)calloc((size_t)(m + 1) * n, sizeof(uint32_t)), *tmp = (uint32_t *)malloc((size_t)(m + 1) * n * sizeof(uint32_t));
+    for (uint32_t t = 0; t < m; t++) {
+        const uint32_t i = ord[t];
+        memset(stack + (size_t)r * n, 0, n * sizeof(uint32_t));
+        for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; k++) stack[(size_t)r * n + col[k]] = val[k];
+        memcpy(tmp, stack, (size_t)(r + 1) * n * sizeof(uint32_t));
+        if (kd_rank_with(tmp, r + 1, n, p) == r + 1) basis[r++] = i; else deps[nd++] = i;
+    }
+    int rc = 0;
+    if (nd == 0) rc = -2;
+    else {
+        const uint32_t ni = plo_oracle_rng_next(&rng) % nd, kept = nd - ni;
+        /* Free: M with the kept dependent rows emptied; Dep: kept x m */
+        uint32_t *rpF = (uint32_t *)calloc(m + 1, sizeof(uint32_t)), *cF = (uint32_t *)malloc((rowptr[m] + 1) * sizeof(uint32_t)), *vF = (uint32_t *)malloc((rowptr[m] + 1) * sizeof(uint32_t));
+        unsigned char *empt = (unsigned char *)calloc(m, 1);
+        for (uint32_t j = 0; j < kept; j++) empt[deps[j]] = 1;
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < m; i++) { if (!empt[i]) for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; k++) { cF[w] = col[k]; vF[w] = val[k]; w++; } rpF[i + 1] = w; }
+        uint32_t *Bt = (uint32_t *)calloc((size_t)n * (r ? r : 1), sizeof(uint32_t));
+        for (uint32_t j = 0; j < r; j++) for (uint32_t k = rowptr[basis[j]]; k < rowptr[basis[j] + 1]; k++) Bt[(size_t)col[k] * r + j] = val[k];
+        uint32_t *rpD = (uint32_t *)calloc(kept + 1, sizeof(uint32_t)), *cD = (uint32_t *)malloc(((size_t)kept * r + 1) * sizeof(uint32_t)), *vD = (uint32_t *)malloc(((size_t)kept * r + 1) * sizeof(uint32_t));
+        uint32_t *x = (uint32_t *)malloc((r ? r : 1) * sizeof(uint32_t)), *dense = (uint32_t *)malloc(n * sizeof(uint32_t)), *byrow = (uint32_t *)malloc(m * sizeof(uint32_t));
+        uint32_t wd = 0;
+        for (uint32_t j = 0; j < kept; j++) {
+            memset(dense, 0, n * sizeof(uint32_t));
+            for (uint32_t k = rowptr[deps[j]]; k < rowptr[deps[j] + 1]; k++) dense[col[k]] = val[k];
+            kd_solve(x, Bt, n, r, dense, p);
+            memset(byrow, 0, m * sizeof(uint32_t));
+            for (uint32_t b = 0; b < r; b++) byrow[basis[b]] = x[b];
+            for (uint32_t i = 0; i < m; i++) if (byrow[i]) { cD[wd] = i; vD[wd] = byrow[i]; wd++; }      /* columns ascending */
+            rpD[j + 1] = wd;
+        }
+        rc = plo_oracle_chain(m, n, rpF, cF, vF, kept, m, rpD, cD, vD, p, seed, adds, muls, NULL, NULL);
+        if (rank) *rank = r;
+        if (notindep) *notindep = ni;
+        if (ndep) *ndep = kept;
+        free(rpF); free(cF); free(vF); free(empt); free(Bt); free(rpD); free(cD); free(vD); free(x); free(dense); free(byrow);
+    }
+    free(ord); free(basis); free(deps); free(stack); free(tmp);
+    return rc;
+}

@@ -123,6 +123,13 @@ int plo_oracle_tril_search_x(uint32_t m, PLO_TRIL_ARGS(A), PLO_TRIL_ARGS(B), PLO
 int plo_oracle_recsub(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
                       uint32_t *adds, uint32_t *muls_recsub, uint32_t *muls_final, uint64_t *nodes);
 
+/* One restart of KernelOptimiser (plinopt_optimize.inl:1299-1340) with the build's decomposition rule restated independently
+ * (see plo_oracle.c): decomposition from the seed's stream, then Optimizer on Free and on Dep with one stream restarted
+ * from the seed.  (adds, muls) summed; rank, NotIndep and the number of dependent rows computed by Dep are returned for the
+ * log line.  0, or -2 for a zero dimensional kernel. */
+int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p, uint64_t seed,
+                              uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep);
+
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);
 

@@ -12,6 +12,7 @@
 // ===========================================================================
 #include "plo_host.hpp"
 #include "plo_fast.hpp"
+#include "plo_compact.hpp"
 #include "../../../include/plinopt_hip.h"
 
 #include <chrono>
@@ -497,7 +498,7 @@ template <class F> bool exhaustive_method(const F &f, const SparseMat<typename F
 
 template <class F>
 int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool tryDirect, bool tryKernel, bool tryLU,
-        bool tryAB, bool mostCSE, bool allkernels, int verbose, uint32_t q, const char *argv0)
+        bool tryAB, bool mostCSE, bool allkernels, bool kfi, int verbose, uint32_t q, const char *argv0)
 {
     auto t0 = std::chrono::steady_clock::now();
     std::clog << std::string(40, '#') << std::endl;
@@ -603,9 +604,36 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
             if (cmp_op_count(dops, nbops)) { nbops = dops; text = t; }                 // :1241-1245
         }
     }
-    if (tryKernel) {                                                                  // :1450-1462 (KFI / -F and -N variants are not built)
+    if (tryKernel && !kfi) {                                                          // :1450-1462
         try { kernel_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
         catch (const std::exception &e) { std::clog << "# -K skipped: " << e.what() << std::endl; }
+    }
+    if (tryKernel && kfi) {
+        // -F: the kernel method with the identity added to the goals (nullspacedecomp :637-685): the inputs become rows that the
+        // decomposition may put in its basis, so a dependent output can be written over inputs as well as over other outputs.
+        // The program of [M ; I] is searched as any other; its identity goals are then no outputs: the text is renamed
+        // (goals 'q'), the real outputs are copied (`o_j := q_j`, :680-681) and the rewriting engine of bin/compacter removes
+        // what only the identity goals needed (the reference does this with OpOnVars / RemoveVars, :657-663).
+        try {
+            auto Mx = lM; const size_t m = lM.rowdim();
+            for (size_t i = 0; i < lM.coldim(); ++i) { Mx.rows.emplace_back(); Mx.rows.back().emplace_back(i, f.one()); }
+            Ops kops{~(size_t)0 >> 1, 0}; std::string ktext;
+            if (kernel_method(f, Mx, seed0, loops, gpu, q, verbose, kops, ktext, argv0) && !ktext.empty()) {
+                std::istringstream in(ktext);
+                std::vector<compact::Line> Pg = compact::parse(in);
+                auto ren = [](std::string &t) { if (t.size() > 1 && t[0] == 'o' && isdigit((unsigned char)t[1])) t[0] = 'q'; };
+                for (auto &l : Pg) { ren(l.lhs); for (auto &t : l.rhs) ren(t); }
+                for (size_t j = 0; j < m; ++j) Pg.push_back(compact::Line{"o" + std::to_string(j), {"q" + std::to_string(j)}});
+                compact::compact_program(Pg, false, compact::letter_outputs('o'));
+                std::ostringstream os; compact::print(os, Pg);
+                SlpEval<F> ev(f); std::istringstream chk(os.str());
+                const Ops cops = ev.run(chk);
+                if (!same_matrix(f, ev.matrix('o', lM.rowdim(), lM.coldim()), lM)) throw std::runtime_error("the cleaned program does not compute the matrix");
+                if (verbose > 0) std::clog << "# Found K with identity goals (-F): " << cops.first << '|' << cops.second << " after cleaning (" << kops.first << '|' << kops.second
+                                           << " with the identity goals) instead of " << nbops.first << '|' << nbops.second << std::endl;
+                if (cmp_op_count(cops, nbops)) { nbops = cops; text = os.str(); }
+            }
+        } catch (const std::exception &e) { std::clog << "# -K -F skipped: " << e.what() << std::endl; }
     }
     if (tryLU) {
         try { lu_method(f, lM, seed0, loops, gpu, q, verbose, nbops, text, argv0); }
@@ -643,13 +671,14 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
 int main(int argc, char **argv)
 {
     bool printMaple = false, printPretty = false, mostCSE = false, tryKernel = false, tryLU = false, tryAB = false,
-         tryDirect = false, allkernels = false;
+         tryDirect = false, allkernels = false, kfi = false;
     int verbose = 1, gpu = 1; size_t loops = 100; uint64_t q = 0, seed0 = 0; std::string filename, only; bool replay_only = false;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
         if (a == "-h") {
             std::clog << "Usage: " << argv[0] << " [-h|-M|-P|-K|-D|-G|-E|-N|-A|-q #|-O #|--gpu #|--seed #] [stdin|matrixfile.sms]\n"
                       << "  -D/-K/-G: direct/kernel/LU methods (default is all)\n"
+                      << "  -F: kernel method with the identity added to its goals (inputs may join the row basis)\n"
                       << "  -q #: search modulo (default is Rationals, on the host)\n"
                       << "  -O #: randomized search with that many loops (default " << loops << " loops)\n"
                       << "  --gpu #: 1 = run the restart loop on the MI355X (default with -q), 0 = host only, N >= 2 = the seeds of -D in N shards, one GPU each\n"
@@ -668,7 +697,7 @@ int main(int argc, char **argv)
         else if (a == "-A") tryAB = true;
         else if (a == "-D") tryDirect = true;
         else if (a == "-K") tryKernel = true;
-        else if (a == "-F") { }
+        else if (a == "-F") kfi = true;
         else if (a == "-E") mostCSE = true;
         else if (a == "-N") allkernels = true;
         else if (a == "-q" && i + 1 < argc) q = strtoull(argv[++i], nullptr, 10);
@@ -717,9 +746,9 @@ int main(int argc, char **argv)
         }
         if (q != 0) {
             if (q < 3 || q >= (1ull << 31)) { std::cerr << "# ERROR: modulus must be an odd prime below 2^31 in this build" << std::endl; return -1; }
-            return run(ZpField((uint32_t)q), MQ, loops, seed0, gpu, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, verbose, (uint32_t)q, argv[0]);
+            return run(ZpField((uint32_t)q), MQ, loops, seed0, gpu, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, kfi, verbose, (uint32_t)q, argv[0]);
         }
-        return run(QField(), MQ, loops, seed0, 0, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, verbose, 0, argv[0]);
+        return run(QField(), MQ, loops, seed0, 0, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, kfi, verbose, 0, argv[0]);
     } catch (const std::exception &e) {
         ++g_failures, std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m" << std::endl;
         return -1;

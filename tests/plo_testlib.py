@@ -350,6 +350,17 @@ class OracleMatrix:
         assert rc == 0
         return a.value, mu.value, s.value
 
+    def kernel_restart(self, seed):
+        """one restart of the kernel method with the build's decomposition rule restated in the oracle:
+        (adds, muls, rank, notindep, dependent rows) or None for a zero dimensional kernel"""
+        a, mu, r, ni, nd = (ctypes.c_uint32() for _ in range(5))
+        rc = oracle().plo_oracle_kernel_restart(self.m, self.n, _arr(self.rowptr), _arr(self.col), _arr(self.val), self.p, ctypes.c_uint64(seed),
+                                                ctypes.byref(a), ctypes.byref(mu), ctypes.byref(r), ctypes.byref(ni), ctypes.byref(nd))
+        if rc == -2:
+            return None
+        assert rc == 0, rc
+        return a.value, mu.value, r.value, ni.value, nd.value
+
     def recsub(self):
         """literal RecSub / RecOptimizer (plinopt_optimize.inl:889-1013): (adds, muls before ProgramGen, muls after, nodes)"""
         a, mr, mf, nd = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()

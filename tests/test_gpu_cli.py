@@ -169,3 +169,32 @@ def test_all_row_orders_on_gpu_equals_host(name):
     assert out == out0
     rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2, err2
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms"])
+def test_kernel_method_on_gpu_equals_the_oracle_restatement(name):
+    """-K on the GPU (batched chained-candidate kernel, one decomposition per restart) against the ORACLE: the winner, its
+    counts and its decomposition (rank, NotIndep, dependent rows) are those of oracle/plo_oracle.c
+    `plo_oracle_kernel_restart` minimised over the same seeds."""
+    from plo_testlib import OracleMatrix
+    from test_host_tools import kernel_oracle_argmin
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    n = 300
+    (a, mu, rank, ni, nd), seed = kernel_oracle_argmin(M, 7, n)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "K", "-O", str(n), "--seed", "7", path])
+    assert rc == 0 and "# GPU (K): %d candidates on %d decompositions" % (n, n) in err, err
+    g = re.search(r"# Found K: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\+(\d+), (\d+) dependent rows\)", err)
+    assert g and tuple(int(x) for x in g.groups()) == (a, mu, seed, rank, ni, nd), (g and g.groups(), (a, mu, seed, rank, ni, nd))
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "2x2x2_7_DPS-accurate_L.sms", "4x4x4_48_rational_L.sms"])
+def test_kernel_method_with_identity_goals_on_gpu(name):
+    """-K -F: the restarts on [M ; I] run on the GPU like -K; same result as the host loop, program verifies."""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "K", "-F", "-O", "1000", path])
+    assert rc == 0 and "# GPU (K): 1000 candidates" in err, err
+    rc0, out0, err0 = run([OPT, "-q", str(P), "--only", "K", "-F", "-O", "1000", "--gpu", "0", path])
+    assert rc0 == 0 and out == out0
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2

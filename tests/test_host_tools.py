@@ -500,3 +500,56 @@ def test_exhaustive_method_with_recsub_accounting_equals_literal_recsub(name):
     assert int(mm.group(3)) == adds and "the whole tree" in err and nodes >= 3
     rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2
+
+
+# ----------------------------------------------------------------------------- -K against the oracle's restatement
+def kernel_oracle_argmin(M, seed0, n):
+    """best restart of the kernel method under (cmpOpCount, seed), from oracle/plo_oracle.c `plo_oracle_kernel_restart`"""
+    best = None
+    for s in range(seed0, seed0 + n):
+        r = M.kernel_restart(s)
+        assert r is not None
+        key = (r[0] + r[1], r[0], s)
+        if best is None or key < best[0]:
+            best = (key, r, s)
+    return best[1], best[2]
+
+
+def test_oracle_reports_a_zero_dimensional_kernel():
+    from plo_testlib import OracleMatrix
+    assert OracleMatrix.from_sms(os.path.join(DATA, "2x2x2_7_DPS-accurate_P.sms"), P).kernel_restart(3) is None      # 4 x 7, full row rank (:883)
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms"])
+def test_kernel_method_equals_the_oracle_restatement(name):
+    """`bin/optimizer --only K` (one decomposition per restart, as the reference :1299-1340): winner, counts, rank, NotIndep
+    and number of dependent rows are those of the oracle's independent restatement of the decomposition rule followed by
+    the oracle's chained Optimizer (not a comparison of the product with itself)."""
+    from plo_testlib import OracleMatrix
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    n = 120
+    (a, mu, rank, ni, nd), seed = kernel_oracle_argmin(M, 40, n)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "K", "-O", str(n), "--seed", "40", "--gpu", "0", path])
+    assert rc == 0, err
+    g = re.search(r"# Found K: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\+(\d+), (\d+) dependent rows\)", err)
+    assert g and tuple(int(x) for x in g.groups()) == (a, mu, seed, rank, ni, nd), (g and g.groups(), (a, mu, seed, rank, ni, nd))
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_Winograd_L.sms", "4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "2x2x2_7_DPS-accurate_L.sms", "cyclic.sms"])
+@pytest.mark.parametrize("field", ["Q", "p"])
+def test_kernel_method_with_identity_goals(name, field):
+    """-K -F (KFI, reference include/plinopt_optimize.inl:637-685): the kernel method on [M ; I]; the printed program (identity
+    goals removed, outputs copied from the goals) computes M with exactly the reported operation count.  cyclic.sms is
+    square and invertible: every row of [M ; I] beyond the basis is dependent, the method still runs."""
+    path = os.path.join(DATA, name)
+    q = ["-q", str(P), "--gpu", "0"] if field == "p" else []
+    rc, out, err = run([OPT, "--only", "K", "-F", "-O", "200"] + q + [path])
+    assert rc == 0, err
+    mm = re.search(r"# Found K with identity goals \(-F\): (\d+)\|(\d+) after cleaning", err)
+    assert mm, err
+    rc, _, err2 = run([CHK] + (["-q", str(P)] if field == "p" else []) + ["-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+    got = re.search(r": (\d+),(\d+) Matrix-Vector", err2)
+    fin = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
+    assert fin and int(got.group(1)) == int(fin.group(1))
