@@ -38,3 +38,13 @@ def test_bench_under_torch_distributed_run_one_rank(hip):
     d = one_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                   "--master-port", "29541", "bench.py", "--gpus", "1", "--workload", "4x4x4_L", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("workload", ["tril", "cob"])
+def test_tril_and_cob_run_under_torch_distributed_run(hip, workload):
+    """the N > 1 launch line of the driver with one rank: seed shards / enumeration shards + the 8-byte all-reduce"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    d = one_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                  "--master-port", "29543", "bench.py", "--gpus", "1", "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["scaling"] == "weak" and ROOF <= set(d["roofline"])
+    assert d["roofline"]["bound"] == "issue" and 0 < d["roofline"]["frac"] <= 1 and "roofline_hbm" in d
