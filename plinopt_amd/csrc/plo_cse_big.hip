@@ -214,40 +214,138 @@ __device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint3
     }
     return 0u;
 }
-// the same for two keys at once: both probe sequences and then both atomics are in flight together (two memory round
-// trips for the pair instead of four); o1/o2 = the frequencies before, 0 = key not found
+// A probe ROUND looks at PLO_GWIN consecutive slots at once (their loads are in flight together): a wave leaves a probe
+// loop only when its slowest lane does, and with one slot per round that lane needed 5-8 dependent memory round trips.
+#ifndef PLO_GWIN
+#define PLO_GWIN 2u
+#endif
+#ifndef PLO_FLU
+#define PLO_FLU 2u       /* aggregated entries per thread and trip of the flush */
+#endif
+// frequency[key] -= d for two keys at once: both probe sequences and then both atomics are in flight together;
+// o1/o2 = the frequencies before, 0 = key not found
 __device__ __forceinline__ void gtab_subn2(uint64_t *tab, uint64_t k1, uint64_t k2, uint32_t d, uint32_t hbits, uint32_t &o1, uint32_t &o2) {
     const uint32_t mask = (1u << hbits) - 1u;
     uint32_t s1 = ghash(k1, hbits), s2 = ghash(k2, hbits);
-    uint64_t v1 = gload64(&tab[s1]), v2 = gload64(&tab[s2]);
     bool p1 = true, p2 = true, m1 = false, m2 = false;
-    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
-        if (p1) { if ((v1 >> PLO_GVB) == k1) { m1 = true; p1 = false; } else if (v1 == PLO_GEMPTY) p1 = false; else s1 = (s1 + 1u) & mask; }
-        if (p2) { if ((v2 >> PLO_GVB) == k2) { m2 = true; p2 = false; } else if (v2 == PLO_GEMPTY) p2 = false; else s2 = (s2 + 1u) & mask; }
-        if (!p1 && !p2) break;
-        if (p1) v1 = gload64(&tab[s1]);
-        if (p2) v2 = gload64(&tab[s2]);
+    for (uint32_t pr = 0; pr < (1u << 22) && (p1 || p2); pr += PLO_GWIN) {
+        uint64_t v1[PLO_GWIN], v2[PLO_GWIN];
+#pragma unroll
+        for (uint32_t j = 0; j < PLO_GWIN; ++j) { v1[j] = gload64(&tab[(s1 + j) & mask]); v2[j] = gload64(&tab[(s2 + j) & mask]); }
+        if (p1) {
+            uint32_t adv = PLO_GWIN;
+#pragma unroll
+            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p1) { if ((v1[j] >> PLO_GVB) == k1) { m1 = true; p1 = false; adv = j; } else if (v1[j] == PLO_GEMPTY) { p1 = false; adv = j; } }
+            s1 = (s1 + adv) & mask;
+        }
+        if (p2) {
+            uint32_t adv = PLO_GWIN;
+#pragma unroll
+            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p2) { if ((v2[j] >> PLO_GVB) == k2) { m2 = true; p2 = false; adv = j; } else if (v2[j] == PLO_GEMPTY) { p2 = false; adv = j; } }
+            s2 = (s2 + adv) & mask;
+        }
     }
     uint64_t a1 = 0, a2 = 0;
     if (m1) a1 = wg_add((unsigned long long *)&tab[s1], (unsigned long long)(0ull - (uint64_t)d));
     if (m2) a2 = wg_add((unsigned long long *)&tab[s2], (unsigned long long)(0ull - (uint64_t)d));
     o1 = m1 ? (uint32_t)(a1 & PLO_GVMASK) : 0u; o2 = m2 ? (uint32_t)(a2 & PLO_GVMASK) : 0u;
 }
-// frequency[key] += d (claims an empty or dead slot); returns the frequency before, 0xFFFFFFFF = table full
+// frequency[key] += d (claims the first empty or dead slot in probe order); returns the frequency before, 0xFFFFFFFF = table full
 __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint32_t d, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
     uint32_t s = ghash(key, hbits);
-    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
-        uint64_t v = gload64(&tab[s]);
-        if ((v >> PLO_GVB) == key) { uint64_t old = wg_add((unsigned long long *)&tab[s], (unsigned long long)d); return (uint32_t)(old & PLO_GVMASK); }
-        if ((v & PLO_GVMASK) == 0ull) {
-            uint64_t old = wg_cas((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | d));
-            if (old == v) return 0u;
-            continue;
+    for (uint32_t pr = 0; pr < (1u << 22); pr += PLO_GWIN) {
+        uint64_t v[PLO_GWIN];
+#pragma unroll
+        for (uint32_t j = 0; j < PLO_GWIN; ++j) v[j] = gload64(&tab[(s + j) & mask]);
+        uint32_t adv = PLO_GWIN; bool live = true;
+#pragma unroll
+        for (uint32_t j = 0; j < PLO_GWIN; ++j) {
+            if (!live) continue;
+            const uint32_t t = (s + j) & mask;
+            if ((v[j] >> PLO_GVB) == key) { uint64_t old = wg_add((unsigned long long *)&tab[t], (unsigned long long)d); return (uint32_t)(old & PLO_GVMASK); }
+            if ((v[j] & PLO_GVMASK) == 0ull) {
+                uint64_t old = wg_cas((unsigned long long *)&tab[t], (unsigned long long)v[j], (unsigned long long)((key << PLO_GVB) | d));
+                if (old == v[j]) return 0u;
+                adv = j; live = false;                           // somebody took it: look again from this slot
+            }
         }
-        s = (s + 1u) & mask;
+        s = (s + adv) & mask;
     }
     return 0xFFFFFFFFu;
+}
+
+// N keys of one thread in lock step (the flush takes several aggregated entries per trip: the table is far larger than
+// the caches, every probe is a memory round trip, and only independent ones overlap).  live[q] = false: key q is skipped.
+template <int N> __device__ __forceinline__ void gtab_subnN(uint64_t *tab, const uint64_t (&key)[N], const uint32_t (&d)[N], const bool (&live)[N], uint32_t hbits, uint32_t (&o)[N]) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s[N]; bool pend[N], hit[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) { s[q] = ghash(key[q], hbits); pend[q] = live[q]; hit[q] = false; }
+    for (uint32_t pr = 0; pr < (1u << 22); pr += PLO_GWIN) {
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < N; ++q) any |= pend[q];
+        if (!any) break;
+        uint64_t v[N][PLO_GWIN];
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+#pragma unroll
+            for (uint32_t j = 0; j < PLO_GWIN; ++j) v[q][j] = pend[q] ? gload64(&tab[(s[q] + j) & mask]) : 0ull;
+#pragma unroll
+        for (int q = 0; q < N; ++q) if (pend[q]) {
+            uint32_t adv = PLO_GWIN;
+#pragma unroll
+            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (pend[q]) { if ((v[q][j] >> PLO_GVB) == key[q]) { hit[q] = true; pend[q] = false; adv = j; } else if (v[q][j] == PLO_GEMPTY) { pend[q] = false; adv = j; } }
+            s[q] = (s[q] + adv) & mask;
+        }
+    }
+    uint64_t old[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) old[q] = hit[q] ? wg_add((unsigned long long *)&tab[s[q]], (unsigned long long)(0ull - (uint64_t)d[q])) : 0ull;
+#pragma unroll
+    for (int q = 0; q < N; ++q) o[q] = (uint32_t)(old[q] & PLO_GVMASK);
+}
+template <int N> __device__ __forceinline__ void gtab_addnN(uint64_t *tab, const uint64_t (&key)[N], const uint32_t (&d)[N], const bool (&live)[N], uint32_t hbits, uint32_t (&o)[N]) {
+    const uint32_t mask = (1u << hbits) - 1u;
+    uint32_t s[N]; bool pend[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) { s[q] = ghash(key[q], hbits); pend[q] = live[q]; o[q] = 0xFFFFFFFFu; }
+    for (uint32_t pr = 0; pr < (1u << 22); pr += PLO_GWIN) {
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < N; ++q) any |= pend[q];
+        if (!any) break;
+        uint64_t v[N][PLO_GWIN];
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+#pragma unroll
+            for (uint32_t j = 0; j < PLO_GWIN; ++j) v[q][j] = pend[q] ? gload64(&tab[(s[q] + j) & mask]) : 0ull;
+        // where every key goes: its own slot (add), the first empty or dead slot of the window (claim), or on
+        uint32_t t[N], at[N]; uint64_t ex[N], res[N];                     // at: 0 move on, 1 add, 2 claim
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            at[q] = 0; t[q] = 0; ex[q] = 0; res[q] = 0;
+            if (pend[q]) {
+#pragma unroll
+                for (uint32_t j = 0; j < PLO_GWIN; ++j) if (at[q] == 0u) {
+                    if ((v[q][j] >> PLO_GVB) == key[q]) { at[q] = 1u; t[q] = (s[q] + j) & mask; }
+                    else if ((v[q][j] & PLO_GVMASK) == 0ull) { at[q] = 2u; t[q] = (s[q] + j) & mask; ex[q] = v[q][j]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            if (at[q] == 1u) res[q] = wg_add((unsigned long long *)&tab[t[q]], (unsigned long long)d[q]);
+            else if (at[q] == 2u) res[q] = wg_cas((unsigned long long *)&tab[t[q]], (unsigned long long)ex[q], (unsigned long long)((key[q] << PLO_GVB) | d[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) if (pend[q]) {
+            if (at[q] == 1u) { o[q] = (uint32_t)(res[q] & PLO_GVMASK); pend[q] = false; }
+            else if (at[q] == 2u) { if (res[q] == ex[q]) { o[q] = 0u; pend[q] = false; } else s[q] = t[q]; }   // somebody took it: look again from this slot
+            else s[q] = (s[q] + PLO_GWIN) & mask;
+        }
+    }
 }
 
 // LDS aggregation table: the rows rewritten by one CSE step retire / create the same triples many times
@@ -255,6 +353,7 @@ __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint3
 // key48<<16 | count16, open addressing, at most 16 probes; `false` = no room, the caller goes to HBM directly.
 #define PLO_AGG_PROBES 16u
 #ifdef PLO_BIG_PROFILE
+__device__ unsigned long long g_prof2[40];     // phase clocks (100 MHz ticks) by step size class [4][8], summed over candidates; [32] candidates
 __device__ unsigned long long g_prof[16];      // thread 0 of every workgroup, sweep 1: cycles per stage (racy sums; profile only)
 #define PROF_T(k_) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t__ = clock64(); if (tid == 0) g_prof[k_] += t__ - tp; tp = t__; } while (0)
 #else
@@ -353,14 +452,19 @@ struct BigShared {
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
 #ifdef PLO_BIG_PROFILE
     unsigned long long tb1[4], tb2[4]; uint32_t nb[4], fb1, fb2, fl1, fl2;   // sweep clocks by step size class, fallbacks, flushed keys
-    unsigned long long pw[8];      // sweep of the big steps, summed over waves: cycles waiting for the chunk + stores, aggregation, loop overhead; trips; wave time; waves
+    unsigned long long tpc[4][8];  // phase clocks by step size class
+    unsigned long long pw[16];      // sweep of the big steps, summed over waves: cycles waiting for the chunk + stores, aggregation, loop overhead; trips; wave time; waves
 #endif
     uint32_t part[8];
     uint64_t sel[PLO_BIG_SELCAP];
 };
 
 #define BSYNC() __syncthreads()
+#ifdef PLO_BIG_PROFILE
+#define PLO_STAMP(q_) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); sh.tph[q_] += t_ - tstamp; sh.tpc[sh.M >= 256u ? 0 : sh.M >= 64u ? 1 : sh.M >= 16u ? 2 : 3][q_] += t_ - tstamp; tstamp = t_; } } while (0)
+#else
 #define PLO_STAMP(q_) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); sh.tph[q_] += t_ - tstamp; tstamp = t_; } } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
@@ -412,7 +516,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         sh.M = P.M0; sh.theta = P.M0 + 1u; sh.ncols = n; sh.nbadd = 0; sh.nbmul = 0; sh.nmult = 0; sh.dmcount = 0; sh.hlcount = 0;
         for (int q = 0; q < 8; ++q) sh.tph[q] = 0;
 #ifdef PLO_BIG_PROFILE
-        for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0; for (int q = 0; q < 8; ++q) sh.pw[q] = 0;
+        for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0; for (int q = 0; q < 16; ++q) sh.pw[q] = 0; for (int c_ = 0; c_ < 4; ++c_) for (int q = 0; q < 8; ++q) sh.tpc[c_][q] = 0;
 #endif
         sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0; sh.nbisect = 0; sh.spilltot = 0; sh.listover = 0;
     }
@@ -570,31 +674,55 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             if (a < n) { la = P.trows + P.tptr[a]; na = P.tptr[a + 1] - P.tptr[a]; } else { la = ncr + ncrptr[a - n]; na = ncrptr[a - n + 1] - ncrptr[a - n]; }
             if (b < n) { lb = P.trows + P.tptr[b]; nb = P.tptr[b + 1] - P.tptr[b]; } else { lb = ncr + ncrptr[b - n]; nb = ncrptr[b - n + 1] - ncrptr[b - n]; }
             const uint32_t *lst = na <= nb ? la : lb; const uint32_t ln = na <= nb ? na : nb;
-            for (uint32_t k = tid; k < ln; k += nth) {
-                const uint32_t i = lst[k], base = P.rs[i], L = len[i];
-                const int pa = row_find(ent, base, L, a);
-                if (pa < 0) continue;
-                const int pb = row_find(ent, base, L, b);
-                if (pb < 0) continue;
-                const uint32_t ea = ent[base + pa], eb = ent[base + pb];
+            // Two rows per thread and trip, both columns of both rows searched in lock step: the four binary searches have
+            // their loads in flight together (8 dependent memory round trips for two rows instead of 36).  A search keeps
+            // the last entry it saw at its upper bound: when it ends that is the entry at the found position.
+            auto emit = [&](uint32_t i, uint32_t base, uint32_t L, uint32_t pa, uint32_t pb, uint32_t ea, uint32_t eb) {
                 uint32_t inv_r;
                 if constexpr (MODE == 2) {
-                    if (rval[rtid[PLO_EVI(eb) * nv + PLO_EVI(ea)]] != r) continue;
+                    if (rval[rtid[PLO_EVI(eb) * nv + PLO_EVI(ea)]] != r) return;
                     inv_r = rval[rtid[PLO_EVI(ea) * nv + PLO_EVI(eb)]];
                 } else {
                     const uint2 A = VT(PLO_EVI(ea)), B = VT(PLO_EVI(eb));
-                    if (B.x != bmul(r, A.x, p, mu, mers)) continue;
+                    if (B.x != bmul(r, A.x, p, mu, mers)) return;
                     inv_r = bmul(A.x, B.y, p, mu, mers);
                 }
                 const uint32_t idx = wg_add(&sh.naff, 1u);
+#ifdef PLO_BIG_PROFILE
+                atomicAdd(&sh.tb2[1], 100ull * L);
+#endif
                 uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each), row start and length; the two packed entries
-                *(uint4 *)rec = make_uint4(i, (uint32_t)pa | ((uint32_t)pb << 16), base, L);
+                *(uint4 *)rec = make_uint4(i, pa | (pb << 16), base, L);
                 *(uint2 *)(rec + 4) = make_uint2(ea, eb);
                 if (idx == 0) sh.invr = inv_r;                                   // 1/r
                 len[i] = L - 1u;                                               // the sweep works from the record
                 if (PLO_EUNIT(ea)) wg_sub(&ucount[a], 1u);                     // :70-77 counts, kept incrementally
                 if (PLO_EUNIT(eb)) wg_sub(&ucount[b], 1u);
                 if (PLO_EUNIT(swap ? eb : ea)) wg_add(&ucount[lm], 1u);
+            };
+#ifdef PLO_BIG_PROFILE
+            if (tid == 0) { sh.tb2[0] += 100ull * ln; sh.tb2[2] += 100ull * (na <= nb ? nb : na); }
+#endif
+            for (uint32_t k = tid; k < ln; k += 2u * nth) {
+                const bool two = k + nth < ln;
+                const uint32_t i0 = lst[k], i1 = two ? lst[k + nth] : i0;
+                const uint32_t bs0 = P.rs[i0], bs1 = P.rs[i1], L0 = len[i0], L1 = two ? len[i1] : 0u;
+                uint32_t lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {L0, L0, L1, L1}, ev[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                for (;;) {
+                    uint32_t v[4], mid[4]; bool any = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        mid[q] = (lo[q] + hi[q]) >> 1; const bool go = lo[q] < hi[q]; any |= go;
+                        v[q] = go ? ent[(q < 2 ? bs0 : bs1) + mid[q]] : 0u;
+                    }
+                    if (!any) break;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (lo[q] < hi[q]) { if (PLO_ECOL(v[q]) < ((q & 1) ? b : a)) lo[q] = mid[q] + 1u; else { hi[q] = mid[q]; ev[q] = v[q]; } }
+                }
+                // (an upper bound that never moved is the row length: ev stays all ones, whose column field matches no column)
+                if (PLO_ECOL(ev[0]) == a && PLO_ECOL(ev[1]) == b && lo[0] < L0 && lo[1] < L0) emit(i0, bs0, L0, lo[0], lo[1], ev[0], ev[1]);
+                if (two && PLO_ECOL(ev[2]) == a && PLO_ECOL(ev[3]) == b && lo[2] < L1 && lo[3] < L1) emit(i1, bs1, L1, lo[2], lo[3], ev[2], ev[3]);
             }
         }
         PLO_BIG_FENCE(); BSYNC();
@@ -849,34 +977,62 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             };
             if (tid == 0) retired(key, M, gtab_subn(tab, key, M, hbits));
             const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
-            for (uint32_t e = tid; e < nslot; e += nth) {
-                const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
-                uint32_t c, x, y = 0, d;
-                if constexpr (MODE == 2) {
-                    const uint32_t kq = aggk[s];
-                    if (kq == 0xFFFFFFFFu) continue;
-                    d = aggc16[s]; c = kq >> PLO_RIDB;
-                    const uint32_t xid = kq & ((1u << PLO_RIDB) - 1u);
-                    x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid];
-                } else {
-                    const uint64_t v = agg[s];
-                    if (v == AEMPTY) continue;
-                    uint64_t k = v >> acb; d = (uint32_t)(v & ((1ull << acb) - 1ull));
-                    if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
-                    c = (uint32_t)(k >> rb); x = (uint32_t)(k & ((1ull << rb) - 1ull));
-                    if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
+            // PLO_FLU entries per thread and trip: their 2 PLO_FLU probe sequences and atomics overlap
+#ifdef PLO_BIG_PROFILE
+            unsigned long long fq0 = 0, fq1 = 0, fq2 = 0, fqn = 0; const unsigned long long fts = clock64();
+#endif
+            for (uint32_t e0 = tid; e0 < nslot; e0 += PLO_FLU * nth) {
+#ifdef PLO_BIG_PROFILE
+                const unsigned long long ft0 = clock64();
+#endif
+                uint64_t kk[2 * PLO_FLU]; uint32_t dd[2 * PLO_FLU], oo[2 * PLO_FLU]; bool lv[2 * PLO_FLU];
+                uint32_t cs[PLO_FLU], ss[PLO_FLU], ins[PLO_FLU];
+#pragma unroll
+                for (int u = 0; u < (int)PLO_FLU; ++u) {
+                    const uint32_t e = e0 + (uint32_t)u * nth; bool ok = e < nslot;
+                    const uint32_t s = ok ? (nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e) : 0u;
+                    uint32_t c = 0, x = 0, y = 0, d = 0;
+                    if constexpr (MODE == 2) {
+                        const uint32_t kq = ok ? aggk[s] : 0xFFFFFFFFu;
+                        ok = kq != 0xFFFFFFFFu;
+                        if (ok) { d = aggc16[s]; c = kq >> PLO_RIDB; const uint32_t xid = kq & ((1u << PLO_RIDB) - 1u); x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid]; }
+                    } else {
+                        const uint64_t v = ok ? agg[s] : AEMPTY;
+                        ok = v != AEMPTY;
+                        if (ok) {
+                            uint64_t k = v >> acb; d = (uint32_t)(v & ((1ull << acb) - 1ull));
+                            if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
+                            c = (uint32_t)(k >> rb); x = (uint32_t)(k & ((1ull << rb) - 1ull));
+                            if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
+                        }
+                    }
+                    const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
+                    const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
+                    kk[2 * u] = c < a ? BKEY(c, a, x) : BKEY(a, c, x); kk[2 * u + 1] = c < b ? BKEY(c, b, x2) : BKEY(b, c, x2);
+                    dd[2 * u] = dd[2 * u + 1] = d; lv[2 * u] = lv[2 * u + 1] = ok; cs[u] = c; ss[u] = s; ins[u] = l0 == a ? y : ry;
+#ifdef PLO_BIG_PROFILE
+                    if (ok) wg_add(&sh.fl1, 1u);
+#endif
                 }
 #ifdef PLO_BIG_PROFILE
-                wg_add(&sh.fl1, 1u);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ft1 = clock64();
 #endif
-                const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
-                const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
-                const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x), k2 = c < b ? BKEY(c, b, x2) : BKEY(b, c, x2);
-                uint32_t o1, o2;
-                gtab_subn2(tab, k1, k2, d, hbits, o1, o2);
-                retired(k1, d, o1); retired(k2, d, o2);
-                if constexpr (MODE != 2) agg[s] = (((((uint64_t)c) << rb) | (l0 == a ? y : ry)) << PLO_GVB) | d;    // (c, coeff / v_c), same count (mode 2: the second pass derives it again)
+                gtab_subnN<2 * PLO_FLU>(tab, kk, dd, lv, hbits, oo);
+#ifdef PLO_BIG_PROFILE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ft2 = clock64();
+#endif
+#pragma unroll
+                for (int u = 0; u < (int)PLO_FLU; ++u) if (lv[2 * u]) {
+                    retired(kk[2 * u], dd[2 * u], oo[2 * u]); retired(kk[2 * u + 1], dd[2 * u], oo[2 * u + 1]);
+                    if constexpr (MODE != 2) agg[ss[u]] = (((((uint64_t)cs[u]) << rb) | ins[u]) << PLO_GVB) | dd[2 * u];    // (c, coeff / v_c), same count (mode 2: the second pass derives it again)
+                }
+#ifdef PLO_BIG_PROFILE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); { const unsigned long long ft3 = clock64(); fq0 += ft1 - ft0; fq1 += ft2 - ft1; fq2 += ft3 - ft2; ++fqn; }
+#endif
             }
+#ifdef PLO_BIG_PROFILE
+            if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[8], fq0); atomicAdd(&sh.pw[9], fq1); atomicAdd(&sh.pw[10], fq2); atomicAdd(&sh.pw[11], fqn); atomicAdd(&sh.pw[12], clock64() - fts); atomicAdd(&sh.pw[13], 1ull); }
+#endif
         }
         PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(4);
@@ -896,29 +1052,42 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 }
             };
             const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
-            for (uint32_t e = tid; e < nslot; e += nth) {
-                const uint32_t s = nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e;
-                uint64_t k; uint32_t d;
-                if constexpr (MODE == 2) {
-                    const uint32_t kq = aggk[s];
-                    if (kq == 0xFFFFFFFFu) continue;
-                    d = aggc16[s]; aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0;
-                    const uint32_t c = kq >> PLO_RIDB, xid = kq & ((1u << PLO_RIDB) - 1u), y = rval[c > a ? (uint32_t)invid[xid] : xid];
-                    k = BKEY(c, lm, l0 == a ? y : bmul(r, y, p, mu, mers));
-                } else {
-                    const uint64_t v = agg[s];
-                    if (v == AEMPTY) continue;                             // (an entry rewritten by the first pass has a count below 2^acb in its low 16 bits: never this pattern)
-                    agg[s] = AEMPTY;
-                    const uint64_t kc = v >> PLO_GVB; d = (uint32_t)(v & PLO_GVMASK);
-                    k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
-                }
-                if (d < 2u && P.prune) continue;                           // seen once in its only step: frequency 1 for ever, never chosen, not kept
-                const uint32_t o = gtab_addn(tab, k, d, hbits);
+            for (uint32_t e0 = tid; e0 < nslot; e0 += PLO_FLU * nth) {
+                uint64_t kk[PLO_FLU]; uint32_t dd[PLO_FLU], oo[PLO_FLU]; bool lv[PLO_FLU];
+#pragma unroll
+                for (int u = 0; u < (int)PLO_FLU; ++u) {
+                    const uint32_t e = e0 + (uint32_t)u * nth; bool ok = e < nslot;
+                    const uint32_t s = ok ? (nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e) : 0u;
+                    uint64_t k = 0; uint32_t d = 0;
+                    if constexpr (MODE == 2) {
+                        const uint32_t kq = ok ? aggk[s] : 0xFFFFFFFFu;
+                        ok = kq != 0xFFFFFFFFu;
+                        if (ok) {
+                            d = aggc16[s]; aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0;
+                            const uint32_t c = kq >> PLO_RIDB, xid = kq & ((1u << PLO_RIDB) - 1u), y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                            k = BKEY(c, lm, l0 == a ? y : bmul(r, y, p, mu, mers));
+                        }
+                    } else {
+                        const uint64_t v = ok ? agg[s] : AEMPTY;
+                        ok = v != AEMPTY;                                    // (an entry rewritten by the first pass has a count below 2^acb in its low 16 bits: never this pattern)
+                        if (ok) {
+                            agg[s] = AEMPTY;
+                            const uint64_t kc = v >> PLO_GVB; d = (uint32_t)(v & PLO_GVMASK);
+                            k = BKEY((uint32_t)(kc >> rb), lm, (uint32_t)(kc & ((1ull << rb) - 1ull)));
+                        }
+                    }
+                    if (d < 2u && P.prune) ok = false;                       // seen once in its only step: frequency 1 for ever, never chosen, not kept
+                    kk[u] = k; dd[u] = d; lv[u] = ok;
 #ifdef PLO_BIG_PROFILE
-                wg_add(&sh.fl2, 1u);
+                    if (ok) wg_add(&sh.fl2, 1u);
 #endif
-                if (o == 0xFFFFFFFFu) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
-                inserted(k, o, d);
+                }
+                gtab_addnN<PLO_FLU>(tab, kk, dd, lv, hbits, oo);
+#pragma unroll
+                for (int u = 0; u < (int)PLO_FLU; ++u) if (lv[u]) {
+                    if (oo[u] == 0xFFFFFFFFu) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
+                    inserted(kk[u], oo[u], dd[u]);
+                }
             }
             const uint32_t nsp = sh.nspill < spillcap ? sh.nspill : spillcap;      // entries that found no room in the LDS table
             for (uint32_t e = tid; e < nsp; e += nth) {
@@ -1258,7 +1427,9 @@ template <int MODE> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_bi
 #ifdef PLO_BIG_PROFILE
                 for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }
                 J.stats[28] = sh.fb1; J.stats[29] = sh.fb2; J.stats[30] = sh.fl1; J.stats[31] = sh.fl2;
-                for (int q = 0; q < 6; ++q) atomicAdd(&g_prof[q], sh.pw[q]);
+                for (int q = 0; q < 16; ++q) atomicAdd(&g_prof[q], sh.pw[q]);
+                for (int c_ = 0; c_ < 4; ++c_) for (int q = 0; q < 8; ++q) atomicAdd(&g_prof2[c_ * 8 + q], sh.tpc[c_][q]);
+                atomicAdd(&g_prof2[32], 1ull);
 #endif
             }   // phase times in us
             // 64-bit cost word: the op-counts of config 5 do not fit 16 bits
