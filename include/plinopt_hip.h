@@ -129,6 +129,18 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
                         int cost_mode, uint32_t *adds, uint32_t *muls, plo_best_t *best, plo_stats_t *stats);
 
 
+/* The kernel method of bin/optimizer -K with EVERYTHING on the device (plo::kmethod_kernel): restart c (seed seed0 + c) is one
+ * pass of the loop of KernelOptimiser, include/plinopt_optimize.inl:1299-1340 -- a nullspace decomposition of M
+ * (nullspacedecomp :689-884: random row order, greedy row basis, NotIndep; this build's rule, restated in
+ * oracle/plo_oracle.c plo_oracle_kernel_restart), then Optimizer() on Free and on Dep from one random stream (:1322-1333).
+ * per_block > 1: the restarts of a block of per_block consecutive seeds share the decomposition of the block's first seed.
+ * adds/muls (nrestarts entries), info (3 per restart: rank, NotIndep, number of dependent rows computed through Dep) and best may each be NULL.
+ * M needs at most 64 rows and 64 columns and a kernel of positive dimension (PLO_E_UNSUPPORTED otherwise: the caller
+ * falls back to host decompositions + plo_cse_chain_batch). */
+int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t nrestarts, uint32_t per_block, int cost_mode,
+                      uint32_t *adds, uint32_t *muls, uint32_t *info, plo_best_t *best, plo_stats_t *stats);
+
+
 /* Change-of-basis (CoB) search of bin/sparsifier: one (block,row) enumeration of `localSparsifier`,
  * include/plinopt_sparsify.inl:282-314, i.e. |coeffs|^4 calls of `testLinComb` (:167-197).  TM is the n x m
  * matrix being sparsified (dense, row major, residues mod p), Cand the n x n matrix whose rows 0..row-1 are the

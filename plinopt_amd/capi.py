@@ -20,7 +20,7 @@ EXPORTS = [
     "plo_cse_plan_create", "plo_cse_plan_create_ex", "plo_cse_plan_is_hbm", "plo_cse_plan_hbm_counters", "plo_cse_plan_destroy",
     "plo_cse_search_plan", "plo_cse_search",
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
-    "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch",
+    "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch", "plo_kernel_search",
     "plo_cse_enum_cost_many_plan", "plo_cse_enum_search_plan",
     "plo_cob_search", "plo_cob_search_range",
     "plo_tril_plan_create", "plo_tril_plan_create_x", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
@@ -109,6 +109,8 @@ def lib():
                                               ctypes.POINTER(Stats)]
         L.plo_cse_chain_batch.argtypes = [ctypes.c_uint32, ctypes.POINTER(CSR), ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32,
                                           ctypes.c_int, u32p, u32p, ctypes.POINTER(Best), ctypes.POINTER(Stats)]
+        L.plo_kernel_search.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                        u32p, u32p, u32p, ctypes.POINTER(Best), ctypes.POINTER(Stats)]
         L.plo_cob_search.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
                                      ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.POINTER(CobBest), ctypes.POINTER(Stats)]

@@ -44,6 +44,7 @@ struct HipLib {
     decltype(&plo_cse_plan_destroy) plan_destroy = nullptr;
     decltype(&plo_cse_enum_search_plan) enum_search = nullptr;
     decltype(&plo_cse_chain_batch) chain_batch = nullptr;
+    decltype(&plo_kernel_search) kernel_search = nullptr;   // optional: -K with the decompositions on the device
     bool load(const char *argv0) {
         std::vector<std::string> cand;
         if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
@@ -60,6 +61,7 @@ struct HipLib {
         plan_create = (decltype(plan_create))dlsym(h, "plo_cse_plan_create"); plan_destroy = (decltype(plan_destroy))dlsym(h, "plo_cse_plan_destroy");
         enum_search = (decltype(enum_search))dlsym(h, "plo_cse_enum_search_plan");
         chain_batch = (decltype(chain_batch))dlsym(h, "plo_cse_chain_batch");
+        kernel_search = (decltype(kernel_search))dlsym(h, "plo_kernel_search");
         return init && last_error && cse_search && shutdown && chain_create && chain_search && chain_destroy && plan_create && plan_destroy && enum_search && chain_batch;
     }
 };
@@ -233,6 +235,7 @@ template <class F> std::string kernel_text(const F &f, const KernelDecomp<F> &kd
 // seeds: block d uses the decomposition drawn from its first seed, and every seed of the block is one run of the two
 // Optimizer calls on it (the reference draws a new decomposition for every restart; with a per-restart elimination on
 // the host the GPU would idle).  Returns false when the method could not run.
+bool g_host_decomp = false;        // --host-decomp: -K eliminates on the host and ships the images (plo_cse_chain_batch)
 uint64_t g_kernel_block = 1;      // restarts per decomposition (--kernel-block; the reference draws one decomposition per restart, :1299-1340)
 #define PLO_KERNEL_BLOCK g_kernel_block
 // restarts s0 .. s0+cnt-1 of the two Optimizer calls on one decomposition: GPU (chained-candidate kernel) or host loop
@@ -293,7 +296,7 @@ template <class F> bool kernel_batch_gpu(HipLib &L, const std::vector<KernelDeco
 
 template <class F> bool kernel_method(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed0, size_t loops, int gpu, uint32_t q,
                                       int verbose, Ops &gops, std::string &gtext, const char *argv0) {
-    uint64_t seed = 0, bdec = 0; Ops best; bool have = false; double kms = 0; uint64_t ncand = 0;
+    uint64_t seed = 0, bdec = 0; Ops best; bool have = false, on_device = false; double kms = 0; uint64_t ncand = 0;
     const uint64_t nblocks = (loops + PLO_KERNEL_BLOCK - 1) / PLO_KERNEL_BLOCK;
     bool use_gpu = false;
     HipLib L;
@@ -304,6 +307,22 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     const uint64_t full = loops / PLO_KERNEL_BLOCK;                    // full blocks go to the GPU in batches of one launch each
     const uint64_t BATCH = 4096;
     uint64_t d = 0;
+    // All of it on the device (plo_kernel_search: the wave of a restart eliminates, builds both images and runs both
+    // Optimizer calls): matrices of at most 64 x 64.  --host-decomp keeps the decompositions on the host (round-1 path).
+    if constexpr (std::is_same<F, ZpField>::value) if (use_gpu && L.kernel_search && !g_host_decomp && lM.rowdim() <= 64 && lM.coldim() <= 64) {
+        KernelDecomp<F> kd0;
+        if (!kernel_decomp(f, lM, seed0, kd0)) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }   // :1343-1346 (the rank does not depend on the order)
+        std::vector<uint32_t> rp, cc, vv; to_csr(lM, rp, cc, vv);
+        plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
+        plo_best_t b{}; plo_stats_t st{};
+        const int rc = L.kernel_search(&A, q, seed0, loops, (uint32_t)std::min<uint64_t>(PLO_KERNEL_BLOCK, 0xFFFFFFFFull), PLO_COST_SUM_THEN_ADD, nullptr, nullptr, nullptr, &b, &st);
+        if (rc == PLO_OK) {
+            best = {b.adds, b.muls}; seed = b.seed; bdec = seed0 + ((b.seed - seed0) / PLO_KERNEL_BLOCK) * PLO_KERNEL_BLOCK; have = true;
+            kms = st.kernel_ms; ncand = st.candidates; d = nblocks; on_device = true;
+        } else if (rc != PLO_E_UNSUPPORTED && rc != PLO_E_CAPACITY) {
+            ++g_failures; std::cerr << "# \033[1;31mERROR: -K on the GPU: " << L.last_error() << "\033[0m" << std::endl; return false;
+        }
+    }
     if (use_gpu) for (; d < full; ) {
         const uint64_t nb = std::min<uint64_t>(BATCH, full - d), s0 = seed0 + d * PLO_KERNEL_BLOCK;
         std::vector<KernelDecomp<F>> kds(nb); bool zero = false;
@@ -352,7 +371,7 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     if (!kernel_decomp(f, lM, bdec, kd)) return false;
     Ops rops; std::string t = kernel_text(f, kd, seed, rops);
     if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -K replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
-    if (use_gpu && verbose > 0) std::clog << "# GPU (K): " << ncand << " candidates on " << nblocks << " decompositions, kernel " << kms << " ms" << std::endl;
+    if (use_gpu && verbose > 0) std::clog << "# GPU (K): " << ncand << " candidates on " << nblocks << " decompositions, kernel " << kms << " ms" << (on_device ? " (decompositions on the device)" : " (decompositions on the host)") << std::endl;
     if (verbose > 0) std::clog << "# Found K: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed
                                << "] (rank " << kd.rank << '+' << kd.notindep << ", " << kd.dep.size() << " dependent rows)" << std::endl;
     if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                              // :1347-1351
@@ -688,6 +707,7 @@ int main(int argc, char **argv)
                       << "      frequency > 1 is a child, once -- the reference tries it once per row holding it); best by additions then multiplications\n"
                       << "      of the printed program, or with --recsub by RecSub's own counts (multiplications before ProgramGen)\n"
                       << "  --only D|K|G|A|E|N: run exactly that method\n"
+                      << "  --host-decomp: -K makes the nullspace decompositions on the host (default: on the device when the matrix has at most 64 rows and columns)\n"
                       << "  --kernel-block #: restarts per nullspace decomposition of -K (default 1: one decomposition per restart, as the reference)\n"
                       << "  -M/-P: also print the matrix (Maple / pretty) on the log stream\n";
             exit(-1);
@@ -707,6 +727,7 @@ int main(int argc, char **argv)
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
         else if (a == "--engine" && i + 1 < argc) { std::string e(argv[++i]); g_engine = e == "literal" ? 1 : e == "fast" ? 2 : 0; }
         else if (a == "--replay") replay_only = true;    // print the program of candidate --seed, no search
+        else if (a == "--host-decomp") g_host_decomp = true;
         else if (a == "--kernel-block" && i + 1 < argc) g_kernel_block = std::max<uint64_t>(1, strtoull(argv[++i], nullptr, 10));
         else if (a == "--recsub") g_recsub_order = true;
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing

@@ -9,6 +9,7 @@
 // entry point fails with PLO_E_HIP.
 // ===========================================================================
 #include "plo_cse_wave.hip"
+#include "plo_kmethod.hip"
 #include "plo_cse_big.hip"
 #include "plo_cob.hip"
 #include "plo_tril.hip"
@@ -453,6 +454,7 @@ int device_error(int err) {
     case plo::ERR_MULT:  return fail(PLO_E_INTERNAL, "device: multiplier list overflow");
     case plo::ERR_STEPS: return fail(PLO_E_INTERNAL, "device: more CSE steps than the column bound");
     case plo::ERR_PGEN:  return fail(PLO_E_UNSUPPORTED, "device: ProgramGen for non +-1 coefficients not available in this build");
+    case plo::ERR_KDEC:  return fail(PLO_E_INTERNAL, "device: nullspace decomposition inconsistent with the rank found on the host");
     default:             return fail(PLO_E_INTERNAL, "device: pair table inconsistency");
     }
 }
@@ -935,6 +937,188 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
         st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return PLO_OK;
     }
+    return device_error(plo::ERR_TABLE);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The kernel method with everything on the device (plo_kmethod.hip): decomposition, both images and both Optimizer
+// calls of every restart in one wave.
+namespace {
+uint32_t rank_mod_p(const plo_csr_t *M, uint32_t p)
+{
+    const uint32_t m = M->m, n = M->n;
+    std::vector<std::vector<uint64_t>> A(m, std::vector<uint64_t>(n, 0));
+    for (uint32_t i = 0; i < m; ++i) for (uint32_t k = M->rowptr[i]; k < M->rowptr[i + 1]; ++k) A[i][M->col[k]] = M->val[k];
+    uint32_t r = 0;
+    for (uint32_t c = 0; c < n && r < m; ++c) {
+        uint32_t piv = r; while (piv < m && A[piv][c] == 0) ++piv;
+        if (piv == m) continue;
+        std::swap(A[piv], A[r]);
+        const uint64_t iv = inv_mod((uint32_t)A[r][c], p);
+        for (uint32_t j = c; j < n; ++j) A[r][j] = A[r][j] * iv % p;
+        for (uint32_t i = r + 1; i < m; ++i) if (A[i][c]) { const uint64_t x = A[i][c]; for (uint32_t j = c; j < n; ++j) A[i][j] = (A[i][j] + (p - x) * A[r][j]) % p; }
+        ++r;
+    }
+    return r;
+}
+// layout of an image that is built on the device (no template): the fields of build_plan() from bounds instead of a matrix
+int layout_plan(plo::WavePlan &P, uint32_t m, uint32_t n, uint32_t nnz, uint32_t p, uint32_t maxlen, uint32_t naive, uint32_t cap)
+{
+    P = plo::WavePlan{};
+    const uint32_t mw = 1;
+    const uint64_t NC = (uint64_t)n + naive / 2 + 2;
+    const uint32_t rb = ceil_log2(p), bb = ceil_log2((uint32_t)NC);
+    if (NC >= 0xFFFFull || 2u * bb + rb > 44u) return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) of the dependent part does not fit 44 bits");
+    if (2ull * nnz >= 65535ull || cap > 65536u) return fail(PLO_E_CAPACITY, "dependent part too large for the wave kernel");
+    P.m = m; P.n = n; P.nnz = nnz; P.p = p; P.NC = (uint32_t)NC; P.cap = cap; P.hbits = ceil_log2(cap);
+    P.lpr_log2 = std::max(2u, ceil_log2(std::max(maxlen, 1u))); P.mw = mw; P.unit = 0u;
+    P.multcap = (uint32_t)(naive / 2 + 8); P.maxlen = maxlen; P.rb = rb; P.bb = bb; P.mu = (~0ull) / p;
+    uint32_t off = 0;
+    P.off_tab = off;   off += cap * 8u;
+    P.off_val = off;   off += nnz * 4u;
+    P.off_inv = off;   off += nnz * 4u;
+    P.off_col = off;   off += nnz * 2u;
+    P.off_len = off;   off += m * 2u;
+    off = round_up(off, 8);
+    P.off_cmask = off; P.off_umask = off + mw * 8u;
+    P.tmpl_bytes = off + n * 2u * mw * 8u;
+    off += (uint32_t)NC * 2u * mw * 8u;
+    P.off_aff = off;   off += (2u * mw + 1u) * 8u;
+    P.off_ties = off;  off += cap * 2u;
+    off = round_up(off, 8);
+    P.off_mult = off;  off += P.multcap * 8u;
+    P.region_bytes = round_up(off, 16);
+    P.rs_bytes = round_up((m + 1) * 2u, 16);
+    return PLO_OK;
+}
+} // namespace
+
+int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t nrestarts, uint32_t per_block, int cost_mode,
+                      uint32_t *adds, uint32_t *muls, uint32_t *info, plo_best_t *best, plo_stats_t *st)
+{
+    if (!M || nrestarts == 0 || per_block == 0) return fail(PLO_E_ARG, "bad argument");
+    if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
+    if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
+    if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
+    if (const char *bad = csr_defect(M, p)) return fail(PLO_E_ARG, bad);
+    if (M->m == 0 || M->m > 64 || M->n == 0 || M->n > 64) return fail(PLO_E_UNSUPPORTED, "device decomposition needs at most 64 rows and 64 columns");
+    if (nrestarts > 0xFFFFFFFFull) return fail(PLO_E_ARG, "at most 2^32-1 restarts per call");
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (best) { best->adds = best->muls = 0xFFFFFFFFu; best->seed = ~0ull; }
+    const uint32_t m = M->m, n = M->n, R = rank_mod_p(M, p), ndeps = m - R;
+    if (ndeps == 0) return fail(PLO_E_UNSUPPORTED, "zero dimensional kernel");
+    if (R == 0) return fail(PLO_E_UNSUPPORTED, "zero matrix");
+
+    uint8_t *d_img = nullptr; uint64_t *d_rsD = nullptr; uint32_t *d_adds = nullptr, *d_muls = nullptr, *d_info = nullptr, *d_err = nullptr, *d_sz = nullptr; unsigned long long *d_best = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_img, (void *)d_rsD, (void *)d_adds, (void *)d_muls, (void *)d_info, (void *)d_err, (void *)d_sz, (void *)d_best}) if (q) (void)hipFree(q);
+        d_img = nullptr; d_rsD = nullptr; d_adds = d_muls = d_info = d_err = d_sz = nullptr; d_best = nullptr;
+        if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); e0 = e1 = nullptr;
+    };
+#define KCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PLO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    uint32_t pairs_max = 0;
+    for (uint32_t cap_scale = 2; cap_scale <= 32; cap_scale *= 2) {
+        plo::KPlan K{};
+        // plan and image of M (the layout of Free)
+        plo_plan tmp; tmp.m = m; tmp.n = n; tmp.p = p; tmp.cap_scale = cap_scale;
+        tmp.rowptr.assign(M->rowptr, M->rowptr + m + 1); tmp.col.assign(M->col, M->col + M->rowptr[m]); tmp.val.assign(M->val, M->val + M->rowptr[m]);
+        std::vector<uint8_t> img;
+        int rc = build_plan(&tmp, &img);
+        if (rc != PLO_OK) { cleanup(); return rc; }
+        K.PM = tmp.P; K.m = m; K.n = n; K.rank = R; K.ndeps = ndeps; K.per_block = per_block;
+        uint32_t off = 0;
+        K.off_ech = off;   off += R * n * 4u;
+        K.off_comb = off;  off += R * R * 4u;
+        K.off_depc = off;  off += ndeps * R * 4u;
+        K.off_vrow = off;  off += 64u * 4u;
+        K.off_ord = off;   off += 64u * 2u;
+        K.off_piv = off;   off += 64u * 2u;
+        K.off_basis = off; off += 64u * 2u;
+        K.off_deps = off;  off += 64u * 2u;
+        K.scratch_bytes = round_up(off, 16);
+        KCHK(hipMalloc((void **)&d_img, img.size() + 64)); KCHK(hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
+        K.PM.tmpl = (const uint64_t *)d_img;
+        KCHK(hipMalloc((void **)&d_err, 4)); KCHK(hipMemset(d_err, 0, 4));
+        KCHK(hipEventCreate(&e0)); KCHK(hipEventCreate(&e1));
+        if (cap_scale == 2) {
+            // sizing launch: Dep's pair count over a sample of the decompositions
+            K.region = K.PM.region_bytes;
+            uint32_t W = 0, lds = 0;
+            for (uint32_t w : {4u, 2u, 1u}) { const uint32_t l = K.PM.rs_bytes + w * (K.region + K.scratch_bytes); if (l <= g_lds_max) { W = w; lds = l; break; } }
+            if (!W) { cleanup(); return fail(PLO_E_CAPACITY, "kernel-method state does not fit LDS"); }
+            KCHK(hipMalloc((void **)&d_sz, 16)); KCHK(hipMemset(d_sz, 0, 16));
+            KCHK(hipFuncSetAttribute((const void *)plo::kmethod_size_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            plo::WaveJob J{}; J.seed0 = seed0; J.ncand = std::min<uint64_t>(nrestarts, 4096); J.err = d_err;
+            const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g_cus * 2u, (J.ncand + W - 1) / W));
+            KCHK(hipEventRecord(e0, g_stream));
+            hipLaunchKernelGGL(plo::kmethod_size_kernel, dim3((uint32_t)grid), dim3(W * 64), lds, g_stream, K, J, d_sz);
+            KCHK(hipGetLastError());
+            KCHK(hipEventRecord(e1, g_stream)); KCHK(hipEventSynchronize(e1));
+            float ms = 0; KCHK(hipEventElapsedTime(&ms, e0, e1)); st->kernel_ms += ms; st->launches += 1;
+            uint32_t sz[4] = {0, 0, 0, 0};
+            KCHK(hipMemcpy(sz, d_sz, 16, hipMemcpyDeviceToHost));
+            if (sz[2]) { cleanup(); return device_error(plo::ERR_KDEC); }
+            pairs_max = sz[0];
+        }
+        // layout of Dep's image from the hard bounds (rows <= m - rank, entries per row <= rank) and the sampled pair count
+        uint32_t capD = 64;
+        while (capD < (cap_scale * pairs_max * 3u) / 4u + 16u) capD <<= 1;
+        rc = layout_plan(K.PD, ndeps, m, ndeps * R, p, R, ndeps * (R - 1u), capD);
+        if (rc != PLO_OK) { cleanup(); return rc; }
+        std::vector<uint16_t> rsD(K.PD.rs_bytes / 2u, 0);
+        for (uint32_t j = 0; j <= ndeps; ++j) rsD[j] = (uint16_t)(j * R);
+        KCHK(hipMalloc((void **)&d_rsD, K.PD.rs_bytes)); KCHK(hipMemcpy(d_rsD, rsD.data(), K.PD.rs_bytes, hipMemcpyHostToDevice));
+        K.rsD = d_rsD;
+        K.region = std::max(K.PM.region_bytes, K.PD.region_bytes);
+        uint32_t W = 0, lds = 0, bestw = 0;
+        for (uint32_t w : {4u, 2u, 1u}) {
+            const uint32_t l = K.PM.rs_bytes + K.PD.rs_bytes + w * (K.region + K.scratch_bytes);
+            if (l > g_lds_max) continue;
+            const uint32_t waves = std::min<uint32_t>(32u, (uint32_t)(g_lds_max / l) * w);
+            if (waves > bestw) { bestw = waves; W = w; lds = l; }
+        }
+        if (!W) { cleanup(); return fail(PLO_E_CAPACITY, "kernel-method state does not fit LDS"); }
+        KCHK(hipMalloc((void **)&d_best, 8)); KCHK(hipMemset(d_best, 0xFF, 8));
+        if (adds) KCHK(hipMalloc((void **)&d_adds, nrestarts * 4));
+        if (muls) KCHK(hipMalloc((void **)&d_muls, nrestarts * 4));
+        if (info) KCHK(hipMalloc((void **)&d_info, nrestarts * 12));
+        const void *fn = K.PM.unit ? (const void *)plo::kmethod_kernel<true> : (const void *)plo::kmethod_kernel<false>;
+        KCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nb = 0;
+        KCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)(W * 64), lds));
+        const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g_cus * std::max(nb, 1), (nrestarts + W - 1) / W));
+        plo::WaveJob J{}; J.seed0 = seed0; J.ncand = nrestarts; J.adds = d_adds; J.muls = d_muls; J.best = best ? d_best : nullptr; J.cost_mode = (uint32_t)cost_mode; J.err = d_err;
+        plo::KInfo I{d_info};
+        KCHK(hipEventRecord(e0, g_stream));
+        if (K.PM.unit) hipLaunchKernelGGL(plo::kmethod_kernel<true>, dim3((uint32_t)grid), dim3(W * 64), lds, g_stream, K, J, I);
+        else hipLaunchKernelGGL(plo::kmethod_kernel<false>, dim3((uint32_t)grid), dim3(W * 64), lds, g_stream, K, J, I);
+        KCHK(hipGetLastError());
+        KCHK(hipEventRecord(e1, g_stream)); KCHK(hipEventSynchronize(e1));
+        float ms = 0; KCHK(hipEventElapsedTime(&ms, e0, e1));
+        uint32_t err = 0; KCHK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+        st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = lds; st->waves_per_wg = W; st->candidates = nrestarts;
+        if (err == plo::ERR_TABLE) { cleanup(); continue; }                      // a pair table filled up: again with twice the slots
+        if (err) { cleanup(); return device_error((int)err); }
+        if (adds) KCHK(hipMemcpy(adds, d_adds, nrestarts * 4, hipMemcpyDeviceToHost));
+        if (muls) KCHK(hipMemcpy(muls, d_muls, nrestarts * 4, hipMemcpyDeviceToHost));
+        if (info) KCHK(hipMemcpy(info, d_info, nrestarts * 12, hipMemcpyDeviceToHost));
+        if (best) {
+            unsigned long long w = 0;
+            KCHK(hipMemcpy(&w, d_best, 8, hipMemcpyDeviceToHost));
+            const uint64_t key = w >> 32, o = w & 0xFFFFFFFFull;
+            uint32_t a = 0, mu = 0;
+            if (cost_mode == PLO_COST_SUM_THEN_ADD) { a = (uint32_t)(key & 0xFFFFu); mu = (uint32_t)(key >> 16) - a; }
+            else if (cost_mode == PLO_COST_ADD_THEN_MUL) { a = (uint32_t)(key >> 16); mu = (uint32_t)(key & 0xFFFFu); }
+            else { a = (uint32_t)key; mu = 0; }
+            best->adds = a; best->muls = mu; best->seed = seed0 + o;
+        }
+        cleanup();
+        st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return PLO_OK;
+    }
+#undef KCHK
     return device_error(plo::ERR_TABLE);
 }
 

@@ -1,0 +1,289 @@
+// ===========================================================================
+// plo_kmethod.hip -- the kernel method (`bin/optimizer -K`) entirely on gfx950:
+// one wavefront = one restart of KernelOptimiser (reference
+// include/plinopt_optimize.inl:1288-1353): a nullspace decomposition of M
+// (nullspacedecomp :689-884, with this build's rule, see host/plo_host.hpp
+// `kernel_decomp_order` and oracle/plo_oracle.c `plo_oracle_kernel_restart`),
+// then Optimizer() on `Free` and on `Dep` from one random stream (:1322-1333).
+//
+// Round 1 made the decomposition and both LDS images on the host (58 ms of
+// kernels in 2.6 s of wall); here the wave does it all:
+//   1. copies M's image (the template of plo_cse_wave.hip) into its LDS region,
+//   2. draws the row order (Fisher-Yates) and eliminates row after row: lane j
+//      holds entry j of the row being reduced and, in a second register,
+//      coefficient j of its combination over the basis rows found so far; the
+//      echelon rows and their combinations are LDS arrays read by all lanes,
+//   3. NotIndep = next() mod #dependent rows; `Free` = M's image with the kept
+//      dependent rows retired from the pair table and the column masks,
+//   4. Optimizer on Free (run_candidate), then the image of `Dep` is built in
+//      the same region (rows = kept dependent rows, columns = rows of M, the
+//      combination over the basis rows; inverses by Fermat, pair table by
+//      tab_inc), Optimizer on Dep with the stream where the first call left it.
+// Needs m, n <= 64 (a row and a combination fit one register per lane); the
+// sizes of Dep's image are bounded from rank(M) by the host, its pair table by a
+// sizing launch (kmethod_size_kernel); a full table is reported (ERR_TABLE) and
+// the launch repeated with a larger one, as for the other wave-kernel plans.
+// ===========================================================================
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plo {
+
+struct KPlan {
+    WavePlan PM, PD;               // PM: plan of M itself (Free has its layout); PD: layout of Dep's image (no template)
+    uint32_t m, n, rank, ndeps, per_block;
+    uint32_t region;               // bytes of the image region of a wave (max of the two plans)
+    uint32_t off_ech, off_comb, off_depc, off_vrow, off_ord, off_piv, off_basis, off_deps, scratch_bytes;   // elimination scratch behind the region
+    const uint64_t *rsD;           // row starts of Dep's image (u16, PD.rs_bytes)
+};
+struct KInfo { uint32_t *info; };  // optional, 3 words per candidate: rank, NotIndep, dependent rows
+enum { ERR_KDEC = 5 };             // device error word: decomposition inconsistent (rank, table of M)
+
+// x^(p-2); x = +-1 are their own inverses
+__device__ __forceinline__ uint32_t kinv(uint32_t x, uint32_t p, uint64_t mu) {
+    if (x == 1u || x == p - 1u) return x;
+    uint32_t res = 1u, bs = x;
+    for (uint32_t e = p - 2u; e; e >>= 1) { if (e & 1u) res = fmul<false>(res, bs, p, mu); bs = fmul<false>(bs, bs, p, mu); }
+    return res;
+}
+
+struct KScratch { uint32_t *ech, *comb, *depc, *vrow; uint16_t *ord, *piv, *basis, *deps; };
+__device__ __forceinline__ KScratch kscratch(const KPlan &K, uint8_t *scr) {
+    return KScratch{(uint32_t *)(scr + K.off_ech), (uint32_t *)(scr + K.off_comb), (uint32_t *)(scr + K.off_depc), (uint32_t *)(scr + K.off_vrow),
+                    (uint16_t *)(scr + K.off_ord), (uint16_t *)(scr + K.off_piv), (uint16_t *)(scr + K.off_basis), (uint16_t *)(scr + K.off_deps)};
+}
+
+// Steps 1-2 and the draw of NotIndep.  M's image must be in `reg`.  Returns the number of dependent rows KEPT in Dep
+// (0: zero dimensional kernel); S.deps / S.depc hold the dependent rows in elimination order and their combinations
+// (indexed by basis position), S.basis the basis rows.
+__device__ uint32_t kmethod_decompose(const KPlan &K, uint8_t *reg, const KScratch &S, const uint16_t *rsM, uint64_t dseed, uint32_t lane,
+                                      uint32_t &notindep_out)
+{
+    const WavePlan &PM = K.PM;
+    const uint32_t p = PM.p, m = K.m, n = K.n, R = K.rank; const uint64_t mu = PM.mu;
+    const uint32_t *valM = (const uint32_t *)(reg + PM.off_val); const uint16_t *colM = (const uint16_t *)(reg + PM.off_col), *lenM = (const uint16_t *)(reg + PM.off_len);
+    uint32_t rng = 1u + (uint32_t)(splitmix64(dseed) % 2147483646ull);
+    if (lane < m) S.ord[lane] = (uint16_t)lane;
+    PLO_WAVE_SYNC();
+    if (lane == 0) for (uint32_t i = m; i > 1u; --i) { const uint32_t j = rng_next(rng) % i; const uint16_t t = S.ord[i - 1u]; S.ord[i - 1u] = S.ord[j]; S.ord[j] = t; }
+    rng = uni32(rng);
+    PLO_WAVE_SYNC();
+    uint32_t nb = 0, nd = 0;
+    for (uint32_t t = 0; t < m; ++t) {
+        const uint32_t row = uni32(S.ord[t]), base = rsM[row], ln = lenM[row];
+        S.vrow[lane] = 0u;
+        PLO_WAVE_SYNC();
+        if (lane < ln) S.vrow[colM[base + lane]] = valM[base + lane];
+        PLO_WAVE_SYNC();
+        uint32_t v = S.vrow[lane], c = 0u;                                   // lanes >= n stay 0
+        for (uint32_t k = 0; k < nb; ++k) {
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni32(S.piv[k]));
+            if (x == 0u) continue;
+            const uint32_t e = lane < n ? S.ech[k * n + lane] : 0u, cb = lane < R ? S.comb[k * R + lane] : 0u;
+            const uint32_t xe = fmul<false>(x, e, p, mu), xc = fmul<false>(x, cb, p, mu);
+            v = v >= xe ? v - xe : v + p - xe;
+            c += xc; c -= c >= p ? p : 0u;
+        }
+        const uint64_t nz = __ballot(v != 0u);
+        if (!nz) {                                                           // row = sum_j c[j] * basis row j
+            if (lane == 0) S.deps[nd] = (uint16_t)row;
+            if (lane < R) S.depc[nd * R + lane] = c;
+            ++nd;
+        } else {                                                             // new basis row: echelon row = (row - sum c_j basis_j) / pivot
+            const uint32_t pc = (uint32_t)__builtin_ctzll(nz);
+            const uint32_t iv = kinv((uint32_t)__builtin_amdgcn_readlane((int)v, (int)pc), p, mu);
+            uint32_t cc = 0u;
+            if (lane < nb) { const uint32_t q = fmul<false>(c, iv, p, mu); cc = q ? p - q : 0u; } else if (lane == nb) cc = iv;
+            v = fmul<false>(v, iv, p, mu);
+            if (nb < R) {
+                if (lane < n) S.ech[nb * n + lane] = v;
+                if (lane < R) S.comb[nb * R + lane] = cc;
+                if (lane == 0) { S.piv[nb] = (uint16_t)pc; S.basis[nb] = (uint16_t)row; }
+            }
+            ++nb;
+        }
+        PLO_WAVE_SYNC();
+    }
+    notindep_out = 0;
+    if (nd == 0u || nb != R) return 0u;                                      // (nb != rank(M) cannot happen: the rank does not depend on the order)
+    const uint32_t ni = uni32(rng_next(rng) % nd);                           // :792-795
+    notindep_out = ni;
+    return nd - ni;
+}
+
+// row j of Dep as (column = row of M, value), columns increasing: returns the length; lane c < m gets has/pos/value
+__device__ __forceinline__ uint32_t kmethod_dep_row(const KPlan &K, const KScratch &S, uint32_t j, uint32_t lane, bool &has, uint32_t &pos, uint32_t &x) {
+    const uint32_t R = K.rank;
+    S.vrow[lane] = 0u;
+    PLO_WAVE_SYNC();
+    if (lane < R) { const uint32_t c = S.depc[j * R + lane]; if (c) S.vrow[S.basis[lane]] = c; }
+    PLO_WAVE_SYNC();
+    x = S.vrow[lane]; has = x != 0u;
+    const uint64_t mk = __ballot(has);
+    pos = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+    PLO_WAVE_SYNC();
+    return (uint32_t)__popcll(mk);
+}
+
+// One restart.  Returns adds<<32 | muls of the two programs together.
+template <bool UNITM>
+__device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr, const uint16_t *rsM, const uint16_t *rsD, uint64_t dseed, uint64_t seed,
+                                      uint32_t lane, uint32_t *errw, uint32_t *info3)
+{
+    const WavePlan &PM = K.PM, &PD = K.PD;
+    const uint32_t p = PM.p, m = K.m, R = K.rank; const uint64_t mu = PM.mu;
+    const KScratch S = kscratch(K, scr);
+    for (uint32_t i = lane; i < (PM.tmpl_bytes >> 3); i += 64u) ((uint64_t *)reg)[i] = PM.tmpl[i];
+    PLO_WAVE_SYNC();
+    uint32_t notindep = 0;
+    const uint32_t kept = kmethod_decompose(K, reg, S, rsM, dseed, lane, notindep);
+    if (info3 && lane == 0) { info3[0] = R; info3[1] = notindep; info3[2] = kept; }
+    if (kept == 0u) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_KDEC); return 0; }
+    bool bad = false;
+    {   // ---- Free: M's image minus the kept dependent rows (their pairs retired, their mask bits cleared)
+        uint64_t *tab = (uint64_t *)(reg + PM.off_tab), *cmask = (uint64_t *)(reg + PM.off_cmask), *umask = (uint64_t *)(reg + PM.off_umask);
+        uint32_t *val = (uint32_t *)(reg + PM.off_val), *inv = (uint32_t *)(reg + PM.off_inv);
+        uint16_t *col = (uint16_t *)(reg + PM.off_col), *len = (uint16_t *)(reg + PM.off_len);
+        const uint32_t abs_ = PM.rb + PM.bb, rb = PM.rb;
+        for (uint32_t j = 0; j < kept; ++j) {
+            const uint32_t i = uni32(S.deps[j]), base = rsM[i], ln = len[i];
+            for (uint32_t x = 0; x + 1u < ln; ++x) {
+                const uint32_t y = x + 1u + lane;
+                if (y < ln) {
+                    const uint32_t r = fmul<UNITM>(val[base + y], UNITM ? val[base + x] : inv[base + x], p, mu);
+                    bad |= !tab_dec(tab, ((uint64_t)col[base + x] << abs_) | ((uint64_t)col[base + y] << rb) | r, PM.cap, PM.hbits);
+                }
+            }
+            if (lane < ln) { const uint32_t c = col[base + lane]; atomicAnd((unsigned long long *)&cmask[c * 2u], ~(1ull << i)); atomicAnd((unsigned long long *)&umask[c * 2u], ~(1ull << i)); }
+            PLO_WAVE_SYNC();
+            if (lane == 0) len[i] = 0;
+        }
+        PLO_WAVE_SYNC();
+    }
+    if (__ballot(bad)) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_KDEC); return 0; }
+    PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull, 0u};
+    const uint64_t r1 = run_candidate<UNITM>(PM, reg, rsM, ps, lane, errw);
+    PLO_WAVE_SYNC();
+    {   // ---- Dep: kept rows, columns = rows of M
+        uint64_t *tab = (uint64_t *)(reg + PD.off_tab), *cmask = (uint64_t *)(reg + PD.off_cmask), *umask = (uint64_t *)(reg + PD.off_umask);
+        uint32_t *val = (uint32_t *)(reg + PD.off_val), *inv = (uint32_t *)(reg + PD.off_inv);
+        uint16_t *col = (uint16_t *)(reg + PD.off_col), *len = (uint16_t *)(reg + PD.off_len);
+        const uint32_t abs_ = PD.rb + PD.bb, rb = PD.rb;
+        for (uint32_t s = lane; s < PD.cap; s += 64u) tab[s] = PLO_EMPTY;
+        if (lane < m) { cmask[lane * 2u] = 0ull; umask[lane * 2u] = 0ull; }
+        if (lane < PD.m) len[lane] = 0;
+        PLO_WAVE_SYNC();
+        for (uint32_t j = 0; j < kept; ++j) {
+            bool has; uint32_t pos, x;
+            const uint32_t ln = kmethod_dep_row(K, S, j, lane, has, pos, x);
+            const uint32_t base = rsD[j];
+            if (has) {
+                col[base + pos] = (uint16_t)lane; val[base + pos] = x;
+                atomicOr((unsigned long long *)&cmask[lane * 2u], 1ull << j);
+                if (absone(x, p)) atomicOr((unsigned long long *)&umask[lane * 2u], 1ull << j);
+            }
+            if (lane == 0) len[j] = (uint16_t)ln;
+        }
+        PLO_WAVE_SYNC();
+        for (uint32_t idx = lane; idx < kept * R; idx += 64u) {               // inverses of all entries, 64 at a time
+            const uint32_t j = idx / R, t = idx - j * R;
+            if (t < len[j]) inv[rsD[j] + t] = kinv(val[rsD[j] + t], p, mu);
+        }
+        PLO_WAVE_SYNC();
+        // pair table (listpairs :30-41): G rows per trip, lane t of a group pairs entry t with every earlier entry x
+        const uint32_t LPR = 1u << PD.lpr_log2, G = 64u >> PD.lpr_log2, g = lane >> PD.lpr_log2, t = lane & (LPR - 1u);
+        for (uint32_t r0 = 0; r0 < kept; r0 += G) {
+            const uint32_t row = r0 + g; const bool act = row < kept;
+            const uint32_t base = act ? rsD[row] : 0u, ln = act ? len[row] : 0u;
+            const bool have = t < ln;
+            const uint32_t cy = have ? col[base + t] : 0u, vy = have ? val[base + t] : 0u;
+            for (uint32_t x = 0; x + 1u < R; ++x) {
+                if (have && x < t) {
+                    const uint32_t r = fmul<false>(vy, inv[base + x], p, mu);
+                    bad |= !tab_inc(tab, ((uint64_t)col[base + x] << abs_) | ((uint64_t)cy << rb) | r, PD.cap, PD.hbits);
+                }
+            }
+        }
+        PLO_WAVE_SYNC();
+    }
+    if (__ballot(bad)) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_TABLE); return 0; }
+    const uint64_t r2 = run_candidate<false>(PD, reg, rsD, ps, lane, errw);
+    return ((uint64_t)((uint32_t)(r1 >> 32) + (uint32_t)(r2 >> 32)) << 32) | ((uint32_t)r1 + (uint32_t)r2);
+}
+
+__device__ __forceinline__ void kmethod_stage_rs(const KPlan &K, uint64_t *lds64) {
+    const uint32_t rwM = K.PM.rs_bytes >> 3, rwD = K.PD.rs_bytes >> 3, twM = K.PM.tmpl_bytes >> 3;
+    for (uint32_t i = threadIdx.x; i < rwM; i += blockDim.x) lds64[i] = K.PM.tmpl[twM + i];
+    for (uint32_t i = threadIdx.x; i < rwD; i += blockDim.x) lds64[rwM + i] = K.rsD[i];
+    __syncthreads();
+}
+
+template <bool UNITM>
+__global__ __launch_bounds__(256) void kmethod_kernel(KPlan K, WaveJob J, KInfo I)
+{
+    extern __shared__ uint64_t lds64[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    kmethod_stage_rs(K, lds64);
+    const uint16_t *rsM = (const uint16_t *)lds64, *rsD = (const uint16_t *)(lds64 + (K.PM.rs_bytes >> 3));
+    uint8_t *reg = (uint8_t *)lds64 + K.PM.rs_bytes + K.PD.rs_bytes + (size_t)wave * (K.region + K.scratch_bytes);
+    uint8_t *scr = reg + K.region;
+    uint64_t best = ~0ull;
+    const uint64_t stride = (uint64_t)gridDim.x * nwaves;
+    for (uint64_t c = (uint64_t)blockIdx.x * nwaves + wave; c < J.ncand; c += stride) {
+        const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
+        const uint64_t dseed = (!J.seeds && K.per_block > 1u) ? J.seed0 + (c / K.per_block) * K.per_block : seed;   // one decomposition per block of restarts
+        const uint64_t res = kmethod_candidate<UNITM>(K, reg, scr, rsM, rsD, dseed, seed, lane, J.err, I.info ? I.info + 3ull * c : nullptr);
+        const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
+        if (lane == 0) { if (J.adds) J.adds[c] = a; if (J.muls) J.muls[c] = mu_; }
+        const uint64_t packed = ((uint64_t)cost_key32(a, mu_, J.cost_mode) << 32) | (uint32_t)c;
+        best = packed < best ? packed : best;
+        PLO_WAVE_SYNC();
+    }
+    if (J.best) {
+        __syncthreads();
+        if (lane == 0) lds64[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t b = lds64[0];
+            for (uint32_t w = 1; w < nwaves; ++w) b = lds64[w] < b ? lds64[w] : b;
+            if (b != ~0ull) atomicMin(J.best, (unsigned long long)b);
+        }
+    }
+}
+template __global__ void kmethod_kernel<true>(KPlan, WaveJob, KInfo);
+template __global__ void kmethod_kernel<false>(KPlan, WaveJob, KInfo);
+
+// Sizing launch: the decompositions of a sample of the restarts; sz[0] = max over them of the number of pairs of Dep
+// (an upper bound of its distinct triples), sz[1] = max entries of Dep, sz[2] = 1 when a decomposition found no dependent row.
+__global__ __launch_bounds__(256) void kmethod_size_kernel(KPlan K, WaveJob J, uint32_t *sz)
+{
+    extern __shared__ uint64_t lds64[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t rwM = K.PM.rs_bytes >> 3, twM = K.PM.tmpl_bytes >> 3;
+    for (uint32_t i = threadIdx.x; i < rwM; i += blockDim.x) lds64[i] = K.PM.tmpl[twM + i];
+    __syncthreads();
+    const uint16_t *rsM = (const uint16_t *)lds64;
+    uint8_t *reg = (uint8_t *)lds64 + K.PM.rs_bytes + (size_t)wave * (K.region + K.scratch_bytes);
+    const KScratch S = kscratch(K, reg + K.region);
+    const uint64_t stride = (uint64_t)gridDim.x * nwaves;
+    for (uint64_t c = (uint64_t)blockIdx.x * nwaves + wave; c < J.ncand; c += stride) {
+        const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
+        const uint64_t dseed = (!J.seeds && K.per_block > 1u) ? J.seed0 + (c / K.per_block) * K.per_block : seed;
+        for (uint32_t i = lane; i < twM; i += 64u) ((uint64_t *)reg)[i] = K.PM.tmpl[i];
+        PLO_WAVE_SYNC();
+        uint32_t ni = 0;
+        const uint32_t kept = kmethod_decompose(K, reg, S, rsM, dseed, lane, ni);
+        if (kept == 0u) { if (lane == 0) atomicMax(&sz[2], 1u); continue; }
+        uint32_t pairs = 0, ent = 0;
+        for (uint32_t j = 0; j < kept; ++j) {
+            bool has; uint32_t pos, x;
+            const uint32_t ln = kmethod_dep_row(K, S, j, lane, has, pos, x);
+            pairs += ln * (ln - (ln ? 1u : 0u)) / 2u; ent += ln;
+        }
+        if (lane == 0) { atomicMax(&sz[0], pairs); atomicMax(&sz[1], ent); }
+        PLO_WAVE_SYNC();
+    }
+}
+
+} // namespace plo

@@ -162,6 +162,23 @@ def chain_batch(pairs, p, seed0, per_pair, cost_mode=capi.COST_SUM_THEN_ADD, wan
     return (list(adds) if want_costs else None), (list(muls) if want_costs else None), (b.adds, b.muls, b.seed), st.as_dict()
 
 
+def kernel_search(M, p, seed0, nrestarts, per_block=1, cost_mode=capi.COST_SUM_THEN_ADD, want_costs=True):
+    """The kernel method with decomposition, images and both Optimizer calls on the device (`plo_kernel_search`):
+    M = (m, n, rowptr, col, val).  Returns (adds, muls, info, (best adds, best muls, best seed), stats); info[c] =
+    (rank, NotIndep, dependent rows) of restart c."""
+    L = capi.lib()
+    m, n, rp, col, val = M
+    A, keep = capi.make_csr(m, n, rp, col, val)
+    adds = (ctypes.c_uint32 * nrestarts)() if want_costs else None
+    muls = (ctypes.c_uint32 * nrestarts)() if want_costs else None
+    info = (ctypes.c_uint32 * (3 * nrestarts))() if want_costs else None
+    b, st = capi.Best(), capi.Stats()
+    capi.check(L.plo_kernel_search(ctypes.byref(A), p, seed0, nrestarts, per_block, cost_mode, adds, muls, info, ctypes.byref(b), ctypes.byref(st)))
+    del keep
+    inf = [tuple(info[3 * k:3 * k + 3]) for k in range(nrestarts)] if want_costs else None
+    return (list(adds) if want_costs else None), (list(muls) if want_costs else None), inf, (b.adds, b.muls, b.seed), st.as_dict()
+
+
 def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1, groups=None):
     """One (block,row) enumeration of `localSparsifier` (reference include/plinopt_sparsify.inl:282-314) on the
     GPU: |coeffs|^4 candidate rows through `testLinComb`.  TM (n x m) and Cand (n x n) are flat row-major lists of

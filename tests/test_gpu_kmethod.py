@@ -1,0 +1,53 @@
+"""`bin/optimizer -K` with everything on the device (plo::kmethod_kernel through `plo_kernel_search`): per restart, the
+nullspace decomposition (this build's rule for nullspacedecomp, reference include/plinopt_optimize.inl:689-884), the two LDS
+images and the two chained Optimizer calls (:1322-1333) -- against the oracle's independent restatement
+(oracle/plo_oracle.c `plo_oracle_kernel_restart`) restart by restart."""
+import os
+
+import pytest
+
+from plo_testlib import DATA, OracleMatrix
+
+pytestmark = pytest.mark.gpu
+P = 131071
+NAMES = ["4x4x4_49_156_L.sms", "4x4x4_49_156_R.sms", "4x4x4_49_156_P.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "4x4x4_48_rational_P.sms",
+         "2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms", "3x3x3_23_58_L.sms", "3x3x3_23_58_P.sms", "2o2o4_5_Toom3_P.sms"]
+
+
+def usable(M):
+    return M.m <= 64 and M.n <= 64 and M.kernel_restart(1) is not None
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_every_restart_equals_the_oracle(hip, name):
+    from plinopt_amd import kernel_search
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
+    if not usable(M):
+        pytest.skip("more than 64 rows/columns or zero dimensional kernel")
+    n, seed0 = 200, 5
+    adds, muls, info, best, st = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n)
+    exp = [M.kernel_restart(seed0 + k) for k in range(n)]
+    assert [(a, mu) + i for a, mu, i in zip(adds, muls, info)] == exp
+    k = min(range(n), key=lambda k: (exp[k][0] + exp[k][1], exp[k][0], k))
+    assert best == (exp[k][0], exp[k][1], seed0 + k)
+    assert st["launches"] >= 2 and st["candidates"] == n          # the sizing launch + the search
+
+
+def test_blocks_of_restarts_share_a_decomposition(hip):
+    """per_block = 16 (`--kernel-block 16`): the decomposition of a block comes from its first seed; the host path does the same"""
+    from plinopt_amd import kernel_search
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), P)
+    n, seed0, per = 96, 40, 16
+    adds, muls, info, best, _ = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n, per_block=per)
+    for b in range(n // per):
+        r = M.kernel_restart(seed0 + b * per)
+        assert info[b * per] == r[2:] and (adds[b * per], muls[b * per]) == r[:2]          # first restart of a block = the oracle's restart of that seed
+        assert all(info[b * per + k] == r[2:] for k in range(per))
+
+
+def test_unsupported_shapes_are_reported(hip):
+    from plinopt_amd import capi, kernel_search
+    M = OracleMatrix.from_sms(os.path.join(DATA, "2x2x2_7_DPS-accurate_P.sms"), P)          # 4 x 7, full row rank
+    with pytest.raises(capi.PloError) as e:
+        kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, 1, 10)
+    assert e.value.code == capi.PLO_E_UNSUPPORTED
