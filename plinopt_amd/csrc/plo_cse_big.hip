@@ -219,6 +219,9 @@ __device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint3
 #ifndef PLO_GWIN
 #define PLO_GWIN 2u
 #endif
+#ifndef PLO_FLUSH_AUTO
+#define PLO_FLUSH_AUTO 1    /* lane-autonomous flush (0: lock-step trips of PLO_FLU entries) */
+#endif
 #ifndef PLO_FLU
 #define PLO_FLU 2u       /* aggregated entries per thread and trip of the flush */
 #endif
@@ -977,6 +980,78 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             };
             if (tid == 0) retired(key, M, gtab_subn(tab, key, M, hbits));
             const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
+#if PLO_FLUSH_AUTO
+            // Every lane runs its own entries: it takes the next one as soon as both keys of the current one are settled, so
+            // a probe round costs the wave one memory round trip whatever the other lanes' probe lengths are, and the
+            // atomics of a settled entry are in flight during the next entry's first round (their results are booked one
+            // trip later; memory operations return in order, so waiting for them does not wait for the newer loads).
+            {
+                const uint32_t tmask = (1u << hbits) - 1u; const bool bylist = nent <= PLO_AGG_LIST;
+                uint32_t e = tid; bool busy = false, prev = false, p1 = false, p2 = false, m1 = false, m2 = false, pm1 = false, pm2 = false;
+                uint64_t k1 = 0, k2 = 0, pk1 = 0, pk2 = 0; unsigned long long a1 = 0, a2 = 0; uint32_t d = 0, pd = 0, s1 = 0, s2 = 0;
+                for (;;) {
+                    if (!busy) {
+                        while (e < nslot) {
+                            const uint32_t s = bylist ? (uint32_t)agglist[e] : e; e += nth;
+                            uint32_t c, x, y = 0;
+                            if constexpr (MODE == 2) {
+                                const uint32_t kq = aggk[s];
+                                if (kq == 0xFFFFFFFFu) continue;
+                                d = aggc16[s]; c = kq >> PLO_RIDB;
+                                const uint32_t xid = kq & ((1u << PLO_RIDB) - 1u);
+                                x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                            } else {
+                                const uint64_t v = agg[s];
+                                if (v == AEMPTY) continue;
+                                uint64_t k = v >> acb; d = (uint32_t)(v & ((1ull << acb) - 1ull));
+                                if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
+                                c = (uint32_t)(k >> rb); x = (uint32_t)(k & ((1ull << rb) - 1ull));
+                                if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
+                            }
+                            const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
+                            const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
+                            k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x); k2 = c < b ? BKEY(c, b, x2) : BKEY(b, c, x2);
+                            s1 = ghash(k1, hbits); s2 = ghash(k2, hbits); p1 = p2 = true; m1 = m2 = false; busy = true;
+                            if constexpr (MODE != 2) agg[s] = (((((uint64_t)c) << rb) | (l0 == a ? y : ry)) << PLO_GVB) | d;    // (c, coeff / v_c), same count (mode 2: the second pass derives it again)
+#ifdef PLO_BIG_PROFILE
+                            wg_add(&sh.fl1, 1u); if (c < a) atomicAdd(&sh.pw[14], 1ull); if (c < b) atomicAdd(&sh.pw[15], 1ull);
+#endif
+                            break;
+                        }
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(busy || prev)) break;
+                    uint64_t v1[PLO_GWIN], v2[PLO_GWIN];
+#pragma unroll
+                    for (uint32_t j = 0; j < PLO_GWIN; ++j) {
+                        v1[j] = (busy && p1) ? gload64(&tab[(s1 + j) & tmask]) : 0ull;
+                        v2[j] = (busy && p2) ? gload64(&tab[(s2 + j) & tmask]) : 0ull;
+                    }
+                    if (prev) {                                                 // the entry settled one trip ago
+                        retired(pk1, pd, pm1 ? (uint32_t)(a1 & PLO_GVMASK) : 0u); retired(pk2, pd, pm2 ? (uint32_t)(a2 & PLO_GVMASK) : 0u);
+                        prev = false;
+                    }
+                    if (busy) {
+                        if (p1) {
+                            uint32_t adv = PLO_GWIN;
+#pragma unroll
+                            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p1) { if ((v1[j] >> PLO_GVB) == k1) { m1 = true; p1 = false; adv = j; } else if (v1[j] == PLO_GEMPTY) { p1 = false; adv = j; } }
+                            s1 = (s1 + adv) & tmask;
+                        }
+                        if (p2) {
+                            uint32_t adv = PLO_GWIN;
+#pragma unroll
+                            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p2) { if ((v2[j] >> PLO_GVB) == k2) { m2 = true; p2 = false; adv = j; } else if (v2[j] == PLO_GEMPTY) { p2 = false; adv = j; } }
+                            s2 = (s2 + adv) & tmask;
+                        }
+                        if (!p1 && !p2) {
+                            if (m1) a1 = wg_add((unsigned long long *)&tab[s1], (unsigned long long)(0ull - (uint64_t)d));
+                            if (m2) a2 = wg_add((unsigned long long *)&tab[s2], (unsigned long long)(0ull - (uint64_t)d));
+                            pk1 = k1; pk2 = k2; pd = d; pm1 = m1; pm2 = m2; prev = m1 || m2; busy = false;
+                        }
+                    }
+                }
+            }
+#else
             // PLO_FLU entries per thread and trip: their 2 PLO_FLU probe sequences and atomics overlap
 #ifdef PLO_BIG_PROFILE
             unsigned long long fq0 = 0, fq1 = 0, fq2 = 0, fqn = 0; const unsigned long long fts = clock64();
@@ -1033,6 +1108,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
 #ifdef PLO_BIG_PROFILE
             if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[8], fq0); atomicAdd(&sh.pw[9], fq1); atomicAdd(&sh.pw[10], fq2); atomicAdd(&sh.pw[11], fqn); atomicAdd(&sh.pw[12], clock64() - fts); atomicAdd(&sh.pw[13], 1ull); }
 #endif
+        #endif
         }
         PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(4);
