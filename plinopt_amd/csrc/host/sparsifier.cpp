@@ -4,9 +4,10 @@
 // stdout, the residue, the density profiles and the "SUCCESS: consistent factorization" line to stderr (:52,
 // plinopt_sparsify.inl:132-155).  New flag: --gpu N (0 = host only).
 //
-// With -q p the exhaustive |Coeffs|^4 enumeration of localSparsifier (plinopt_sparsify.inl:299-314) runs
-// on the GPU through plo_cob_search (include/plinopt_hip.h); over the rationals it runs on the host, as in the
-// reference.  A failing GPU call is fatal: there is no silent fallback.
+// The exhaustive |Coeffs|^4 enumeration of localSparsifier (plinopt_sparsify.inl:299-314) runs on the GPU through
+// plo_cob_search (include/plinopt_hip.h): with -q p modulo p, and without -q (the rationals, the reference's default)
+// modulo two 31-bit primes with every winner re-evaluated over Q (CobGpuQBackend).  A failing GPU call is fatal: there is
+// no silent fallback; --gpu 0 / --host-q keep the host loops.
 // ===========================================================================
 #include "plo_sparsify.hpp"
 #include "../../../include/plinopt_hip.h"
@@ -55,6 +56,74 @@ struct CobGpuBackend : CobBackend<ZpField> {
         this->candidates += st.candidates; kernel_ms += st.kernel_ms;
         CobBest r; r.zv = b.zeros_v; r.zw = b.zeros_w; r.index = b.index; r.found = b.found != 0;
         return r;
+    }
+};
+
+// GPU backend of the enumeration over the RATIONALS (the reference's default field for bin/sparsifier, src/sparsifier.cpp:66-83).
+// The zero pattern of TM^T w and the independence of w from the rows already chosen do not change when TM, the coefficient set
+// and each chosen row are scaled to integers; the enumeration then runs on the device modulo TWO 31-bit primes.  A candidate is
+// judged differently modulo p only when p divides a non-zero integer of the computation (a sum of at most four products for
+// the zero counts -- impossible when 4 max|w| max|TM| < p, which is checked -- or a minor of the chosen rows for the
+// independence test).  The two runs must name the same candidate and that candidate is re-evaluated over Q on the host
+// (independence by rank, both zero counts); anything else sends this (block, row) to the host enumeration over Q.
+struct CobGpuQBackend : CobBackend<QField> {
+    HipCob &L; double kernel_ms = 0; uint64_t fallbacks = 0, gpu_calls = 0;
+    CobHostBackend<QField> host;
+    explicit CobGpuQBackend(HipCob &l) : L(l) {}
+    static int64_t lcm64(int64_t a, int64_t b) { int64_t x = a, y = b; while (y) { int64_t t = x % y; x = y; y = t; } __int128 r = (__int128)a / x * b; if (r > ((__int128)1 << 40)) throw std::overflow_error("denominators too large"); return (int64_t)r; }
+    CobBest best(const QField &f, const DMat<Rat> &TM, const DMat<Rat> &Cand, size_t row, size_t off, const std::vector<Rat> &coeffs, int w0, int w1) override {
+        const size_t n = TM.size(), m = n ? TM[0].size() : 0, C = coeffs.size();
+        static const uint32_t primes[2] = {2147483647u, 2147483629u};
+        try {
+            // integer images: TM by one common factor, the coefficients by one common factor, every chosen row by its own
+            int64_t dT = 1, dC = 1;
+            for (auto &r : TM) for (auto &e : r) dT = lcm64(dT, e.d);
+            for (auto &e : coeffs) dC = lcm64(dC, e.d);
+            std::vector<__int128> tmi(n * m), cfi(C), cdi(n * n, 0);
+            __int128 tmax = 0, cmax = 0;
+            for (size_t i = 0; i < n; ++i) for (size_t j = 0; j < m; ++j) { __int128 v = (__int128)TM[i][j].n * (dT / TM[i][j].d); tmi[i * m + j] = v; tmax = std::max(tmax, v < 0 ? -v : v); }
+            for (size_t k = 0; k < C; ++k) { __int128 v = (__int128)coeffs[k].n * (dC / coeffs[k].d); cfi[k] = v; cmax = std::max(cmax, v < 0 ? -v : v); }
+            for (size_t i = 0; i < row; ++i) { int64_t dr = 1; for (auto &e : Cand[i]) dr = lcm64(dr, e.d); for (size_t j = 0; j < n; ++j) cdi[i * n + j] = (__int128)Cand[i][j].n * (dr / Cand[i][j].d); }
+            if (4 * tmax * cmax >= (__int128)primes[1]) throw std::overflow_error("entries too large for an exact zero test modulo a 31-bit prime");
+            plo_cob_best_t b[2]{}; plo_stats_t st[2]{};
+            for (int q = 0; q < 2; ++q) {
+                const __int128 P = primes[q];
+                auto red = [&](__int128 v) { __int128 r = v % P; if (r < 0) r += P; return (uint32_t)r; };
+                std::vector<uint32_t> tm(n * m), cd(n * n), cf(C);
+                for (size_t k = 0; k < n * m; ++k) tm[k] = red(tmi[k]);
+                for (size_t k = 0; k < n * n; ++k) cd[k] = red(cdi[k]);
+                for (size_t k = 0; k < C; ++k) cf[k] = red(cfi[k]);
+                const int rc = L.cob_search((uint32_t)n, (uint32_t)m, tm.data(), cd.data(), (uint32_t)row, (uint32_t)off, cf.data(), (uint32_t)C, primes[q], w0, w1, &b[q], &st[q]);
+                if (rc != PLO_OK) throw std::runtime_error(std::string("GPU CoB search failed: ") + L.last_error());
+                kernel_ms += st[q].kernel_ms;
+            }
+            this->candidates += st[0].candidates; ++gpu_calls;
+            if (b[0].found != b[1].found || (b[0].found && (b[0].index != b[1].index || b[0].zeros_v != b[1].zeros_v || b[0].zeros_w != b[1].zeros_w)))
+                throw std::runtime_error("the two moduli disagree");
+            CobBest r; r.zv = w0; r.zw = w1;
+            if (!b[0].found) return r;
+            // the winner over Q
+            uint64_t idx = b[0].index; size_t ix[4];
+            for (int t = 3; t >= 0; --t) { ix[t] = (size_t)(idx % C); idx /= C; }
+            std::vector<Rat> w(n, f.zero());
+            for (size_t t = 0; t < 4; ++t) if (off + t < n) w[off + t] = coeffs[ix[t]];
+            DMat<Rat> prev(Cand.begin(), Cand.begin() + (long)row); prev.push_back(w);
+            if (drank(f, prev) != row + 1) throw std::runtime_error("winner is dependent over Q");
+            int zv = 0, zw = (int)n;
+            for (size_t t = 0; t < 4 && off + t < n; ++t) if (!f.isZero(w[off + t])) --zw;
+            for (size_t c = 0; c < m; ++c) { Rat sacc = f.zero(); for (size_t t = 0; t < 4 && off + t < n; ++t) sacc = f.add(sacc, f.mul(w[off + t], TM[off + t][c])); if (f.isZero(sacc)) ++zv; }
+            if (zv != b[0].zeros_v || zw != b[0].zeros_w) throw std::runtime_error("winner's zero counts differ over Q");
+            r.zv = zv; r.zw = zw; r.index = b[0].index; r.found = true;
+            return r;
+        } catch (const std::exception &e) {
+            if (std::string(e.what()).rfind("GPU CoB search failed", 0) == 0) throw;           // a failing GPU call is fatal, as with -q
+            ++fallbacks;
+            std::clog << "# CoB over Q on the host for block " << off << ", row " << row << ": " << e.what() << std::endl;
+            const uint64_t before = host.candidates;
+            CobBest r = host.best(f, TM, Cand, row, off, coeffs, w0, w1);
+            this->candidates += host.candidates - before;
+            return r;
+        }
     }
 };
 
@@ -108,7 +177,7 @@ template <class F> int tsparsifier(const F &f, const SparseMat<typename F::Elt> 
 int main(int argc, char **argv)
 {
     if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
-    Fmt fmt = PRETTY; std::string filename; size_t maxnumcoeff = 11, blocksize = 4; bool initialElimination = true; uint64_t q = 0; int gpu = 1;
+    Fmt fmt = PRETTY; std::string filename; size_t maxnumcoeff = 11, blocksize = 4; bool initialElimination = true; uint64_t q = 0; int gpu = 1; bool gpu_q = true;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
         if (a == "-h") {
@@ -117,7 +186,8 @@ int main(int argc, char **argv)
                       << "  -b #: states the blocking dimension (default " << blocksize << ")\n"
                       << "  -U [1|0]: initial LU factorization (default) or not\n"
                       << "  -M/-P/-S/-L: selects the ouput format\n"
-                      << "  --gpu #: 1 = enumerate the candidate rows on the MI355X (default with -q), 0 = host only\n";
+                      << "  --gpu #: 1 = enumerate the candidate rows on the MI355X (default), 0 = host only\n"
+                      << "  --host-q: without -q (rationals) enumerate on the host (default: on the GPU modulo two primes, winners checked over Q)\n";
             exit(-1);
         } else if (a == "-q" && i + 1 < argc) q = strtoull(argv[++i], nullptr, 10);
         else if (a == "-M") fmt = MAPLE;
@@ -128,6 +198,7 @@ int main(int argc, char **argv)
         else if (a == "-b" && i + 1 < argc) blocksize = strtoull(argv[++i], nullptr, 10);
         else if (a == "-U" && i + 1 < argc) initialElimination = atoi(argv[++i]) != 0;
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+        else if (a == "--host-q") gpu_q = false;
         else filename = a;
     }
     try {
@@ -148,7 +219,17 @@ int main(int argc, char **argv)
             CobHostBackend<ZpField> B;
             return tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
         }
-        QField f; CobHostBackend<QField> B;
+        QField f;
+        if (gpu > 0 && gpu_q) {
+            // over the rationals, as the reference runs it (src/sparsifier.cpp:66-83): the enumeration on the GPU modulo two primes, winners checked over Q
+            HipCob L;
+            if (!L.load() || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return 2; }
+            CobGpuQBackend B(L);
+            int rc = tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
+            std::clog << "# GPU (Q, two 31-bit primes + check over Q): " << B.gpu_calls << " enumerations, kernels " << B.kernel_ms << " ms, " << B.fallbacks << " on the host" << std::endl;
+            return rc;
+        }
+        CobHostBackend<QField> B;
         return tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
     } catch (const std::exception &e) {
         std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m" << std::endl;

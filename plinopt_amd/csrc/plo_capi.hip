@@ -346,7 +346,7 @@ int build_big_plan(plo_plan *pl)
     // dynamic LDS, in words: histogram, tables of the mode, then max(ProgramGen scratch, aggregation table: 2^aggbits entries of 8 bytes, 6 in mode 2)
     const uint32_t agg_words = B.mode == 2u ? (1u << B.aggbits) + (1u << B.aggbits) / 2u : 2u << B.aggbits;
     const uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, agg_words);
-    const uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + (B.nv * B.nv + 3u) / 4u * 2u + (B.nr + 3u) / 4u * 2u + (PLO_BIG_THREADS / 64) * PLO_RING : 0u;
+    const uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + (B.nv * B.nv + 3u) / 4u * 2u + (B.nr + 3u) / 4u * 2u + (1u << B.aggbits) / 2u : 0u;   // mode 2: ratio values, ratio ids, inverse ids, slot list of the aggregation table
     pl->big_lds = (((B.maxf0 + 2u) & ~1u) + tab_words + scr_words) * 4u;
     if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
     HIPCHK(hipFuncSetAttribute(B.mode == 2u ? (const void *)plo::cse_big_kernel<2> : B.mode == 1u ? (const void *)plo::cse_big_kernel<1> : (const void *)plo::cse_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
@@ -410,7 +410,7 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
                     g2[c_ * 8 + 0] / 1e5 / g2[32], g2[c_ * 8 + 1] / 1e5 / g2[32], g2[c_ * 8 + 2] / 1e5 / g2[32], g2[c_ * 8 + 3] / 1e5 / g2[32], g2[c_ * 8 + 4] / 1e5 / g2[32], (g2[c_ * 8 + 6] + g2[c_ * 8 + 5]) / 1e5 / g2[32], g2[c_ * 8 + 7] / 1e5 / g2[32]); } } }
             { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[3]) fprintf(stderr, "#   sweep of the steps with >= 256 rows, all candidates: %llu trips by %llu wave-sweeps; cycles per trip: chunk wait + stores %.0f, aggregation of both chunks %.0f, rest of the loop %.0f; per wave-sweep %.0f cycles, %.1f trips\n", gp[3], gp[5], (double)gp[0] / gp[3], (double)gp[1] / gp[3], (double)gp[2] / gp[3], (double)gp[4] / gp[5], (double)gp[3] / gp[5]); }
             { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && (gp[14] || gp[15])) fprintf(stderr, "#   flush 1, all candidates: entries whose pair with a has a as SECOND column %llu, with b %llu\n", gp[14], gp[15]); }
-            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[11]) fprintf(stderr, "#   flush 1 of the steps with >= 256 rows: %llu wave-trips by %llu wave-flushes; cycles per trip: decode %.0f, probes + atomics %.0f, bookkeeping %.0f; per wave-flush %.0f cycles, %.1f trips\n", gp[11], gp[13], (double)gp[8] / gp[11], (double)gp[9] / gp[11], (double)gp[10] / gp[11], (double)gp[12] / gp[13], (double)gp[11] / gp[13]); }
+            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[11]) fprintf(stderr, "#   flush 1 of the steps with >= 256 rows: %llu wave-trips by %llu wave-flushes; cycles per trip: fetch + decode %.0f, probe loads %.0f, stores + bookkeeping %.0f; per wave-flush %.0f cycles, %.1f trips\n", gp[11], gp[13], (double)gp[8] / gp[11], (double)gp[9] / gp[11], (double)gp[10] / gp[11], (double)gp[12] / gp[13], (double)gp[11] / gp[13]); }
             fprintf(stderr, "#   steps by rows/step [>=256, 64.., 16.., <16]: %u %u %u %u; sweep1 us %u %u %u %u; sweep2 us %u %u %u %u; fallbacks %u %u; flushed keys %u %u\n",
                     hs[24], hs[25], hs[26], hs[27], hs[16], hs[17], hs[18], hs[19], hs[20], hs[21], hs[22], hs[23], hs[28], hs[29], hs[30], hs[31]);
 #endif

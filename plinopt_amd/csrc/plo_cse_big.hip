@@ -104,6 +104,7 @@ template <class T> __device__ __forceinline__ T wg_cas(T *p, T expected, T desir
     return expected;
 }
 __device__ __forceinline__ uint64_t gload64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
+__device__ __forceinline__ void gstore64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
 __device__ __forceinline__ uint32_t gload32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PLO_BIG_SCOPE); }
 __device__ __forceinline__ uint32_t ghash(uint64_t key, uint32_t hbits) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
@@ -217,7 +218,7 @@ __device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint3
 // A probe ROUND looks at PLO_GWIN consecutive slots at once (their loads are in flight together): a wave leaves a probe
 // loop only when its slowest lane does, and with one slot per round that lane needed 5-8 dependent memory round trips.
 #ifndef PLO_GWIN
-#define PLO_GWIN 2u
+#define PLO_GWIN 1u
 #endif
 #ifndef PLO_FLUSH_AUTO
 #define PLO_FLUSH_AUTO 1    /* lane-autonomous flush (0: lock-step trips of PLO_FLU entries) */
@@ -363,7 +364,7 @@ __device__ unsigned long long g_prof[16];      // thread 0 of every workgroup, s
 #define PROF_T(k_) do { } while (0)
 #endif
 #define PLO_AGG_LIST (PLO_BIG_SELCAP * 4u)     // slot list (u16) kept in the tie-selection buffer, idle during the sweeps
-__device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_t acb, uint64_t key, uint32_t hk, uint32_t *aggn, uint16_t *agglist) {
+__device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_t acb, uint64_t key, uint32_t hk, uint32_t *aggn, uint16_t *agglist, uint32_t listcap) {
     const uint32_t mask = (1u << aggbits) - 1u;
     const uint64_t EMPTY = ~0ull << acb;
     uint32_t s = (hk * 0x9E3779B1u) >> (32u - aggbits);       // hk: 32 bits that determine the key ((column, ratio) on config 5)
@@ -392,7 +393,7 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
         if (claimed != 0xFFFFFFFFu) {
             const uint32_t idx = base + (uint32_t)__builtin_popcountll(cm & ((1ull << lane) - 1ull));
-            if (idx < PLO_AGG_LIST) agglist[idx] = (uint16_t)claimed;
+            if (idx < listcap) agglist[idx] = (uint16_t)claimed;
         }
     }
     return done;
@@ -402,9 +403,8 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_
 // (column << 10 | ratio identifier) in a u32 key array and a u16 count array -- 6 bytes per entry instead of 8, 32-bit
 // LDS operations, and no modular product in the sweep (the identifier comes from a 2-byte table lookup).
 #define PLO_RIDB 10u
-#define PLO_RING 256u                         // keys per wave in the sweep's ring (mode 2)
-struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint32_t *ring; };
-__device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *aggn, uint16_t *agglist) {
+struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint16_t *list; };   // list: mode 2, one u16 per aggregation slot
+__device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *aggn, uint16_t *agglist, uint32_t listcap) {
     const uint32_t mask = (1u << aggbits) - 1u;
     uint32_t s = (key * 0x9E3779B1u) >> (32u - aggbits);
     uint32_t claimed = 0xFFFFFFFFu; bool done = false;
@@ -430,7 +430,7 @@ __device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, ui
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
         if (claimed != 0xFFFFFFFFu) {
             const uint32_t idx = base + (uint32_t)__builtin_popcountll(cm & ((1ull << lane) - 1ull));
-            if (idx < PLO_AGG_LIST) agglist[idx] = (uint16_t)claimed;
+            if (idx < listcap) agglist[idx] = (uint16_t)claimed;
         }
     }
     return done;
@@ -484,10 +484,13 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
     // (MODE is a template parameter: the compiler turns a run-time choice between the two address spaces into a flat load)
     const uint2 *vtg = P.vt; const uint2 *vts = TB.vts;
     auto VT = [&](uint32_t vi) -> uint2 { if constexpr (MODE == 1) return vts[vi]; else return vtg[vi]; };
-    const uint16_t *rtid = TB.rtid, *invid = TB.invid; const uint32_t *rval = TB.rval; const uint32_t nv = P.nv; uint32_t *ringbase = TB.ring;   // mode 2
+    const uint16_t *rtid = TB.rtid, *invid = TB.invid; const uint32_t *rval = TB.rval; const uint32_t nv = P.nv;   // mode 2
     uint32_t *aggk = (uint32_t *)agg, *aggc32 = aggk + (1u << aggbits); uint16_t *aggc16 = (uint16_t *)aggc32;      // mode 2: key array, count array
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
-    uint16_t *agglist = (uint16_t *)sh.sel;       // slots claimed in the aggregation table by the running sweep
+    // slots claimed in the aggregation table by the running sweep (the flush walks this list, not the table): mode 2 has room
+    // for every slot; the other modes keep a short list in the tie-selection buffer, idle during the sweeps, and walk the
+    // table when a step claims more
+    uint16_t *agglist = MODE == 2 ? TB.list : (uint16_t *)sh.sel; const uint32_t listcap = MODE == 2 ? (1u << aggbits) : PLO_AGG_LIST;
     uint64_t *spill = (uint64_t *)(ws + P.o_spill); const uint32_t spillcap = P.nnz + 64u;   // new-column pairs of entries that found no room in LDS (a step touches every entry at most once)
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
     const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
@@ -672,6 +675,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
         if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; }
         BSYNC();
+#define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
         {   // rows holding the triple: walk the shorter row list of the two columns
             const uint32_t *la, *lb; uint32_t na, nb;
             if (a < n) { la = P.trows + P.tptr[a]; na = P.tptr[a + 1] - P.tptr[a]; } else { la = ncr + ncrptr[a - n]; na = ncrptr[a - n + 1] - ncrptr[a - n]; }
@@ -747,7 +751,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 if constexpr (MODE == 2) {
                     const uint32_t vi = PLO_EVI(e), via = PLO_EVI(ea_);
                     const uint32_t yid = rtid[via * nv + vi], xid = c < a ? yid : (uint32_t)rtid[vi * nv + via];
-                    if (agg_add_rid(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, &sh.aggn, agglist)) return;
+                    if (agg_add_rid(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, &sh.aggn, agglist, listcap)) return;
                     const uint32_t vib = PLO_EVI(eb_), bc = rval[rtid[vib * nv + vi]];                       // v_b / v_c
                     x = rval[xid]; y = rval[yid];
                     q2 = c < b ? bc : rval[rtid[vi * nv + vib]];
@@ -757,7 +761,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                     y = bmul(VA.x, V.y, p, mu, mers);
                     x = c < a ? y : bmul(V.x, VA.y, p, mu, mers);
                     const uint64_t cx = ((uint64_t)c << rb) | x;
-                    if (agg_add(agg, aggbits, acb, P.agg_dual ? (cx << rb) | y : cx, (uint32_t)cx ^ ((uint32_t)(cx >> 32) * 0x85EBCA6Bu), &sh.aggn, agglist)) return;
+                    if (agg_add(agg, aggbits, acb, P.agg_dual ? (cx << rb) | y : cx, (uint32_t)cx ^ ((uint32_t)(cx >> 32) * 0x85EBCA6Bu), &sh.aggn, agglist, listcap)) return;
                     q2 = c < b ? bmul(VB.x, V.y, p, mu, mers) : bmul(V.x, VB.y, p, mu, mers);
                     ins = bmul(l0 == a ? VA.x : VB.x, V.y, p, mu, mers);
                 }
@@ -788,121 +792,10 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             // (clamped index, length 0 past the end): no branch around a load.  In-place rewrite: a chunk's stores reach back
             // at most two positions and never forward, the chunks of a row are worked on in order by one wave, and a chunk
             // is loaded before the chunks before it are stored -- so no load sees a store.
-#define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
             const uint32_t nrw = naff > wave ? (naff - wave + nwaves - 1u) / nwaves : 0u;      // rows of this wave: wave, wave + nwaves, ...
 #ifdef PLO_BIG_PROFILE
             unsigned long long pw0 = 0, pw1 = 0, pw2 = 0, ptr = 0, tl_ = clock64(); const unsigned long long ts_ = tl_;
 #endif
-#ifndef PLO_BIG_RING_SWEEP
-#define PLO_BIG_RING_SWEEP 0      /* measured slower than the two-row loop (0.48 s against 0.30 s of sweep per candidate): kept for reference */
-#endif
-            if constexpr (MODE == 2 && PLO_BIG_RING_SWEEP) {
-                // Mode 2: the aggregation key of an entry is 25 bits and names everything the flush needs, so the sweep is
-                // split into a PRODUCER (lock step: load a chunk, rewrite the row, compute 64 keys, append them to a ring of
-                // keys private to the wave) and a CONSUMER in which every lane owns one key at a time, probes two slots per
-                // round and takes the next key from the ring as soon as its own is settled.  A round then costs the
-                // AVERAGE number of probes of a key, not the maximum over the 64 keys of a chunk (which is 3-4 rounds at
-                // the table loads of the big steps, each an LDS round trip).
-                uint32_t *ring = ringbase + wave * PLO_RING;
-                uint32_t head = 0, tail = 0;                                   // wave-uniform, monotonic
-                uint32_t key = 0xFFFFFFFFu, slot = 0, probes = 0;              // the lane's key in flight (none: all ones)
-                uint32_t k0 = 0, ck = 0, cz = 0, cnt = 0;                      // block of records, row in the block, offset in the row
-                uint32_t Rpp = 0, Rbase = 0, RL_ = 0, Rea = 0, Reb = 0, eNext = 0;
-                bool more = nrw > 0u, fresh = true;
-                const uint64_t lt = (1ull << lane) - 1ull;
-                for (;;) {
-                    if (more && tail - head <= PLO_RING - 64u) {
-                        if (fresh) {                                           // records of the next 64 rows, and the first chunk
-                            const bool have = k0 + lane < nrw;
-                            const uint32_t qq = have ? wave + (k0 + lane) * nwaves : wave;
-                            const uint4 R0 = *(const uint4 *)(aff + 8u * qq); const uint2 R1 = *(const uint2 *)(aff + 8u * qq + 4u);
-                            Rpp = R0.y; Rbase = R0.z; RL_ = have ? R0.w : 0u; Rea = R1.x; Reb = R1.y;
-                            cnt = nrw - k0 < 64u ? nrw - k0 : 64u; ck = 0; cz = 0; fresh = false;
-                            const uint32_t L0 = RL(RL_, 0);
-                            eNext = ent[RL(Rbase, 0) + (lane < L0 ? lane : 0u)];
-                        }
-                        const uint32_t L = RL(RL_, ck), base = RL(Rbase, ck), pp = RL(Rpp, ck), ea_ = RL(Rea, ck), eb_ = RL(Reb, ck);
-                        const uint32_t pa = pp & 0xFFFFu, pb = pp >> 16, z = cz + lane, e = eNext;
-                        // cursor of the following chunk, requested now
-                        uint32_t nk = ck, nz = cz + 64u;
-                        if (nz >= L) { nk = ck + 1u; nz = 0u; }
-                        { const uint32_t kx = nk & 63u, Ln = nk < cnt ? RL(RL_, kx) : 0u, zn = nz + lane; eNext = ent[RL(Rbase, kx) + (zn < Ln ? zn : 0u)]; }
-                        const bool act = z < L && z != pa && z != pb;
-                        // the row is rewritten in the same pass (:96-110): entries right of the first removed position shift left
-                        if (act && z > pa) ent[base + z - 1u - (z > pb ? 1u : 0u)] = e;
-                        if (nz == 0u && lane == 0) ent[base + L - 2u] = (((l0 == a) ? ea_ : eb_) & 0xFFFF8000u) | lm;   // last chunk: the new column's entry goes last
-                        // keys of the chunk, compacted into the ring
-                        const uint32_t c = PLO_ECOL(e), vi = PLO_EVI(e), via = PLO_EVI(ea_);
-                        const uint32_t yid = rtid[via * nv + (act ? vi : 0u)], xid = c < a ? yid : (uint32_t)rtid[(act ? vi : 0u) * nv + via];
-                        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
-                        if (act) __hip_atomic_store(&ring[(tail + (uint32_t)__builtin_popcountll(am & lt)) & (PLO_RING - 1u)], (c << PLO_RIDB) | xid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        tail += (uint32_t)__builtin_popcountll(am);
-                        ck = nk; cz = nz;
-                        if (ck >= cnt) { k0 += 64u; fresh = true; more = k0 < nrw; }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    // lanes without a key take the next ones of the ring
-                    {
-                        const uint64_t need = __builtin_amdgcn_ballot_w64(key == 0xFFFFFFFFu);
-                        const uint32_t avail = tail - head, rank = (uint32_t)__builtin_popcountll(need & lt);
-                        if (key == 0xFFFFFFFFu && rank < avail) {
-                            key = __hip_atomic_load(&ring[(head + rank) & (PLO_RING - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            slot = (key * 0x9E3779B1u) >> (32u - aggbits); probes = 0;
-                        }
-                        const uint32_t want = (uint32_t)__builtin_popcountll(need);
-                        head += want < avail ? want : avail;
-                    }
-                    if (!__builtin_amdgcn_ballot_w64(key != 0xFFFFFFFFu)) { if (!more && head == tail) break; continue; }
-                    // one round: two slots per lane
-                    uint32_t claimed = 0xFFFFFFFFu;
-                    if (key != 0xFFFFFFFFu) {
-                        const uint32_t amask = (1u << aggbits) - 1u, s1 = (slot + 1u) & amask;
-                        const uint32_t q0 = __hip_atomic_load(&aggk[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), q1 = __hip_atomic_load(&aggk[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const bool hit0 = q0 == key, emp0 = q0 == 0xFFFFFFFFu, first = hit0 || emp0;
-                        const bool hit = hit0 || (!emp0 && q1 == key), emp = emp0 || (!hit && q1 == 0xFFFFFFFFu);
-                        const uint32_t t = first ? slot : s1;
-                        if (hit) { wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); key = 0xFFFFFFFFu; }
-                        else if (emp) {
-                            const uint32_t old = wg_cas(&aggk[t], 0xFFFFFFFFu, key);
-                            if (old == 0xFFFFFFFFu || old == key) { if (old != key) claimed = t; wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); key = 0xFFFFFFFFu; }
-                            // else: somebody took the slot for another key: look at both again next round
-                        } else {
-                            slot = (slot + 2u) & amask; probes += 2u;
-                            if (probes >= PLO_AGG_PROBES) {
-                                // no room in the LDS table (the key then stays out of it for the whole sweep): retire in HBM directly;
-                                // everything follows from the key, as in the flush.  An absent triple had frequency 1 (pruned).
-                                const uint32_t c = key >> PLO_RIDB, xid = key & ((1u << PLO_RIDB) - 1u);
-                                const uint32_t x = rval[xid], y = rval[c > a ? (uint32_t)invid[xid] : xid];
-                                const uint32_t ry = bmul(r, y, p, mu, mers), q2 = c < b ? ry : bmul(x, sh.invr, p, mu, mers);
-                                const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x), k2 = c < b ? BKEY(c, b, q2) : BKEY(b, c, q2);
-                                const uint32_t o1 = gtab_dec(tab, k1, hbits);
-                                if (o1) {
-                                    wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
-                                    if (o1 == M) { wg_sub(&cntM[c < a ? c : a], 1u); wg_sub(&sh.cblk[(c < a ? c : a) >> 6], 1u); }
-                                }
-                                const uint32_t o2 = gtab_dec(tab, k2, hbits);
-                                if (o2) {
-                                    wg_sub(&hist[o2], 1u); if (o2 > 1u) wg_add(&hist[o2 - 1u], 1u);
-                                    if (o2 == M) { wg_sub(&cntM[c < b ? c : b], 1u); wg_sub(&sh.cblk[(c < b ? c : b) >> 6], 1u); }
-                                }
-                                const uint32_t idx = wg_add(&sh.nspill, 1u);
-                                if (idx < spillcap) spill[idx] = BKEY(c, lm, l0 == a ? y : ry); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
-                                key = 0xFFFFFFFFu;
-                            }
-                        }
-                    }
-                    // new entries: remember their slots (the flush walks the entries, not the table); one counter update per wave
-                    const uint64_t cm = __builtin_amdgcn_ballot_w64(claimed != 0xFFFFFFFFu);
-                    if (cm) {
-                        const uint32_t leader = (uint32_t)__builtin_ctzll(cm);
-                        uint32_t bs = 0;
-                        if (lane == leader) bs = wg_add(&sh.aggn, (uint32_t)__builtin_popcountll(cm));
-                        bs = RL(bs, leader);
-                        if (claimed != 0xFFFFFFFFu) { const uint32_t idx = bs + (uint32_t)__builtin_popcountll(cm & lt); if (idx < PLO_AGG_LIST) agglist[idx] = (uint16_t)claimed; }
-                    }
-                }
-            } else
             for (uint32_t k0 = 0; k0 < nrw; k0 += 64u) {
                 // two rows per trip; the first chunks of the next pair are requested before the current pair is worked on
                 const bool have = k0 + lane < nrw;
@@ -956,11 +849,11 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                     baseA = nbaseA; LA = nLA; baseB = nbaseB; LB = nLB; eA = nfA; eB = nfB;
                 }
             }
-#undef RL
 #ifdef PLO_BIG_PROFILE
             if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[0], pw0); atomicAdd(&sh.pw[1], pw1); atomicAdd(&sh.pw[2], pw2); atomicAdd(&sh.pw[3], ptr); atomicAdd(&sh.pw[4], clock64() - ts_); atomicAdd(&sh.pw[5], 1ull); }
 #endif
         }
+#undef RL
         BSYNC();
 #ifdef PLO_BIG_PROFILE
         if (tid == 0) { const int cl = M >= 256u ? 0 : M >= 64u ? 1 : M >= 16u ? 2 : 3; sh.tb1[cl] += wall_clock64() - tstamp; ++sh.nb[cl]; }
@@ -979,17 +872,25 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 if (o == M) { wg_sub(&cntM[(uint32_t)(k >> abits)], 1u); wg_sub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
             };
             if (tid == 0) retired(key, M, gtab_subn(tab, key, M, hbits));
-            const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
+            const uint32_t nent = sh.aggn, nslot = nent <= listcap ? nent : (1u << aggbits);
 #if PLO_FLUSH_AUTO
             // Every lane runs its own entries: it takes the next one as soon as both keys of the current one are settled, so
-            // a probe round costs the wave one memory round trip whatever the other lanes' probe lengths are, and the
-            // atomics of a settled entry are in flight during the next entry's first round (their results are booked one
-            // trip later; memory operations return in order, so waiting for them does not wait for the newer loads).
+            // a probe round costs the wave one memory round trip whatever the other lanes' probe lengths are.  The keys of
+            // the entries are all different (and different from the chosen triple), so every slot has ONE writer in this
+            // pass: the new frequency is a plain store of the word the probe has just read -- no read-modify-write atomic
+            // (tests/micro/random_access.hip: the chip sustains 27 G table atomics/s however local they are, against
+            // 50-900 G loads/s; 1.2e7 of them per candidate were a third of the step).
             {
-                const uint32_t tmask = (1u << hbits) - 1u; const bool bylist = nent <= PLO_AGG_LIST;
-                uint32_t e = tid; bool busy = false, prev = false, p1 = false, p2 = false, m1 = false, m2 = false, pm1 = false, pm2 = false;
-                uint64_t k1 = 0, k2 = 0, pk1 = 0, pk2 = 0; unsigned long long a1 = 0, a2 = 0; uint32_t d = 0, pd = 0, s1 = 0, s2 = 0;
+                const uint32_t tmask = (1u << hbits) - 1u; const bool bylist = nent <= listcap;
+                uint32_t e = tid; bool busy = false, p1 = false, p2 = false;
+                uint64_t k1 = 0, k2 = 0; uint32_t d = 0, s1 = 0, s2 = 0;
+#ifdef PLO_BIG_PROFILE
+                unsigned long long fq0 = 0, fq1 = 0, fq2 = 0, fqn = 0; const unsigned long long fts = clock64(); uint32_t nfl1 = 0;
+#endif
                 for (;;) {
+#ifdef PLO_BIG_PROFILE
+                    const unsigned long long ft0 = clock64();
+#endif
                     if (!busy) {
                         while (e < nslot) {
                             const uint32_t s = bylist ? (uint32_t)agglist[e] : e; e += nth;
@@ -1011,45 +912,62 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                             const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
                             const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
                             k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x); k2 = c < b ? BKEY(c, b, x2) : BKEY(b, c, x2);
-                            s1 = ghash(k1, hbits); s2 = ghash(k2, hbits); p1 = p2 = true; m1 = m2 = false; busy = true;
+                            s1 = ghash(k1, hbits); s2 = ghash(k2, hbits); p1 = p2 = true; busy = true;
                             if constexpr (MODE != 2) agg[s] = (((((uint64_t)c) << rb) | (l0 == a ? y : ry)) << PLO_GVB) | d;    // (c, coeff / v_c), same count (mode 2: the second pass derives it again)
 #ifdef PLO_BIG_PROFILE
-                            wg_add(&sh.fl1, 1u); if (c < a) atomicAdd(&sh.pw[14], 1ull); if (c < b) atomicAdd(&sh.pw[15], 1ull);
+                            ++nfl1;
 #endif
                             break;
                         }
                     }
-                    if (!__builtin_amdgcn_ballot_w64(busy || prev)) break;
+                    if (!__builtin_amdgcn_ballot_w64(busy)) break;
+#ifdef PLO_BIG_PROFILE
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ft1 = clock64();
+#endif
                     uint64_t v1[PLO_GWIN], v2[PLO_GWIN];
 #pragma unroll
                     for (uint32_t j = 0; j < PLO_GWIN; ++j) {
                         v1[j] = (busy && p1) ? gload64(&tab[(s1 + j) & tmask]) : 0ull;
                         v2[j] = (busy && p2) ? gload64(&tab[(s2 + j) & tmask]) : 0ull;
                     }
-                    if (prev) {                                                 // the entry settled one trip ago
-                        retired(pk1, pd, pm1 ? (uint32_t)(a1 & PLO_GVMASK) : 0u); retired(pk2, pd, pm2 ? (uint32_t)(a2 & PLO_GVMASK) : 0u);
-                        prev = false;
-                    }
+#ifdef PLO_BIG_PROFILE
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ft2 = clock64();
+#endif
                     if (busy) {
                         if (p1) {
                             uint32_t adv = PLO_GWIN;
 #pragma unroll
-                            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p1) { if ((v1[j] >> PLO_GVB) == k1) { m1 = true; p1 = false; adv = j; } else if (v1[j] == PLO_GEMPTY) { p1 = false; adv = j; } }
+                            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p1) {
+                                if ((v1[j] >> PLO_GVB) == k1) {
+                                    p1 = false; adv = j; const uint32_t o = (uint32_t)(v1[j] & PLO_GVMASK);
+                                    if (o >= d) gstore64(&tab[(s1 + j) & tmask], v1[j] - (uint64_t)d);
+                                    retired(k1, d, o);
+                                } else if (v1[j] == PLO_GEMPTY) { p1 = false; adv = j; }                  // not in the table: a triple of frequency 1 (pruned)
+                            }
                             s1 = (s1 + adv) & tmask;
                         }
                         if (p2) {
                             uint32_t adv = PLO_GWIN;
 #pragma unroll
-                            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p2) { if ((v2[j] >> PLO_GVB) == k2) { m2 = true; p2 = false; adv = j; } else if (v2[j] == PLO_GEMPTY) { p2 = false; adv = j; } }
+                            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p2) {
+                                if ((v2[j] >> PLO_GVB) == k2) {
+                                    p2 = false; adv = j; const uint32_t o = (uint32_t)(v2[j] & PLO_GVMASK);
+                                    if (o >= d) gstore64(&tab[(s2 + j) & tmask], v2[j] - (uint64_t)d);
+                                    retired(k2, d, o);
+                                } else if (v2[j] == PLO_GEMPTY) { p2 = false; adv = j; }
+                            }
                             s2 = (s2 + adv) & tmask;
                         }
-                        if (!p1 && !p2) {
-                            if (m1) a1 = wg_add((unsigned long long *)&tab[s1], (unsigned long long)(0ull - (uint64_t)d));
-                            if (m2) a2 = wg_add((unsigned long long *)&tab[s2], (unsigned long long)(0ull - (uint64_t)d));
-                            pk1 = k1; pk2 = k2; pd = d; pm1 = m1; pm2 = m2; prev = m1 || m2; busy = false;
-                        }
+                        busy = p1 || p2;
                     }
+#ifdef PLO_BIG_PROFILE
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); { const unsigned long long ft3 = clock64(); fq0 += ft1 - ft0; fq1 += ft2 - ft1; fq2 += ft3 - ft2; ++fqn; }
+#endif
                 }
+#ifdef PLO_BIG_PROFILE
+                wg_add(&sh.fl1, nfl1);
+                if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[8], fq0); atomicAdd(&sh.pw[9], fq1); atomicAdd(&sh.pw[10], fq2); atomicAdd(&sh.pw[11], fqn); atomicAdd(&sh.pw[12], clock64() - fts); atomicAdd(&sh.pw[13], 1ull); }
+#endif
             }
 #else
             // PLO_FLU entries per thread and trip: their 2 PLO_FLU probe sequences and atomics overlap
@@ -1065,7 +983,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
 #pragma unroll
                 for (int u = 0; u < (int)PLO_FLU; ++u) {
                     const uint32_t e = e0 + (uint32_t)u * nth; bool ok = e < nslot;
-                    const uint32_t s = ok ? (nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e) : 0u;
+                    const uint32_t s = ok ? (nent <= listcap ? (uint32_t)agglist[e] : e) : 0u;
                     uint32_t c = 0, x = 0, y = 0, d = 0;
                     if constexpr (MODE == 2) {
                         const uint32_t kq = ok ? aggk[s] : 0xFFFFFFFFu;
@@ -1127,13 +1045,13 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                     if (idx < P.dmcap) DM[idx] = k; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
                 }
             };
-            const uint32_t nent = sh.aggn, nslot = nent <= PLO_AGG_LIST ? nent : (1u << aggbits);
+            const uint32_t nent = sh.aggn, nslot = nent <= listcap ? nent : (1u << aggbits);
             for (uint32_t e0 = tid; e0 < nslot; e0 += PLO_FLU * nth) {
                 uint64_t kk[PLO_FLU]; uint32_t dd[PLO_FLU], oo[PLO_FLU]; bool lv[PLO_FLU];
 #pragma unroll
                 for (int u = 0; u < (int)PLO_FLU; ++u) {
                     const uint32_t e = e0 + (uint32_t)u * nth; bool ok = e < nslot;
-                    const uint32_t s = ok ? (nent <= PLO_AGG_LIST ? (uint32_t)agglist[e] : e) : 0u;
+                    const uint32_t s = ok ? (nent <= listcap ? (uint32_t)agglist[e] : e) : 0u;
                     uint64_t k = 0; uint32_t d = 0;
                     if constexpr (MODE == 2) {
                         const uint32_t kq = ok ? aggk[s] : 0xFFFFFFFFu;
@@ -1196,7 +1114,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 }
             }
         }
-        if (tid == 0) { ++sh.nbadd; ++sh.steps; sh.ncols = lm + 1u; sh.spilltot += sh.nspill; if (sh.aggn > PLO_AGG_LIST) ++sh.listover; }      // :292, :190-191
+        if (tid == 0) { ++sh.nbadd; ++sh.steps; sh.ncols = lm + 1u; sh.spilltot += sh.nspill; if (sh.aggn > listcap) ++sh.listover; }      // :292, :190-191
         PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(7);
     }
@@ -1474,7 +1392,7 @@ template <int MODE> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_bi
         for (uint32_t k = threadIdx.x; k < P.nr; k += blockDim.x) { rv[k] = P.rval[k]; iv[k] = P.invid[k]; }
         for (uint32_t k = threadIdx.x; k < P.nv * P.nv; k += blockDim.x) rt[k] = P.rtid[k];
         TB.rval = rv; TB.rtid = rt; TB.invid = iv;
-        TB.ring = nextw; nextw += (PLO_BIG_THREADS / 64) * PLO_RING;
+        TB.list = (uint16_t *)nextw; nextw += (1u << P.aggbits) / 2u;
     }
     uint32_t *scratch = nextw;                                     // ProgramGen scratch and the CSE aggregation table share this space
     uint64_t *agg = (uint64_t *)scratch;

@@ -89,6 +89,24 @@ def test_sparsifier_cli_gpu_equals_host(hip, name):
     assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)
 
 
+@pytest.mark.parametrize("name,c", [("4x4x4_49_156_L.sms", "4"), ("2x2x2_7_Winograd_L.sms", "6"), ("2x2x2_7_DPS-accurate_L.sms", "6"), ("4x4x4_48_rational_L.sms", "5"),
+                                    ("3x3x3_23_58_P.sms", "6")])
+def test_sparsifier_over_the_rationals_on_gpu_equals_host(hip, name, c):
+    """BASELINE configs[2] as written (`sparsifier -c 4 data/4x4x4_49_156_L.sms`, no -q): over Q, the field the reference runs it in
+    (src/sparsifier.cpp:66-83).  The enumeration runs on the GPU modulo two 31-bit primes, every winner is re-evaluated over Q;
+    same change of basis and residue as the host enumeration over Q, no (block, row) sent back to the host, consistent factorization."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+    path = os.path.join(DATA, name)
+    g = subprocess.run([SPS, "-c", c, "-S", path], capture_output=True, text=True, timeout=900)
+    h = subprocess.run([SPS, "-c", c, "-S", "--gpu", "0", path], capture_output=True, text=True, timeout=900)
+    assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
+    assert "SUCCESS: consistent factorization" in g.stderr
+    m = re.search(r"# GPU \(Q, two 31-bit primes \+ check over Q\): (\d+) enumerations, kernels [0-9.e+-]+ ms, (\d+) on the host", g.stderr)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) == 0, g.stderr
+    assert g.stdout == h.stdout
+    assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)
+
+
 @pytest.mark.parametrize("generic", [False, True])
 def test_cob_enumeration_sharded_by_prefix_equals_whole(hip, generic, monkeypatch):
     """N-GPU split of ONE enumeration (plo_cob_search_range): shards of (i,j,k) prefixes, then the MAX reduction of
