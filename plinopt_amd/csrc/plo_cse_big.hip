@@ -215,45 +215,15 @@ __device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint3
     }
     return 0u;
 }
-// A probe ROUND looks at PLO_GWIN consecutive slots at once (their loads are in flight together): a wave leaves a probe
-// loop only when its slowest lane does, and with one slot per round that lane needed 5-8 dependent memory round trips.
+// A probe round looks at PLO_GWIN consecutive slots at once (their loads are in flight together).  Measured on config 5:
+// 1 slot per round 648-659 candidates/s, 2 slots 634 -- the extra load instructions cost more than the rounds they save
+// (the table phases run at the memory system's request rate).
 #ifndef PLO_GWIN
 #define PLO_GWIN 1u
-#endif
-#ifndef PLO_FLUSH_AUTO
-#define PLO_FLUSH_AUTO 1    /* lane-autonomous flush (0: lock-step trips of PLO_FLU entries) */
 #endif
 #ifndef PLO_FLU
 #define PLO_FLU 2u       /* aggregated entries per thread and trip of the flush */
 #endif
-// frequency[key] -= d for two keys at once: both probe sequences and then both atomics are in flight together;
-// o1/o2 = the frequencies before, 0 = key not found
-__device__ __forceinline__ void gtab_subn2(uint64_t *tab, uint64_t k1, uint64_t k2, uint32_t d, uint32_t hbits, uint32_t &o1, uint32_t &o2) {
-    const uint32_t mask = (1u << hbits) - 1u;
-    uint32_t s1 = ghash(k1, hbits), s2 = ghash(k2, hbits);
-    bool p1 = true, p2 = true, m1 = false, m2 = false;
-    for (uint32_t pr = 0; pr < (1u << 22) && (p1 || p2); pr += PLO_GWIN) {
-        uint64_t v1[PLO_GWIN], v2[PLO_GWIN];
-#pragma unroll
-        for (uint32_t j = 0; j < PLO_GWIN; ++j) { v1[j] = gload64(&tab[(s1 + j) & mask]); v2[j] = gload64(&tab[(s2 + j) & mask]); }
-        if (p1) {
-            uint32_t adv = PLO_GWIN;
-#pragma unroll
-            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p1) { if ((v1[j] >> PLO_GVB) == k1) { m1 = true; p1 = false; adv = j; } else if (v1[j] == PLO_GEMPTY) { p1 = false; adv = j; } }
-            s1 = (s1 + adv) & mask;
-        }
-        if (p2) {
-            uint32_t adv = PLO_GWIN;
-#pragma unroll
-            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (p2) { if ((v2[j] >> PLO_GVB) == k2) { m2 = true; p2 = false; adv = j; } else if (v2[j] == PLO_GEMPTY) { p2 = false; adv = j; } }
-            s2 = (s2 + adv) & mask;
-        }
-    }
-    uint64_t a1 = 0, a2 = 0;
-    if (m1) a1 = wg_add((unsigned long long *)&tab[s1], (unsigned long long)(0ull - (uint64_t)d));
-    if (m2) a2 = wg_add((unsigned long long *)&tab[s2], (unsigned long long)(0ull - (uint64_t)d));
-    o1 = m1 ? (uint32_t)(a1 & PLO_GVMASK) : 0u; o2 = m2 ? (uint32_t)(a2 & PLO_GVMASK) : 0u;
-}
 // frequency[key] += d (claims the first empty or dead slot in probe order); returns the frequency before, 0xFFFFFFFF = table full
 __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint32_t d, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
@@ -279,37 +249,8 @@ __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint3
     return 0xFFFFFFFFu;
 }
 
-// N keys of one thread in lock step (the flush takes several aggregated entries per trip: the table is far larger than
-// the caches, every probe is a memory round trip, and only independent ones overlap).  live[q] = false: key q is skipped.
-template <int N> __device__ __forceinline__ void gtab_subnN(uint64_t *tab, const uint64_t (&key)[N], const uint32_t (&d)[N], const bool (&live)[N], uint32_t hbits, uint32_t (&o)[N]) {
-    const uint32_t mask = (1u << hbits) - 1u;
-    uint32_t s[N]; bool pend[N], hit[N];
-#pragma unroll
-    for (int q = 0; q < N; ++q) { s[q] = ghash(key[q], hbits); pend[q] = live[q]; hit[q] = false; }
-    for (uint32_t pr = 0; pr < (1u << 22); pr += PLO_GWIN) {
-        bool any = false;
-#pragma unroll
-        for (int q = 0; q < N; ++q) any |= pend[q];
-        if (!any) break;
-        uint64_t v[N][PLO_GWIN];
-#pragma unroll
-        for (int q = 0; q < N; ++q)
-#pragma unroll
-            for (uint32_t j = 0; j < PLO_GWIN; ++j) v[q][j] = pend[q] ? gload64(&tab[(s[q] + j) & mask]) : 0ull;
-#pragma unroll
-        for (int q = 0; q < N; ++q) if (pend[q]) {
-            uint32_t adv = PLO_GWIN;
-#pragma unroll
-            for (uint32_t j = 0; j < PLO_GWIN; ++j) if (pend[q]) { if ((v[q][j] >> PLO_GVB) == key[q]) { hit[q] = true; pend[q] = false; adv = j; } else if (v[q][j] == PLO_GEMPTY) { pend[q] = false; adv = j; } }
-            s[q] = (s[q] + adv) & mask;
-        }
-    }
-    uint64_t old[N];
-#pragma unroll
-    for (int q = 0; q < N; ++q) old[q] = hit[q] ? wg_add((unsigned long long *)&tab[s[q]], (unsigned long long)(0ull - (uint64_t)d[q])) : 0ull;
-#pragma unroll
-    for (int q = 0; q < N; ++q) o[q] = (uint32_t)(old[q] & PLO_GVMASK);
-}
+// N insertions of one thread in lock step (second flush pass: PLO_FLU entries per trip; the table is far larger than the
+// caches, every probe is a memory round trip, and only independent ones overlap).  live[q] = false: key q is skipped.
 template <int N> __device__ __forceinline__ void gtab_addnN(uint64_t *tab, const uint64_t (&key)[N], const uint32_t (&d)[N], const bool (&live)[N], uint32_t hbits, uint32_t (&o)[N]) {
     const uint32_t mask = (1u << hbits) - 1u;
     uint32_t s[N]; bool pend[N];
@@ -873,7 +814,6 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             };
             if (tid == 0) retired(key, M, gtab_subn(tab, key, M, hbits));
             const uint32_t nent = sh.aggn, nslot = nent <= listcap ? nent : (1u << aggbits);
-#if PLO_FLUSH_AUTO
             // Every lane runs its own entries: it takes the next one as soon as both keys of the current one are settled, so
             // a probe round costs the wave one memory round trip whatever the other lanes' probe lengths are.  The keys of
             // the entries are all different (and different from the chosen triple), so every slot has ONE writer in this
@@ -969,64 +909,6 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[8], fq0); atomicAdd(&sh.pw[9], fq1); atomicAdd(&sh.pw[10], fq2); atomicAdd(&sh.pw[11], fqn); atomicAdd(&sh.pw[12], clock64() - fts); atomicAdd(&sh.pw[13], 1ull); }
 #endif
             }
-#else
-            // PLO_FLU entries per thread and trip: their 2 PLO_FLU probe sequences and atomics overlap
-#ifdef PLO_BIG_PROFILE
-            unsigned long long fq0 = 0, fq1 = 0, fq2 = 0, fqn = 0; const unsigned long long fts = clock64();
-#endif
-            for (uint32_t e0 = tid; e0 < nslot; e0 += PLO_FLU * nth) {
-#ifdef PLO_BIG_PROFILE
-                const unsigned long long ft0 = clock64();
-#endif
-                uint64_t kk[2 * PLO_FLU]; uint32_t dd[2 * PLO_FLU], oo[2 * PLO_FLU]; bool lv[2 * PLO_FLU];
-                uint32_t cs[PLO_FLU], ss[PLO_FLU], ins[PLO_FLU];
-#pragma unroll
-                for (int u = 0; u < (int)PLO_FLU; ++u) {
-                    const uint32_t e = e0 + (uint32_t)u * nth; bool ok = e < nslot;
-                    const uint32_t s = ok ? (nent <= listcap ? (uint32_t)agglist[e] : e) : 0u;
-                    uint32_t c = 0, x = 0, y = 0, d = 0;
-                    if constexpr (MODE == 2) {
-                        const uint32_t kq = ok ? aggk[s] : 0xFFFFFFFFu;
-                        ok = kq != 0xFFFFFFFFu;
-                        if (ok) { d = aggc16[s]; c = kq >> PLO_RIDB; const uint32_t xid = kq & ((1u << PLO_RIDB) - 1u); x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid]; }
-                    } else {
-                        const uint64_t v = ok ? agg[s] : AEMPTY;
-                        ok = v != AEMPTY;
-                        if (ok) {
-                            uint64_t k = v >> acb; d = (uint32_t)(v & ((1ull << acb) - 1ull));
-                            if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
-                            c = (uint32_t)(k >> rb); x = (uint32_t)(k & ((1ull << rb) - 1ull));
-                            if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
-                        }
-                    }
-                    const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
-                    const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
-                    kk[2 * u] = c < a ? BKEY(c, a, x) : BKEY(a, c, x); kk[2 * u + 1] = c < b ? BKEY(c, b, x2) : BKEY(b, c, x2);
-                    dd[2 * u] = dd[2 * u + 1] = d; lv[2 * u] = lv[2 * u + 1] = ok; cs[u] = c; ss[u] = s; ins[u] = l0 == a ? y : ry;
-#ifdef PLO_BIG_PROFILE
-                    if (ok) wg_add(&sh.fl1, 1u);
-#endif
-                }
-#ifdef PLO_BIG_PROFILE
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ft1 = clock64();
-#endif
-                gtab_subnN<2 * PLO_FLU>(tab, kk, dd, lv, hbits, oo);
-#ifdef PLO_BIG_PROFILE
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ft2 = clock64();
-#endif
-#pragma unroll
-                for (int u = 0; u < (int)PLO_FLU; ++u) if (lv[2 * u]) {
-                    retired(kk[2 * u], dd[2 * u], oo[2 * u]); retired(kk[2 * u + 1], dd[2 * u], oo[2 * u + 1]);
-                    if constexpr (MODE != 2) agg[ss[u]] = (((((uint64_t)cs[u]) << rb) | ins[u]) << PLO_GVB) | dd[2 * u];    // (c, coeff / v_c), same count (mode 2: the second pass derives it again)
-                }
-#ifdef PLO_BIG_PROFILE
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); { const unsigned long long ft3 = clock64(); fq0 += ft1 - ft0; fq1 += ft2 - ft1; fq2 += ft3 - ft2; ++fqn; }
-#endif
-            }
-#ifdef PLO_BIG_PROFILE
-            if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[8], fq0); atomicAdd(&sh.pw[9], fq1); atomicAdd(&sh.pw[10], fq2); atomicAdd(&sh.pw[11], fqn); atomicAdd(&sh.pw[12], clock64() - fts); atomicAdd(&sh.pw[13], 1ull); }
-#endif
-        #endif
         }
         PLO_BIG_FENCE(); BSYNC();
         PLO_STAMP(4);

@@ -31,6 +31,15 @@
 
 namespace plo {
 
+// waves per SIMD the wave kernels are compiled for (register budget 512 / waves): the kernels are LDS-latency bound, more
+// resident waves hide more of it
+#ifndef PLO_WAVE_OCC_UNIT
+#define PLO_WAVE_OCC_UNIT 7
+#endif
+#ifndef PLO_WAVE_OCC_GEN
+#define PLO_WAVE_OCC_GEN 4
+#endif
+
 struct WavePlan {
     uint32_t m, n, nnz, p, NC, cap, hbits, lpr_log2, mw, unit, multcap, maxlen;
     uint32_t rb, bb;        // bits of a ratio (p-1) and of a column index (NC-1): 2*bb+rb <= 44
@@ -601,7 +610,7 @@ __device__ __forceinline__ uint32_t cost_key32(uint32_t a, uint32_t mu_, uint32_
 }
 
 template <bool UNIT>
-__global__ __launch_bounds__(256) void cse_wave_kernel(WavePlan P, WaveJob J)
+__global__ __launch_bounds__(256, UNIT ? PLO_WAVE_OCC_UNIT : PLO_WAVE_OCC_GEN) void cse_wave_kernel(WavePlan P, WaveJob J)
 {
     extern __shared__ uint64_t lds64[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
