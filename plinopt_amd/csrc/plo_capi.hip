@@ -447,6 +447,14 @@ int launch(plo_plan *pl, plo::WaveJob J, plo_stats_t *st, float *ms_out)
     HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (ms_out) *ms_out = ms;
     if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = W; st->algo_bytes = pl->algo_bytes; }
+#ifdef PLO_WAVE_PROFILE
+    if (getenv("PLO_WAVE_STATS")) {
+        unsigned long long g[12] = {0};
+        if (hipMemcpyFromSymbol(g, HIP_SYMBOL(plo::g_wprof), sizeof g) == hipSuccess && g[9])
+            fprintf(stderr, "# wave kernel, cumulative: %llu candidates, %.1f steps each; cycles per step: max scan %.0f, tie list %.0f, tie pick %.0f, sweep 1 %.0f, sweep 2 %.0f, tail %.0f\n",
+                    g[9], (double)g[8] / g[9], (double)g[0] / g[8], (double)g[1] / g[8], (double)g[2] / g[8], (double)g[3] / g[8], (double)g[4] / g[8], (double)g[5] / g[8]);
+    }
+#endif
     return (int)err;   // >0: device error word
 }
 
@@ -471,7 +479,7 @@ int run_job(plo_plan *pl, plo::WaveJob J, plo_stats_t *st)
         pl->cap_scale *= 2;                       // table full: re-plan with twice the slots and retry
         int rc = build_plan(pl);
         if (rc != PLO_OK) return rc;
-        if (J.best) HIPCHK(hipMemset(pl->d_best, 0xFF, sizeof(unsigned long long)));
+        if (J.best) HIPCHK(hipMemsetAsync(pl->d_best, 0xFF, sizeof(unsigned long long), g_stream));
     }
     return device_error(plo::ERR_TABLE);
 }
@@ -532,7 +540,7 @@ int run_chain(plo_chain *ch, plo::WaveJob J, plo_stats_t *st)
         if (err != plo::ERR_TABLE) return device_error((int)err);
         for (int k = 0; k < 2; ++k) { ch->st[k]->cap_scale *= 2; int rc = build_plan(ch->st[k]); if (rc != PLO_OK) return rc; }
         int rc = chain_config(ch); if (rc != PLO_OK) return rc;
-        if (J.best) HIPCHK(hipMemset(p0->d_best, 0xFF, sizeof(unsigned long long)));
+        if (J.best) HIPCHK(hipMemsetAsync(p0->d_best, 0xFF, sizeof(unsigned long long), g_stream));
     }
     return device_error(plo::ERR_TABLE);
 }
@@ -776,7 +784,7 @@ int plo_cse_enum_search_plan(plo_plan_t *pl, uint64_t first, uint64_t count, int
     out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull; *maxprod = 0;
     unsigned long long *d_pm = nullptr;
     HIPCHK(hipMalloc((void **)&d_pm, sizeof(unsigned long long)));
-    HIPCHK(hipMemset(d_pm, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d_pm, 0, sizeof(unsigned long long), g_stream));
     uint64_t bkey = ~0ull, bidx = ~0ull;
     const uint64_t CH = 0xFFFFFFFFull;
     int rc = PLO_OK;
@@ -900,8 +908,8 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
         for (size_t k = 0; k < plans.size(); ++k) plans[k].tmpl = (const uint64_t *)(d_img + offs[k]);
         BCHK(hipMalloc((void **)&d_plans, plans.size() * sizeof(plo::WavePlan)));
         BCHK(hipMemcpy(d_plans, plans.data(), plans.size() * sizeof(plo::WavePlan), hipMemcpyHostToDevice));
-        BCHK(hipMalloc((void **)&d_err, 4)); BCHK(hipMemset(d_err, 0, 4));
-        BCHK(hipMalloc((void **)&d_best, 8)); BCHK(hipMemset(d_best, 0xFF, 8));
+        BCHK(hipMalloc((void **)&d_err, 4)); BCHK(hipMemsetAsync(d_err, 0, 4, g_stream));
+        BCHK(hipMalloc((void **)&d_best, 8)); BCHK(hipMemsetAsync(d_best, 0xFF, 8, g_stream));
         if (adds) BCHK(hipMalloc((void **)&d_adds, ncand * 4));
         if (muls) BCHK(hipMalloc((void **)&d_muls, ncand * 4));
         BCHK(hipFuncSetAttribute((const void *)plo::cse_chain_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1020,10 +1028,12 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
     };
 #define KCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PLO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     uint32_t pairs_max = 0;
-    for (uint32_t cap_scale = 2; cap_scale <= 32; cap_scale *= 2) {
+    // Dep's table starts at 0.75 x the sampled PAIR count (an upper bound of its distinct triples, usually far above it): a
+    // smaller image means more resident waves; a full table is reported by the device and the launch repeated with twice the slots
+    for (uint32_t cap_scale = 1; cap_scale <= 32; cap_scale *= 2) {
         plo::KPlan K{};
         // plan and image of M (the layout of Free)
-        plo_plan tmp; tmp.m = m; tmp.n = n; tmp.p = p; tmp.cap_scale = cap_scale;
+        plo_plan tmp; tmp.m = m; tmp.n = n; tmp.p = p; tmp.cap_scale = std::max(2u, cap_scale);
         tmp.rowptr.assign(M->rowptr, M->rowptr + m + 1); tmp.col.assign(M->col, M->col + M->rowptr[m]); tmp.val.assign(M->val, M->val + M->rowptr[m]);
         std::vector<uint8_t> img;
         int rc = build_plan(&tmp, &img);
@@ -1041,15 +1051,15 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         K.scratch_bytes = round_up(off, 16);
         KCHK(hipMalloc((void **)&d_img, img.size() + 64)); KCHK(hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
         K.PM.tmpl = (const uint64_t *)d_img;
-        KCHK(hipMalloc((void **)&d_err, 4)); KCHK(hipMemset(d_err, 0, 4));
+        KCHK(hipMalloc((void **)&d_err, 4)); KCHK(hipMemsetAsync(d_err, 0, 4, g_stream));
         KCHK(hipEventCreate(&e0)); KCHK(hipEventCreate(&e1));
-        if (cap_scale == 2) {
+        if (cap_scale == 1) {
             // sizing launch: Dep's pair count over a sample of the decompositions
             K.region = K.PM.region_bytes;
             uint32_t W = 0, lds = 0;
             for (uint32_t w : {4u, 2u, 1u}) { const uint32_t l = K.PM.rs_bytes + w * (K.region + K.scratch_bytes); if (l <= g_lds_max) { W = w; lds = l; break; } }
             if (!W) { cleanup(); return fail(PLO_E_CAPACITY, "kernel-method state does not fit LDS"); }
-            KCHK(hipMalloc((void **)&d_sz, 16)); KCHK(hipMemset(d_sz, 0, 16));
+            KCHK(hipMalloc((void **)&d_sz, 16)); KCHK(hipMemsetAsync(d_sz, 0, 16, g_stream));
             KCHK(hipFuncSetAttribute((const void *)plo::kmethod_size_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             plo::WaveJob J{}; J.seed0 = seed0; J.ncand = std::min<uint64_t>(nrestarts, 4096); J.err = d_err;
             const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g_cus * 2u, (J.ncand + W - 1) / W));
@@ -1081,7 +1091,7 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
             if (waves > bestw) { bestw = waves; W = w; lds = l; }
         }
         if (!W) { cleanup(); return fail(PLO_E_CAPACITY, "kernel-method state does not fit LDS"); }
-        KCHK(hipMalloc((void **)&d_best, 8)); KCHK(hipMemset(d_best, 0xFF, 8));
+        KCHK(hipMalloc((void **)&d_best, 8)); KCHK(hipMemsetAsync(d_best, 0xFF, 8, g_stream));
         if (adds) KCHK(hipMalloc((void **)&d_adds, nrestarts * 4));
         if (muls) KCHK(hipMalloc((void **)&d_muls, nrestarts * 4));
         if (info) KCHK(hipMalloc((void **)&d_info, nrestarts * 12));

@@ -40,6 +40,13 @@ namespace plo {
 #define PLO_WAVE_OCC_GEN 4
 #endif
 
+#ifdef PLO_WAVE_PROFILE
+__device__ unsigned long long g_wprof[12];   // lane 0 of every wave: cycles in max scan, tie list, tie pick, sweep 1, sweep 2, step tail, image load, ProgramGen; steps; candidates
+#define WP_T(k_) do { const unsigned long long t__ = clock64(); wp_acc[k_] += t__ - wp_t; wp_t = t__; } while (0)
+#else
+#define WP_T(k_) do { } while (0)
+#endif
+
 struct WavePlan {
     uint32_t m, n, nnz, p, NC, cap, hbits, lpr_log2, mw, unit, multcap, maxlen;
     uint32_t rb, bb;        // bits of a ratio (p-1) and of a column index (NC-1): 2*bb+rb <= 44
@@ -93,6 +100,19 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t srclane) { return (uint32_t)__shfl((int)v, (int)srclane); }
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t srclane) {
     return ((uint64_t)bcast((uint32_t)(v >> 32), srclane) << 32) | bcast((uint32_t)v, srclane);
+}
+
+// position of the n-th (0-based) set bit of m; n < popcount(m)
+__device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t n) {
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    uint32_t c = (uint32_t)__popc(lo), base = 0, wv = lo;
+    if (n >= c) { n -= c; wv = hi; base = 32u; }
+    c = (uint32_t)__popc(wv & 0xFFFFu); if (n >= c) { n -= c; wv >>= 16; base += 16u; }
+    c = (uint32_t)__popc(wv & 0xFFu);   if (n >= c) { n -= c; wv >>= 8;  base += 8u; }
+    c = (uint32_t)__popc(wv & 0xFu);    if (n >= c) { n -= c; wv >>= 4;  base += 4u; }
+    c = (uint32_t)__popc(wv & 0x3u);    if (n >= c) { n -= c; wv >>= 2;  base += 2u; }
+    c = wv & 1u;                        if (n >= c) base += 1u;
+    return base;
 }
 
 template <bool UNIT>
@@ -436,12 +456,16 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
 
     uint32_t ncols = P.n, nbadd = 0, nbmul = 0, nmult = 0;
 
+#ifdef PLO_WAVE_PROFILE
+    unsigned long long wp_t = clock64(), wp_acc[6] = {0, 0, 0, 0, 0, 0}, wp_steps = 0;
+#endif
     for (;;) {
         if (ncols >= NC) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_STEPS); break; }
         // ---- OneSub :244-253  maximal frequency over the pair table
         uint32_t lmax = 0;
         for (uint32_t s = lane; s < cap; s += 64u) { uint32_t c = (uint32_t)(tab[s] & PLO_VMASK); lmax = c > lmax ? c : lmax; }
         const uint32_t maxfrq = uni32(wave_max(lmax));
+        WP_T(0);
         if (maxfrq <= 1u) break;                                            // :255
         // ---- ties in map order; random pick :260-265
         uint32_t T = 0;
@@ -455,6 +479,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         }
         T = uni32(T);
         PLO_WAVE_SYNC();
+        WP_T(1);
         uint64_t key;
         if (T == 1u) {
             key = tab[ties[0]] >> PLO_VB;
@@ -485,6 +510,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
             }
         }
         key = uni64(key);
+        WP_T(2);
         ++nbadd;                                                            // :292
         // ---- RemOneCSE :60-194
         const uint32_t r = (uint32_t)(key & ((1ull << rb) - 1ull)), b = (uint32_t)(key >> rb) & ((1u << bb) - 1u), a = (uint32_t)(key >> abs_);
@@ -499,8 +525,11 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         for (uint32_t w = 0; w < mw; ++w) {
             uint64_t msk = uni64(cmask[a * ms + w] & cmask[b * ms + w]);
             while (msk) {
-                int myrow = -1;
-                for (uint32_t gg = 0; gg < G && msk; ++gg) { int i = __builtin_ctzll(msk); msk &= msk - 1ull; if (g == gg) myrow = (int)(w * 64u) + i; }
+                // group g takes the g-th row of the mask (bit arithmetic per lane: no scalar loop over the groups)
+                const uint32_t pc = (uint32_t)__popcll(msk);
+                const int myrow = g < pc ? (int)(w * 64u + nth_set_bit(msk, g)) : -1;
+                if (pc <= G) msk = 0ull;
+                else msk &= ~((2ull << ((uint32_t)__builtin_amdgcn_readlane(myrow, (int)((G - 1u) << P.lpr_log2)) & 63u)) - 1ull);
                 const bool act = myrow >= 0;
                 const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
                 const bool have = t < ln;
@@ -525,12 +554,16 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
             }
         }
         PLO_WAVE_SYNC();
+        WP_T(3);
         // sweep 2: rewrite the rows, add the pairs with the new column (:96-110, :132-142)
         for (uint32_t w = 0; w < mw; ++w) {
             uint64_t msk = uni64(affw[w]);
             while (msk) {
-                int myrow = -1;
-                for (uint32_t gg = 0; gg < G && msk; ++gg) { int i = __builtin_ctzll(msk); msk &= msk - 1ull; if (g == gg) myrow = (int)(w * 64u) + i; }
+                // group g takes the g-th row of the mask (bit arithmetic per lane: no scalar loop over the groups)
+                const uint32_t pc = (uint32_t)__popcll(msk);
+                const int myrow = g < pc ? (int)(w * 64u + nth_set_bit(msk, g)) : -1;
+                if (pc <= G) msk = 0ull;
+                else msk &= ~((2ull << ((uint32_t)__builtin_amdgcn_readlane(myrow, (int)((G - 1u) << P.lpr_log2)) & 63u)) - 1ull);
                 const bool act = myrow >= 0;
                 const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
                 const bool have = t < ln;
@@ -554,6 +587,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
             }
         }
         PLO_WAVE_SYNC();
+        WP_T(4);
         if (lane < mw) {
             const uint64_t af = affw[lane], uaf = affw[mw + lane];
             cmask[l0 * ms + lane] &= ~af; cmask[l1 * ms + lane] &= ~af;
@@ -578,7 +612,14 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         }
         ncols = lm + 1u;                                                    // :190-191
         PLO_WAVE_SYNC();
+        WP_T(5);
+#ifdef PLO_WAVE_PROFILE
+        ++wp_steps;
+#endif
     }
+#ifdef PLO_WAVE_PROFILE
+    if (lane == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_wprof[q_], wp_acc[q_]); atomicAdd(&g_wprof[8], wp_steps); }
+#endif
 
     // ---- ProgramGen :513-611
     if (UNIT) {
@@ -628,6 +669,9 @@ __global__ __launch_bounds__(256, UNIT ? PLO_WAVE_OCC_UNIT : PLO_WAVE_OCC_GEN) v
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
         PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), J.enumerate, seed, 1ull, 0u};
         const uint64_t res = run_candidate<UNIT>(P, reg, rs, ps, lane, J.err);
+#ifdef PLO_WAVE_PROFILE
+        if (lane == 0) atomicAdd(&g_wprof[9], 1ull);
+#endif
         if (J.enumerate && lane == 0) { if (J.prods) J.prods[c] = ps.prod; if (J.prodmax) atomicMax(J.prodmax, (unsigned long long)ps.prod); }
         const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
         if (lane == 0) {

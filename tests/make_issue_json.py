@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""profiles/r02_issue.json entry from a rocprofv3 --pmc summary (tests/rocpd_summary.py *_pmc.csv):
+   python tests/make_issue_json.py <workload> <kernel substring> <profiles/xxx_pmc.csv> "<source note>"
+Rates are per clock and compute unit (256 CUs); cycles = SQ_BUSY_CYCLES / 32 (MI355X_MICROARCH.md, profiling section)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(name, kern, csv, note):
+    avg = {}
+    for ln in open(csv):
+        f = ln.strip().split(",")
+        if len(f) >= 5 and kern in f[1]:
+            avg[f[2]] = float(f[4])
+    cyc = avg["SQ_BUSY_CYCLES"] / 32.0
+    e = {"cycles_per_launch": cyc,
+         "valu_per_clk_cu": avg["SQ_INSTS_VALU"] / cyc / 256, "salu_per_clk_cu": avg["SQ_INSTS_SALU"] / cyc / 256,
+         "lds_per_clk_cu": avg["SQ_INSTS_LDS"] / cyc / 256, "vmem_per_clk_cu": (avg.get("SQ_INSTS_VMEM_RD", 0) + avg.get("SQ_INSTS_VMEM_WR", 0)) / cyc / 256,
+         "source": note}
+    e["bound_unit"] = "scalar" if e["salu_per_clk_cu"] / 1.0 >= e["valu_per_clk_cu"] / 2.0 else "vector"
+    p = os.path.join(ROOT, "profiles", "r02_issue.json")
+    d = json.load(open(p))
+    d[name] = e
+    json.dump(d, open(p, "w"), indent=1)
+    print(name, json.dumps(e))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
