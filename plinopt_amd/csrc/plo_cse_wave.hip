@@ -98,6 +98,10 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
     return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v);
 }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t srclane) { return (uint32_t)__shfl((int)v, (int)srclane); }
+// the same from a wave-uniform lane index: two v_readlane
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t srclane) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)srclane) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)srclane);
+}
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t srclane) {
     return ((uint64_t)bcast((uint32_t)(v >> 32), srclane) << 32) | bcast((uint32_t)v, srclane);
 }
@@ -163,6 +167,17 @@ __device__ __forceinline__ bool tab_dec(uint64_t *tab, uint64_t key, uint32_t ca
         s = (s + 1u) & (cap - 1u);
     }
     return false;
+}
+// the same for two live keys at once: both probe sequences in flight together (one LDS round trip per round for the pair)
+__device__ __forceinline__ bool tab_dec2(uint64_t *tab, uint64_t k1, uint64_t k2, uint32_t cap, uint32_t hbits) {
+    uint32_t s1 = tab_hash(k1, hbits), s2 = tab_hash(k2, hbits);
+    bool p1 = true, p2 = true;
+    for (uint32_t pr = 0; pr < cap && (p1 || p2); ++pr) {
+        const uint64_t v1 = lds_ld64(&tab[s1]), v2 = lds_ld64(&tab[s2]);
+        if (p1) { if ((v1 >> PLO_VB) == k1) { atomicAdd((unsigned long long *)&tab[s1], ~0ull); p1 = false; } else s1 = (s1 + 1u) & (cap - 1u); }
+        if (p2) { if ((v2 >> PLO_VB) == k2) { atomicAdd((unsigned long long *)&tab[s2], ~0ull); p2 = false; } else s2 = (s2 + 1u) & (cap - 1u); }
+    }
+    return !p1 && !p2;
 }
 // count[key] += 1 ; claims an empty or dead (count 0) slot for a new key.
 // Only called when no decrement is in flight (see the two sweeps below), so a
@@ -493,9 +508,9 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
             if (T <= 64u) {
                 const uint64_t mine = lane < T ? (tab[ties[lane]] >> PLO_VB) : ~0ull;
                 uint32_t rank = 0;
-                for (uint32_t j = 0; j < T; ++j) rank += (bcast64(mine, j) < mine) ? 1u : 0u;
+                for (uint32_t j = 0; j < T; ++j) rank += (rdlane64(mine, j) < mine) ? 1u : 0u;      // j is wave-uniform: v_readlane, not an LDS permute
                 uint64_t w = __ballot(lane < T && rank == k);
-                key = bcast64(mine, (uint32_t)__builtin_ctzll(w));
+                key = rdlane64(mine, (uint32_t)__builtin_ctzll(w));
             } else {
                 uint64_t lo = 0ull, hi = (1ull << 44) - 1ull;             // k-th smallest by bisection on the key value
                 while (lo < hi) {
@@ -543,8 +558,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
                     if (lane != la && lane != lb) {
                         uint64_t k1 = c < a ? PLO_KEY(c, a, fmul<UNIT>(va, iv, p, mu)) : PLO_KEY(a, c, fmul<UNIT>(v, ia, p, mu));
                         uint64_t k2 = c < b ? PLO_KEY(c, b, fmul<UNIT>(vb, iv, p, mu)) : PLO_KEY(b, c, fmul<UNIT>(v, ib, p, mu));
-                        bad |= !tab_dec(tab, k1, cap, hbits);
-                        bad |= !tab_dec(tab, k2, cap, hbits);
+                        bad |= !tab_dec2(tab, k1, k2, cap, hbits);
                     } else if (lane == la) {
                         bad |= !tab_dec(tab, key, cap, hbits);
                         atomicOr((unsigned long long *)&affw[(uint32_t)myrow >> 6], 1ull << ((uint32_t)myrow & 63u));
