@@ -541,23 +541,38 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         const uint32_t ncols = sh.ncols;
         {
             if (wave == 0) {
-                // block of 64 first columns from the LDS block sums (thread 0), then one wave-wide load of that block
+                // block of 64 first columns from the LDS block sums, then one wave-wide load of that block.  The 512 block sums are
+                // scanned by the wave (8 per lane, prefix sum over the lanes), not by one thread reading them one after the other.
                 uint32_t blk = 0; uint64_t k = 0, run = 0;
                 if (lane == 0) {
                     const uint32_t T = hist[M];
                     if (T > 1u) { uint64_t x = 950706376ull * (uint64_t)sh.rng; sh.rng = (uint32_t)(x % 2147483647ull); k = sh.rng % T; }
-                    const uint32_t nb = (ncols + 63u) >> 6;
-                    for (; blk < nb; ++blk) { const uint32_t q = sh.cblk[blk]; if (k < run + q) break; run += q; }
-                    if (blk >= nb) { wg_max(&sh.errflag, (uint32_t)BERR_SEL); blk = 0; }
                     sh.sel_n = 0; sh.sel_over = 0;
                 }
-                blk = (uint32_t)__shfl((int)blk, 0);
+                {
+                    const uint32_t k32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 0);         // k < T < 2^32
+                    uint32_t q8[8], mine = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { q8[u] = sh.cblk[lane * 8u + (uint32_t)u]; mine += q8[u]; }
+                    uint32_t inc = mine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += t; }
+                    const uint64_t hm0 = __ballot(k32 < inc);
+                    if (!hm0) { if (lane == 0) wg_max(&sh.errflag, (uint32_t)BERR_SEL); }
+                    const uint32_t L0 = hm0 ? (uint32_t)__builtin_ctzll(hm0) : 0u;
+                    uint32_t b_ = lane * 8u, r_ = inc - mine;                          // the owner lane walks its 8 sums
+                    { bool done = false;
+#pragma unroll
+                      for (int u = 0; u < 8; ++u) if (!done) { if (k32 < r_ + q8[u]) done = true; else { r_ += q8[u]; ++b_; } } }
+                    blk = (uint32_t)__builtin_amdgcn_readlane((int)b_, (int)L0);
+                    run = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r_, (int)L0);
+                    k = (uint64_t)k32;
+                }
                 const uint32_t c = blk * 64u + lane;
                 uint32_t q = c < ncols ? gload32(&cntM[c]) : 0u, incl = q;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += t; }
-                const uint64_t kk = (((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k >> 32), 0)) << 32 | (uint32_t)__shfl((int)(uint32_t)k, 0))
-                                    - (((uint64_t)(uint32_t)__shfl((int)(uint32_t)(run >> 32), 0)) << 32 | (uint32_t)__shfl((int)(uint32_t)run, 0));
+                const uint64_t kk = k - run;                                           // (both wave-uniform)
                 const uint64_t hm = __ballot(kk < (uint64_t)incl);
                 if (!hm) { if (lane == 0) wg_max(&sh.errflag, (uint32_t)BERR_SEL); }
                 else if (lane == (uint32_t)__builtin_ctzll(hm)) { sh.a = c; sh.kprime = kk - (uint64_t)(incl - q); }
@@ -625,6 +640,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             // Two rows per thread and trip, both columns of both rows searched in lock step: the four binary searches have
             // their loads in flight together (8 dependent memory round trips for two rows instead of 36).  A search keeps
             // the last entry it saw at its upper bound: when it ends that is the entry at the found position.
+            uint32_t *newrows = ncr + ncrptr[lm - n];
             auto emit = [&](uint32_t i, uint32_t base, uint32_t L, uint32_t pa, uint32_t pb, uint32_t ea, uint32_t eb) {
                 uint32_t inv_r;
                 if constexpr (MODE == 2) {
@@ -642,6 +658,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each), row start and length; the two packed entries
                 *(uint4 *)rec = make_uint4(i, pa | (pb << 16), base, L);
                 *(uint2 *)(rec + 4) = make_uint2(ea, eb);
+                newrows[idx] = i;                                              // row list of the new column (4-byte entries: the records are 32 bytes apart)
                 if (idx == 0) sh.invr = inv_r;                                   // 1/r
                 len[i] = L - 1u;                                               // the sweep works from the record
                 if (PLO_EUNIT(ea)) wg_sub(&ucount[a], 1u);                     // :70-77 counts, kept incrementally
@@ -978,9 +995,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         PLO_STAMP(5);
         // row list of the new column, multiplier reuse (:153-169), counters
         {
-            const uint32_t o = ncrptr[lm - n];
-            for (uint32_t k = tid; k < naff; k += nth) ncr[o + k] = aff[8u * k];
-            if (tid == 0) { ncrptr[lm - n + 1u] = o + naff; sh.part[0] = 0; }
+            if (tid == 0) { ncrptr[lm - n + 1u] = ncrptr[lm - n] + naff; sh.part[0] = 0; }      // (the row search wrote the rows)
         }
         BSYNC();
         if (!P.unit) {
