@@ -235,6 +235,7 @@ template <class F> std::string kernel_text(const F &f, const KernelDecomp<F> &kd
 // seeds: block d uses the decomposition drawn from its first seed, and every seed of the block is one run of the two
 // Optimizer calls on it (the reference draws a new decomposition for every restart; with a per-restart elimination on
 // the host the GPU would idle).  Returns false when the method could not run.
+struct KShard { bool done = false; Ops ops; uint64_t seed = 0, ncand = 0; double kms = 0; int shards = 0; } g_kshard;   // -K searched by --gpu N shards (main) before this process touched the HIP runtime
 bool g_host_decomp = false;        // --host-decomp: -K eliminates on the host and ships the images (plo_cse_chain_batch)
 uint64_t g_kernel_block = 1;      // restarts per decomposition (--kernel-block; the reference draws one decomposition per restart, :1299-1340)
 #define PLO_KERNEL_BLOCK g_kernel_block
@@ -300,16 +301,21 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     const uint64_t nblocks = (loops + PLO_KERNEL_BLOCK - 1) / PLO_KERNEL_BLOCK;
     bool use_gpu = false;
     HipLib L;
-    if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0) {
+    if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0 && !g_kshard.done) {
         if (!L.load(argv0) || L.init(0) != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: -K: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return false; }
         use_gpu = true;
     }
     const uint64_t full = loops / PLO_KERNEL_BLOCK;                    // full blocks go to the GPU in batches of one launch each
     const uint64_t BATCH = 4096;
     uint64_t d = 0;
+    if (g_kshard.done) {                                               // searched by N forked shards, one device each (main): only the replay is left
+        best = g_kshard.ops; seed = g_kshard.seed; bdec = seed; have = true; kms = g_kshard.kms; ncand = g_kshard.ncand; d = nblocks; on_device = true;
+        g_kshard.done = false;
+        if (verbose > 0) std::clog << "# " << g_kshard.shards << " shards (one GPU each): -K" << std::endl;
+    }
     // All of it on the device (plo_kernel_search: the wave of a restart eliminates, builds both images and runs both
     // Optimizer calls): matrices of at most 64 x 64.  --host-decomp keeps the decompositions on the host (round-1 path).
-    if constexpr (std::is_same<F, ZpField>::value) if (use_gpu && L.kernel_search && !g_host_decomp && lM.rowdim() <= 64 && lM.coldim() <= 64) {
+    if constexpr (std::is_same<F, ZpField>::value) if (!have && use_gpu && L.kernel_search && !g_host_decomp && lM.rowdim() <= 64 && lM.coldim() <= 64) {
         KernelDecomp<F> kd0;
         if (!kernel_decomp(f, lM, seed0, kd0)) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }   // :1343-1346 (the rank does not depend on the order)
         std::vector<uint32_t> rp, cc, vv; to_csr(lM, rp, cc, vv);
@@ -371,7 +377,7 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     if (!kernel_decomp(f, lM, bdec, kd)) return false;
     Ops rops; std::string t = kernel_text(f, kd, seed, rops);
     if (rops != best) { ++g_failures, std::cerr << "# \033[1;31mERROR: -K replay of seed " << seed << " gives " << rops.first << '|' << rops.second << ", search said " << best.first << '|' << best.second << "\033[0m" << std::endl; return false; }
-    if (use_gpu && verbose > 0) std::clog << "# GPU (K): " << ncand << " candidates on " << nblocks << " decompositions, kernel " << kms << " ms" << (on_device ? " (decompositions on the device)" : " (decompositions on the host)") << std::endl;
+    if ((use_gpu || on_device) && verbose > 0) std::clog << "# GPU (K): " << ncand << " candidates on " << nblocks << " decompositions, kernel " << kms << " ms" << (on_device ? " (decompositions on the device)" : " (decompositions on the host)") << std::endl;
     if (verbose > 0) std::clog << "# Found K: " << best.first << '|' << best.second << " instead of " << gops.first << '|' << gops.second << "\t[seed " << seed
                                << "] (rank " << kd.rank << '+' << kd.notindep << ", " << kd.dep.size() << " dependent rows)" << std::endl;
     if (cmp_op_count(best, gops)) { gops = best; gtext = t; }                                              // :1347-1351
@@ -574,6 +580,39 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         }
         sharded.done = have;
         if (verbose > 0) std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one GPU each)") << ": " << total << " candidates, slowest kernel " << kmax << " ms" << std::endl;
+    }
+    // the same for -K (decompositions on the device, one per restart): N shards of the restart range
+    if constexpr (std::is_same<F, ZpField>::value) if (tryKernel && !kfi && q != 0 && gpu >= 2 && loops > 0 && !g_host_decomp && g_kernel_block == 1 && lM.rowdim() <= 64 && lM.coldim() <= 64) {
+        KernelDecomp<F> kd0;
+        if (kernel_decomp(f, lM, seed0, kd0)) {                                       // (a zero dimensional kernel is reported by kernel_method)
+            std::vector<uint32_t> rp, cc, vv; to_csr(lM, rp, cc, vv);
+            auto shard = [&](int, int device, uint64_t s0, uint64_t cnt) {
+                ShardOut o{};
+                if (cnt == 0) { o.ok = 1; o.a = o.b = 0xFFFFFFFFu; return o; }
+                HipLib L;
+                if (!L.load(argv0) || !L.kernel_search || L.init(device) != PLO_OK) { snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error ? L.last_error() : "library missing"); return o; }
+                plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
+                plo_best_t b{}; plo_stats_t st{};
+                const int rc = L.kernel_search(&A, q, s0, cnt, 1u, PLO_COST_SUM_THEN_ADD, nullptr, nullptr, nullptr, &b, &st);
+                if (rc != PLO_OK) { snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error()); return o; }
+                o.ok = 1; o.a = b.adds; o.b = b.muls; o.seed = b.seed; o.candidates = st.candidates; o.kernel_ms = st.kernel_ms;
+                L.shutdown();
+                return o;
+            };
+            std::vector<ShardOut> outs;
+            if (!forked_shards(gpu, seed0, loops, shard, outs)) {
+                for (auto &o : outs) if (!o.ok) ++g_failures, std::cerr << "# \033[1;31mERROR: -K shard failed: " << o.msg << "\033[0m" << std::endl;
+                return 2;
+            }
+            bool have = false;
+            for (auto &o : outs) {
+                g_kshard.ncand += o.candidates; g_kshard.kms = std::max(g_kshard.kms, o.kernel_ms);
+                if (o.a == 0xFFFFFFFFu && o.b == 0xFFFFFFFFu) continue;
+                const Ops ops{o.a, o.b};
+                if (!have || cmp_op_count(ops, g_kshard.ops) || (!cmp_op_count(g_kshard.ops, ops) && o.seed < g_kshard.seed)) { g_kshard.ops = ops; g_kshard.seed = o.seed; have = true; }
+            }
+            g_kshard.done = have; g_kshard.shards = gpu;
+        }
     }
     if (tryAB) {                                                                      // :1436-1440 (inner dimension = column count)
         // every inner dimension from the column count to the row count - 1 (:1437-1439); a square matrix has the identity factorization only

@@ -87,8 +87,10 @@ __device__ uint32_t kmethod_decompose(const KPlan &K, uint8_t *reg, const KScrat
         }
         const uint64_t nz = __ballot(v != 0u);
         if (!nz) {                                                           // row = sum_j c[j] * basis row j
-            if (lane == 0) S.deps[nd] = (uint16_t)row;
-            if (lane < R) S.depc[nd * R + lane] = c;
+            if (nd < K.ndeps) {                                              // (always: the rank does not depend on the order; the guard keeps a wrong host rank from overrunning the scratch)
+                if (lane == 0) S.deps[nd] = (uint16_t)row;
+                if (lane < R) S.depc[nd * R + lane] = c;
+            }
             ++nd;
         } else {                                                             // new basis row: echelon row = (row - sum c_j basis_j) / pivot
             const uint32_t pc = (uint32_t)__builtin_ctzll(nz);
@@ -106,7 +108,7 @@ __device__ uint32_t kmethod_decompose(const KPlan &K, uint8_t *reg, const KScrat
         PLO_WAVE_SYNC();
     }
     notindep_out = 0;
-    if (nd == 0u || nb != R) return 0u;                                      // (nb != rank(M) cannot happen: the rank does not depend on the order)
+    if (nd == 0u || nb != R || nd != K.ndeps) return 0u;                     // (nb != rank(M) cannot happen: the rank does not depend on the order)
     const uint32_t ni = uni32(rng_next(rng) % nd);                           // :792-795
     notindep_out = ni;
     return nd - ni;
