@@ -505,7 +505,7 @@ def main():
             pass
         if plan.is_hbm:
             out["roofline"]["note"] = ("candidate state (64 MB pair table + 5 MB packed rows + lists, 140 MB workspace) is HBM-resident; measured HBM traffic "
-                                       "is 3.1 GB per candidate = 51x the algorithmic bytes (round 1: 91x), 2.0 TB/s (rocprofv3 PMC, profiles/r02f_*). The traffic "
+                                       "is 3.1 GB per candidate = 51x the algorithmic bytes (round 1: 91x), 1.9-2.0 TB/s (rocprofv3 PMC, profiles/r02j_*). The traffic "
                                        "is random 8-byte accesses to the table and the rows: tests/micro/random_access.hip measures 49 G such loads/s chip-wide "
                                        "(3.1 TB/s of 64-byte lines) whatever the number in flight, and this kernel issues about 45 G L2 requests/s -- it runs at "
                                        "the memory system's random-access rate, not at the streaming peak this `frac` is priced against (DESIGN.md 2.3, 6)")
