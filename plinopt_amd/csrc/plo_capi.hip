@@ -1072,6 +1072,7 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
             KCHK(hipMemcpy(sz, d_sz, 16, hipMemcpyDeviceToHost));
             if (sz[2]) { cleanup(); return device_error(plo::ERR_KDEC); }
             pairs_max = sz[0];
+            if (const char *e = getenv("PLO_KMETHOD_PAIRS_DIV")) pairs_max /= (uint32_t)std::max(1l, strtol(e, nullptr, 10));   // test knob: undersized first table, exercises the repeat-with-more-slots path
         }
         // layout of Dep's image from the hard bounds (rows <= m - rank, entries per row <= rank) and the sampled pair count
         uint32_t capD = 64;

@@ -51,3 +51,15 @@ def test_unsupported_shapes_are_reported(hip):
     with pytest.raises(capi.PloError) as e:
         kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, 1, 10)
     assert e.value.code == capi.PLO_E_UNSUPPORTED
+
+
+def test_a_full_pair_table_is_repeated_with_more_slots(hip, monkeypatch):
+    """Dep's pair table is sized from a sample; when a restart fills it the device reports it and the call is repeated with twice
+    the slots (here the first size is forced 64 times too small): same results as the oracle."""
+    from plinopt_amd import kernel_search
+    monkeypatch.setenv("PLO_KMETHOD_PAIRS_DIV", "64")
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), P)
+    n, seed0 = 120, 900
+    adds, muls, info, best, st = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n)
+    assert st["launches"] >= 3                                     # sizing + at least one repeated search launch
+    assert [(a, mu) + i for a, mu, i in zip(adds, muls, info)] == [M.kernel_restart(seed0 + k) for k in range(n)]
