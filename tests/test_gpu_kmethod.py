@@ -63,3 +63,24 @@ def test_a_full_pair_table_is_repeated_with_more_slots(hip, monkeypatch):
     adds, muls, info, best, st = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n)
     assert st["launches"] >= 3                                     # sizing + at least one repeated search launch
     assert [(a, mu) + i for a, mu, i in zip(adds, muls, info)] == [M.kernel_restart(seed0 + k) for k in range(n)]
+
+
+@pytest.mark.parametrize("prime", [7, 101, 2147483647])
+@pytest.mark.parametrize("name", ["4x4x4_48_rational_L.sms", "3x3x6_40_L.sms", "2x2x2_7_DPS-accurate_L.sms"])
+def test_other_moduli(hip, name, prime):
+    """small and large moduli (the reference's pipelines check modulo 7, bin/FDT.sh): inverses by Fermat, Barrett products with
+    mu = floor(2^64 / p); matrices with rational coefficients (entries vanish or collide modulo small primes)"""
+    from plinopt_amd import kernel_search
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), prime)
+    if M.m > 64 or M.n > 64 or M.kernel_restart(1) is None:
+        pytest.skip("shape or zero dimensional kernel modulo %d" % prime)
+    n, seed0 = 60, 77
+    from plinopt_amd import capi
+    try:
+        adds, muls, info, best, _ = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), prime, seed0, n)
+    except capi.PloError as e:
+        if e.code == capi.PLO_E_CAPACITY:                  # 31-bit ratios leave 6 bits per column in the 44-bit pair key of the LDS kernels
+            pytest.skip(str(e))
+        raise
+    exp = [M.kernel_restart(seed0 + k) for k in range(n)]
+    assert [(a, mu) + i for a, mu, i in zip(adds, muls, info)] == exp
