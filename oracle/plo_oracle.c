@@ -810,3 +810,49 @@ int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, co
     free(ord); free(basis); free(deps); free(stack); free(tmp);
     return rc;
 }
+
+/* ---- LU factors of the -G method (see plo_oracle.h).  Dense restatement: A is eliminated in place, the multipliers of row i against
+ * pivot k go to Lm[i][k]; permutations are applied when U and L are written out. */
+int plo_oracle_lu(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                  uint32_t *U, uint32_t *L, uint32_t *rank)
+{
+    uint32_t *A = (uint32_t *)calloc((size_t)m * n + 1, 4), *Lm = (uint32_t *)calloc((size_t)m * m + 1, 4);
+    uint32_t *prow = (uint32_t *)calloc(m + 1, 4), *pcol = (uint32_t *)calloc(n + 1, 4), *invP = (uint32_t *)calloc(n + 1, 4), *pos = (uint32_t *)calloc(m + 1, 4);
+    char *usedr = (char *)calloc(m + 1, 1), *usedc = (char *)calloc(n + 1, 1);
+    uint32_t r = 0, k, i, j, c;
+    for (i = 0; i < m; ++i) for (k = rowptr[i]; k < rowptr[i + 1]; ++k) A[(size_t)i * n + col[k]] = val[k] % p;
+    for (;;) {
+        uint32_t pr = m;
+        for (i = 0; i < m && pr == m; ++i) {
+            if (usedr[i]) continue;
+            for (j = 0; j < n; ++j) if (A[(size_t)i * n + j]) { pr = i; break; }
+        }
+        if (pr == m) break;
+        for (c = 0; !A[(size_t)pr * n + c]; ++c) {}
+        {
+            const uint32_t piv = A[(size_t)pr * n + c];
+            usedr[pr] = 1; usedc[c] = 1; prow[r] = pr; pcol[r] = c;
+            for (i = 0; i < m; ++i) {
+                uint32_t l;
+                if (usedr[i] || !A[(size_t)i * n + c]) continue;
+                l = f_div(A[(size_t)i * n + c], piv, p);
+                for (j = 0; j < n; ++j) if (A[(size_t)pr * n + j]) A[(size_t)i * n + j] = (uint32_t)(((uint64_t)A[(size_t)i * n + j] + f_neg(f_mul(l, A[(size_t)pr * n + j], p), p)) % p);
+                Lm[(size_t)i * m + r] = l;
+            }
+            ++r;
+        }
+    }
+    *rank = r;
+    for (k = 0; k < r; ++k) invP[pcol[k]] = k;
+    for (j = 0, k = r; j < n; ++j) if (!usedc[j]) invP[j] = k++;
+    for (k = 0; k < r; ++k) pos[prow[k]] = k;
+    for (i = 0, k = r; i < m; ++i) if (!usedr[i]) pos[i] = k++;
+    memset(U, 0, (size_t)m * n * 4); memset(L, 0, (size_t)m * m * 4);
+    for (k = 0; k < r; ++k) for (j = 0; j < n; ++j) U[(size_t)k * n + invP[j]] = A[(size_t)prow[k] * n + j];
+    for (i = 0; i < m; ++i) {
+        for (k = 0; k < r; ++k) if (Lm[(size_t)i * m + k]) L[(size_t)pos[i] * m + k] = Lm[(size_t)i * m + k];
+        if (usedr[i]) L[(size_t)pos[i] * m + pos[i]] = 1u % p;
+    }
+    free(A); free(Lm); free(prow); free(pcol); free(invP); free(pos); free(usedr); free(usedc);
+    return 0;
+}

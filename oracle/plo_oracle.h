@@ -130,6 +130,14 @@ int plo_oracle_recsub(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint
 int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p, uint64_t seed,
                               uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep);
 
+/* The LU factors bin/optimizer -G hands to the two chained Optimizer calls (LUOptimiser, plinopt_optimize.inl:1021-1109), with the build's
+ * pivot rule (LinBox's is not in the reference tree): pivot row = smallest unused row holding an entry, pivot column = its smallest
+ * column; restated on dense arrays, independently of host/plo_host.hpp `sparse_lu`.  U (m x n, row major, rows >= rank zero, columns
+ * permuted: pivot columns first, then the others in increasing order) and L (m x m: multipliers, unit diagonal on the pivot rows; rows
+ * permuted: pivot rows first) are written into caller arrays of m*n and m*m words; *rank is set.  Returns 0. */
+int plo_oracle_lu(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                  uint32_t *U, uint32_t *L, uint32_t *rank);
+
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);
 

@@ -361,6 +361,22 @@ class OracleMatrix:
         assert rc == 0, rc
         return a.value, mu.value, r.value, ni.value, nd.value
 
+    def lu_factors(self):
+        """(U, L, rank) of the -G method by the oracle's dense restatement of the build's pivot rule (plo_oracle_lu): two OracleMatrix"""
+        U = (ctypes.c_uint32 * (self.m * self.n))(); L = (ctypes.c_uint32 * (self.m * self.m))(); rk = ctypes.c_uint32()
+        rc = oracle().plo_oracle_lu(self.m, self.n, _arr(self.rowptr), _arr(self.col), _arr(self.val), self.p, U, L, ctypes.byref(rk))
+        assert rc == 0
+
+        def csr(D, rows, cols):
+            rp, c, v = [0], [], []
+            for i in range(rows):
+                for j in range(cols):
+                    if D[i * cols + j]:
+                        c.append(j); v.append(D[i * cols + j])
+                rp.append(len(c))
+            return OracleMatrix(rows, cols, rp, c, v, self.p)
+        return csr(U, self.m, self.n), csr(L, self.m, self.m), rk.value
+
     def recsub(self):
         """literal RecSub / RecOptimizer (plinopt_optimize.inl:889-1013): (adds, muls before ProgramGen, muls after, nodes)"""
         a, mr, mf, nd = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()

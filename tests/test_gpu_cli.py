@@ -188,6 +188,21 @@ def test_kernel_method_on_gpu_equals_the_oracle_restatement(name):
     assert g and tuple(int(x) for x in g.groups()) == (a, mu, seed, rank, ni, nd), (g and g.groups(), (a, mu, seed, rank, ni, nd))
 
 
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "cyclic.sms"])
+def test_lu_method_on_gpu_equals_the_oracle_restatement(name):
+    """-G on the GPU (chained-candidate kernel on U and L) against the ORACLE: its own dense restatement of the LU rule, then its chained
+    Optimizer, minimised over the same seeds"""
+    from test_host_tools import lu_oracle_argmin
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    n = 200
+    a, mu, seed, rank = lu_oracle_argmin(M, 9, n)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "G", "-O", str(n), "--seed", "9", path])
+    assert rc == 0 and "GPU" in err, err
+    g = re.search(r"# Found G: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\)", err)
+    assert g and tuple(int(x) for x in g.groups()) == (a, mu, seed, rank), (g and g.groups(), (a, mu, seed, rank))
+
+
 def test_kernel_method_sharded_over_devices_equals_one_device():
     """-K --gpu 3: the restart range in three shards, one forked child per shard (here all on device 0: PLO_GPU_DEVICES), every shard
     = plo_kernel_search on its block; same winner, counts, decomposition and program as one device."""

@@ -553,3 +553,33 @@ def test_kernel_method_with_identity_goals(name, field):
     got = re.search(r": (\d+),(\d+) Matrix-Vector", err2)
     fin = re.search(r"# \S*?(\d+)\tadditions\tinstead of (\d+)", err)
     assert fin and int(got.group(1)) == int(fin.group(1))
+
+
+# ----------------------------------------------------------------------------- -G against the oracle's restatement of the LU rule
+def lu_oracle_argmin(M, seed0, n):
+    """best restart of the LU method under (cmpOpCount, seed): the oracle's own LU factors (plo_oracle_lu, dense restatement of the
+    build's pivot rule) through the oracle's chained Optimizer"""
+    from plo_testlib import oracle_chain
+    U, L, rank = M.lu_factors()
+    best = None
+    for s in range(seed0, seed0 + n):
+        a, mu = oracle_chain(U, L, s)
+        key = (a + mu, a, s)
+        if best is None or key < best:
+            best = key
+    return best[1], best[0] - best[1], best[2], rank
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "2x2x2_7_Winograd_P.sms", "2x2x2_7_DPS-accurate_L.sms", "cyclic.sms"])
+def test_lu_method_equals_the_oracle_restatement(name):
+    """`bin/optimizer --only G` (host loop): winner, counts and rank are those of the oracle's independent LU restatement followed by the
+    oracle's chained Optimizer -- not a comparison of the product with itself"""
+    from plo_testlib import OracleMatrix
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    n = 60
+    a, mu, seed, rank = lu_oracle_argmin(M, 3, n)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "G", "-O", str(n), "--seed", "3", "--gpu", "0", path])
+    assert rc == 0, err
+    g = re.search(r"# Found G: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\)", err)
+    assert g and tuple(int(x) for x in g.groups()) == (a, mu, seed, rank), (g and g.groups(), (a, mu, seed, rank))
