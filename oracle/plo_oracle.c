@@ -856,3 +856,100 @@ int plo_oracle_lu(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t
     free(A); free(Lm); free(prow); free(pcol); free(invP); free(pos); free(usedr); free(usedc);
     return 0;
 }
+
+/* ---- factorization of the -A method (see plo_oracle.h) */
+static uint32_t ab_rank(const uint32_t *D, const uint32_t *rows, uint32_t cnt, uint32_t n, uint32_t p)
+{   /* rank of the rows D[rows[0..cnt)] (n columns), by elimination of a copy */
+    uint32_t *T = (uint32_t *)malloc((size_t)(cnt + 1) * n * 4), r = 0, c, i, j;
+    for (i = 0; i < cnt; ++i) memcpy(T + (size_t)i * n, D + (size_t)rows[i] * n, (size_t)n * 4);
+    for (c = 0; c < n && r < cnt; ++c) {
+        uint32_t pv = r;
+        while (pv < cnt && !T[(size_t)pv * n + c]) ++pv;
+        if (pv == cnt) continue;
+        if (pv != r) for (j = 0; j < n; ++j) { uint32_t t = T[(size_t)pv * n + j]; T[(size_t)pv * n + j] = T[(size_t)r * n + j]; T[(size_t)r * n + j] = t; }
+        for (i = r + 1; i < cnt; ++i) if (T[(size_t)i * n + c]) {
+            const uint32_t l = f_div(T[(size_t)i * n + c], T[(size_t)r * n + c], p);
+            for (j = c; j < n; ++j) T[(size_t)i * n + j] = (uint32_t)(((uint64_t)T[(size_t)i * n + j] + f_neg(f_mul(l, T[(size_t)r * n + j], p), p)) % p);
+        }
+        ++r;
+    }
+    free(T);
+    return r;
+}
+static uint32_t ab_lcg(uint32_t *s) { *s = (uint32_t)((950706376ull * (uint64_t)*s) % 2147483647ull); return *s; }
+static uint32_t ab_seed(uint64_t seed) {
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
+    return 1u + (uint32_t)(x % 2147483646ull);
+}
+int plo_oracle_ab_factor(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                         uint64_t seed0, uint32_t loops, uint32_t k, uint32_t *Alt, uint32_t *CoB, uint32_t *score)
+{
+    uint32_t *D, *ord, *B, *Bi, *cA, *cC, i, j, q, t, it;
+    uint64_t best[3], cur[3];
+    if (m <= n || k < n || k > m) return -2;
+    D = (uint32_t *)calloc((size_t)m * n + 1, 4); ord = (uint32_t *)malloc((size_t)(m + 1) * 4);
+    B = (uint32_t *)malloc((size_t)n * n * 4 + 4); Bi = (uint32_t *)malloc((size_t)n * n * 4 + 4);
+    cA = (uint32_t *)malloc((size_t)m * k * 4 + 4); cC = (uint32_t *)malloc((size_t)k * n * 4 + 4);
+    for (i = 0; i < m; ++i) for (t = rowptr[i]; t < rowptr[i + 1]; ++t) D[(size_t)i * n + col[t]] = val[t] % p;
+    /* start: (M | 0) . (I ; 0) */
+    memset(Alt, 0, (size_t)m * k * 4); memset(CoB, 0, (size_t)k * n * 4);
+    best[0] = best[1] = 0; best[2] = n;
+    for (i = 0; i < m; ++i) for (j = 0; j < n; ++j) { const uint32_t v = D[(size_t)i * n + j]; Alt[(size_t)i * k + j] = v; if (v) { ++best[0]; if (!f_isone(v, p) && !f_ismone(v, p)) ++best[1]; } }
+    for (i = 0; i < n; ++i) CoB[(size_t)i * n + i] = 1u % p;
+    for (it = 0; it < loops; ++it) {
+        uint32_t st = ab_seed(seed0 + it), ok = 1;
+        for (i = 0; i < m; ++i) ord[i] = i;
+        for (i = m; i > 1; --i) { const uint32_t r = ab_lcg(&st) % i, tmp = ord[i - 1]; ord[i - 1] = ord[r]; ord[r] = tmp; }
+        for (i = 0; i < n && ok; ++i) {                       /* position i: first later row that raises the rank */
+            uint32_t got = 0;
+            for (j = i; j < m && !got; ++j) {
+                const uint32_t keep = ord[i]; ord[i] = ord[j];
+                if (ab_rank(D, ord, i + 1, n, p) == i + 1) { ord[j] = keep; got = 1; }
+                else ord[i] = keep;
+            }
+            if (!got) ok = 0;
+        }
+        if (!ok) continue;
+        /* B = the n chosen rows, Bi = its inverse (Gauss-Jordan on [B | I]) */
+        for (i = 0; i < n; ++i) for (j = 0; j < n; ++j) { B[(size_t)i * n + j] = D[(size_t)ord[i] * n + j]; Bi[(size_t)i * n + j] = (i == j) ? 1u % p : 0u; }
+        for (q = 0; q < n; ++q) {
+            uint32_t pv = q, iv;
+            while (pv < n && !B[(size_t)pv * n + q]) ++pv;
+            if (pv == n) { ok = 0; break; }
+            if (pv != q) for (j = 0; j < n; ++j) { uint32_t x = B[(size_t)pv * n + j]; B[(size_t)pv * n + j] = B[(size_t)q * n + j]; B[(size_t)q * n + j] = x; x = Bi[(size_t)pv * n + j]; Bi[(size_t)pv * n + j] = Bi[(size_t)q * n + j]; Bi[(size_t)q * n + j] = x; }
+            iv = f_inv(B[(size_t)q * n + q], p);
+            for (j = 0; j < n; ++j) { B[(size_t)q * n + j] = f_mul(B[(size_t)q * n + j], iv, p); Bi[(size_t)q * n + j] = f_mul(Bi[(size_t)q * n + j], iv, p); }
+            for (i = 0; i < n; ++i) if (i != q && B[(size_t)i * n + q]) {
+                const uint32_t l = B[(size_t)i * n + q];
+                for (j = 0; j < n; ++j) {
+                    B[(size_t)i * n + j] = (uint32_t)(((uint64_t)B[(size_t)i * n + j] + f_neg(f_mul(l, B[(size_t)q * n + j], p), p)) % p);
+                    Bi[(size_t)i * n + j] = (uint32_t)(((uint64_t)Bi[(size_t)i * n + j] + f_neg(f_mul(l, Bi[(size_t)q * n + j], p), p)) % p);
+                }
+            }
+        }
+        if (!ok) continue;
+        memset(cA, 0, (size_t)m * k * 4); memset(cC, 0, (size_t)k * n * 4);
+        cur[0] = cur[1] = cur[2] = 0;
+        for (t = 0; t < k; ++t) {
+            for (j = 0; j < n; ++j) { cC[(size_t)t * n + j] = D[(size_t)ord[t] * n + j]; if (cC[(size_t)t * n + j]) ++cur[2]; }
+            cA[(size_t)ord[t] * k + t] = 1u % p; ++cur[0];
+        }
+        for (t = k; t < m; ++t) {                              /* x = row . B^-1 (x . B = row), supported on the n chosen rows */
+            const uint32_t r = ord[t];
+            for (q = 0; q < n; ++q) {
+                uint64_t acc = 0;
+                for (j = 0; j < n; ++j) acc = (acc + (uint64_t)f_mul(D[(size_t)r * n + j], Bi[(size_t)j * n + q], p)) % p;
+                cA[(size_t)r * k + q] = (uint32_t)acc;
+                if (acc) { ++cur[0]; if (!f_isone((uint32_t)acc, p) && !f_ismone((uint32_t)acc, p)) ++cur[1]; }
+            }
+        }
+        if (cur[0] < best[0] || (cur[0] == best[0] && (cur[1] < best[1] || (cur[1] == best[1] && cur[2] < best[2])))) {
+            best[0] = cur[0]; best[1] = cur[1]; best[2] = cur[2];
+            memcpy(Alt, cA, (size_t)m * k * 4); memcpy(CoB, cC, (size_t)k * n * 4);
+        }
+    }
+    score[0] = (uint32_t)best[0]; score[1] = (uint32_t)best[1]; score[2] = (uint32_t)best[2];
+    free(D); free(ord); free(B); free(Bi); free(cA); free(cC);
+    return 0;
+}

@@ -138,6 +138,16 @@ int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, co
 int plo_oracle_lu(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
                   uint32_t *U, uint32_t *L, uint32_t *rank);
 
+/* The factorization M = Alt . CoB that bin/optimizer -A hands to the two chained Optimizer calls (ABOptimiser, plinopt_optimize.inl:1113-1187;
+ * Factorizer / backSolver, plinopt_sparsify.inl:756-867, 924-984) with the build's rule, restated independently of host/plo_host.hpp
+ * `ab_backsolve`: per back-solve (seed seed0 + i, i < loops) a random order of the rows; position i < n takes the first later row that
+ * raises the rank of the rows before it (ranks recomputed from scratch); the first k rows of the resulting order are CoB (k x n) and unit
+ * rows of Alt (m x k); every other row is row . B^-1 with B the first n rows (inverse by Gauss-Jordan).  Best = smallest
+ * (nnz(Alt), non +-1 entries of Alt, nnz(CoB)), earlier seed on ties, starting from (M | 0) . (I ; 0).  Alt (m*k words) and CoB (k*n
+ * words) row major, score[3].  Returns 0, or -2 when m <= n (identity / skipped). */
+int plo_oracle_ab_factor(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                         uint64_t seed0, uint32_t loops, uint32_t k, uint32_t *Alt, uint32_t *CoB, uint32_t *score);
+
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);
 

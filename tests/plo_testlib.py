@@ -377,6 +377,25 @@ class OracleMatrix:
             return OracleMatrix(rows, cols, rp, c, v, self.p)
         return csr(U, self.m, self.n), csr(L, self.m, self.m), rk.value
 
+    def ab_factors(self, seed0, loops, k=None):
+        """(CoB, Alt, score) of the -A method by the oracle's restatement of the build's back-solver rule (plo_oracle_ab_factor); None when m <= n"""
+        k = self.n if k is None else k
+        Alt = (ctypes.c_uint32 * (self.m * k))(); CoB = (ctypes.c_uint32 * (k * self.n))(); sc = (ctypes.c_uint32 * 3)()
+        rc = oracle().plo_oracle_ab_factor(self.m, self.n, _arr(self.rowptr), _arr(self.col), _arr(self.val), self.p, ctypes.c_uint64(seed0), loops, k, Alt, CoB, sc)
+        if rc == -2:
+            return None
+        assert rc == 0
+
+        def csr(D, rows, cols):
+            rp, c, v = [0], [], []
+            for i in range(rows):
+                for j in range(cols):
+                    if D[i * cols + j]:
+                        c.append(j); v.append(D[i * cols + j])
+                rp.append(len(c))
+            return OracleMatrix(rows, cols, rp, c, v, self.p)
+        return csr(CoB, k, self.n), csr(Alt, self.m, k), tuple(sc)
+
     def recsub(self):
         """literal RecSub / RecOptimizer (plinopt_optimize.inl:889-1013): (adds, muls before ProgramGen, muls after, nodes)"""
         a, mr, mf, nd = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()

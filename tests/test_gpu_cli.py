@@ -203,6 +203,22 @@ def test_lu_method_on_gpu_equals_the_oracle_restatement(name):
     assert g and tuple(int(x) for x in g.groups()) == (a, mu, seed, rank), (g and g.groups(), (a, mu, seed, rank))
 
 
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "3x3x3_23_58_L.sms"])
+def test_ab_method_on_gpu_equals_the_oracle_restatement(name):
+    """-A on the GPU (chained-candidate kernel on CoB and Alt), first inner dimension, against the ORACLE: its own restatement of the
+    back-solver rule (1 + N/8 back-solves), then its chained Optimizer minimised over the same N seeds"""
+    from test_host_tools import AB_PAT, ab_oracle_argmin
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    n = 160
+    exp = ab_oracle_argmin(M, 21, n)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "A", "-O", str(n), "--seed", "21", path])
+    assert rc == 0 and "# GPU (A):" in err, err
+    g = re.search(AB_PAT, err)
+    got = tuple(int(x) for x in g.groups())
+    assert (got[:5], got[5], got[6], got[7]) == exp, (got, exp)
+
+
 def test_kernel_method_sharded_over_devices_equals_one_device():
     """-K --gpu 3: the restart range in three shards, one forked child per shard (here all on device 0: PLO_GPU_DEVICES), every shard
     = plo_kernel_search on its block; same winner, counts, decomposition and program as one device."""

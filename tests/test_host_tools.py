@@ -583,3 +583,42 @@ def test_lu_method_equals_the_oracle_restatement(name):
     assert rc == 0, err
     g = re.search(r"# Found G: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\)", err)
     assert g and tuple(int(x) for x in g.groups()) == (a, mu, seed, rank), (g and g.groups(), (a, mu, seed, rank))
+
+
+# ----------------------------------------------------------------------------- -A against the oracle's restatement of the back-solver rule
+def ab_oracle_argmin(M, seed0, n, k=None):
+    """the factorization the oracle finds with 1 + n/8 back-solves (ABOptimiser :1129-1130), then its chained Optimizer on CoB and Alt
+    minimised over n seeds: ((rows, inner, cols, nnz Alt, nnz CoB), adds, muls, seed)"""
+    from plo_testlib import oracle_chain
+    r = M.ab_factors(seed0, 1 + (n >> 3), k)
+    if r is None:
+        return None
+    CoB, Alt, sc = r
+    best = None
+    for s in range(seed0, seed0 + n):
+        a, mu = oracle_chain(CoB, Alt, s)
+        key = (a + mu, a, s)
+        if best is None or key < best:
+            best = key
+    return (Alt.m, Alt.n, CoB.n, sc[0], sc[2]), best[1], best[0] - best[1], best[2]
+
+
+AB_PAT = r"# Found A: \((\d+)x(\d+)x(\d+) (\d+)/(\d+)\)\t(\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\]"
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "3x3x6_40_L.sms", "4x4x4_48_rational_L.sms", "2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms", "3x3x3_23_58_L.sms"])
+def test_ab_method_equals_the_oracle_restatement(name):
+    """`bin/optimizer --only A` (host loop), first inner dimension (= column count): factor shapes and sparsities, winner, counts and seed
+    are those of the oracle's independent restatement of the back-solver rule followed by the oracle's chained Optimizer"""
+    from plo_testlib import OracleMatrix
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    n = 64
+    exp = ab_oracle_argmin(M, 5, n)
+    assert exp is not None
+    rc, out, err = run([OPT, "-q", str(P), "--only", "A", "-O", str(n), "--seed", "5", "--gpu", "0", path])
+    assert rc == 0, err
+    g = re.search(AB_PAT, err)
+    assert g, err
+    got = tuple(int(x) for x in g.groups())
+    assert (got[:5], got[5], got[6], got[7]) == exp, (got, exp)
