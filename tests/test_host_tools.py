@@ -174,7 +174,7 @@ SPS = os.path.join(ROOT, "bin", "sparsifier")
 
 @pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "4x4x4_49_156_P.sms", "2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms",
                                   "3x3x3_23_58_R.sms", "4x4x4_48_rational_P.sms", "3o3o6_Toom4_P.sms", "cyclic.sms"])
-@pytest.mark.parametrize("args", [[], ["-q", "7", "--gpu", "0"], ["-q", str(P), "--gpu", "0", "-b", "1"], ["-U", "0"]])
+@pytest.mark.parametrize("args", [["--gpu", "0"], ["-q", "7", "--gpu", "0"], ["-q", str(P), "--gpu", "0", "-b", "1"], ["-U", "0", "--host-q"]])   # host loops (over Q the GPU is the default)
 def test_sparsifier_factorization_is_consistent(name, args):
     """bin/FDT.sh:64-66: `sparsifier [-q 7] -c 5 file` must print SUCCESS (M == Res . CoB); the residue is never
     denser than the input; stdout carries the change of basis only."""
@@ -189,9 +189,23 @@ def test_sparsifier_factorization_is_consistent(name, args):
     assert lines[0].split()[1] == str(n) and lines[-1] == "0 0 0"          # an n x n matrix in SMS format
 
 
+def test_sparsifier_over_q_needs_the_gpu_unless_told_otherwise():
+    """no silent fallback: without a device `sparsifier file` (rationals, GPU enumeration by default) stops with an error, `--gpu 0` and
+    `--host-q` run the host loops"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    path = os.path.join(DATA, "2x2x2_7_Winograd_L.sms")
+    rc, out, err = run([SPS, "-c", "4", "-S", path])
+    assert rc != 0 and "cannot use the GPU" in err and out == ""
+    for flag in (["--gpu", "0"], ["--host-q"]):
+        rc, out, err = run([SPS, "-c", "4", "-S"] + flag + [path])
+        assert rc == 0 and "SUCCESS" in err
+
+
 def test_sparsifier_finds_the_known_sparse_basis_of_winograd():
     """Winograd's L matrix (14 non-zeros) has an alternative basis with 10 (data/2x2x2_7_DPS-accurate-ALT_L.sms)."""
-    rc, out, err = run([SPS, "-c", "4", "-S", os.path.join(DATA, "2x2x2_7_Winograd_L.sms")])
+    rc, out, err = run([SPS, "-c", "4", "-S", "--gpu", "0", os.path.join(DATA, "2x2x2_7_Winograd_L.sms")])
     assert rc == 0 and re.search(r"with (\d+) non-zeroes", err).group(1) == "10"
 
 
