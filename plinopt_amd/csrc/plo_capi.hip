@@ -1039,9 +1039,8 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         int rc = build_plan(&tmp, &img);
         if (rc != PLO_OK) { cleanup(); return rc; }
         K.PM = tmp.P; K.m = m; K.n = n; K.rank = R; K.ndeps = ndeps; K.per_block = per_block;
+        K.mers = 0; for (uint32_t kk = 2; kk < 31; ++kk) if (p == (1u << kk) - 1u) K.mers = kk;
         uint32_t off = 0;
-        K.off_ech = off;   off += R * n * 4u;
-        K.off_comb = off;  off += R * R * 4u;
         K.off_depc = off;  off += ndeps * R * 4u;
         K.off_vrow = off;  off += 64u * 4u;
         K.off_ord = off;   off += 64u * 2u;
@@ -1049,13 +1048,15 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         K.off_basis = off; off += 64u * 2u;
         K.off_deps = off;  off += 64u * 2u;
         K.scratch_bytes = round_up(off, 16);
+        K.off_vc = round_up(K.PM.tmpl_bytes, 16);                                 // V (m x (n+1)) and C (m x (rank+1)) of the elimination, behind M's template
+        const uint32_t vc_end = K.off_vc + m * (n + 1u + R + 1u) * 4u;
         KCHK(hipMalloc((void **)&d_img, img.size() + 64)); KCHK(hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
         K.PM.tmpl = (const uint64_t *)d_img;
         KCHK(hipMalloc((void **)&d_err, 4)); KCHK(hipMemsetAsync(d_err, 0, 4, g_stream));
         KCHK(hipEventCreate(&e0)); KCHK(hipEventCreate(&e1));
         if (cap_scale == 1) {
             // sizing launch: Dep's pair count over a sample of the decompositions
-            K.region = K.PM.region_bytes;
+            K.region = round_up(std::max(K.PM.region_bytes, vc_end), 16);
             uint32_t W = 0, lds = 0;
             for (uint32_t w : {4u, 2u, 1u}) { const uint32_t l = K.PM.rs_bytes + w * (K.region + K.scratch_bytes); if (l <= g_lds_max) { W = w; lds = l; break; } }
             if (!W) { cleanup(); return fail(PLO_E_CAPACITY, "kernel-method state does not fit LDS"); }
@@ -1083,7 +1084,7 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         for (uint32_t j = 0; j <= ndeps; ++j) rsD[j] = (uint16_t)(j * R);
         KCHK(hipMalloc((void **)&d_rsD, K.PD.rs_bytes)); KCHK(hipMemcpy(d_rsD, rsD.data(), K.PD.rs_bytes, hipMemcpyHostToDevice));
         K.rsD = d_rsD;
-        K.region = std::max(K.PM.region_bytes, K.PD.region_bytes);
+        K.region = round_up(std::max(std::max(K.PM.region_bytes, K.PD.region_bytes), vc_end), 16);
         uint32_t W = 0, lds = 0, bestw = 0;
         for (uint32_t w : {4u, 2u, 1u}) {
             const uint32_t l = K.PM.rs_bytes + K.PD.rs_bytes + w * (K.region + K.scratch_bytes);
@@ -1111,6 +1112,14 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         float ms = 0; KCHK(hipEventElapsedTime(&ms, e0, e1));
         uint32_t err = 0; KCHK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
         st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = lds; st->waves_per_wg = W; st->candidates = nrestarts;
+#ifdef PLO_KM_PROFILE
+        if (getenv("PLO_KM_STATS")) {
+            unsigned long long g[8] = {0};
+            if (hipMemcpyFromSymbol(g, HIP_SYMBOL(plo::g_kprof), sizeof g) == hipSuccess && g[5])
+                fprintf(stderr, "# kernel method, cumulative over %llu restarts: cycles per restart: copy + decomposition %.0f, Free image %.0f, Optimizer on Free %.0f, Dep image %.0f, Optimizer on Dep %.0f; inside the decomposition: elimination loops %.0f, pivot + inverse + stores %.0f\n",
+                        g[5], (double)g[0] / g[5], (double)g[1] / g[5], (double)g[2] / g[5], (double)g[3] / g[5], (double)g[4] / g[5], (double)g[6] / g[5], (double)g[7] / g[5]);
+        }
+#endif
         if (err == plo::ERR_TABLE) { cleanup(); continue; }                      // a pair table filled up: again with twice the slots
         if (err) { cleanup(); return device_error((int)err); }
         if (adds) KCHK(hipMemcpy(adds, d_adds, nrestarts * 4, hipMemcpyDeviceToHost));

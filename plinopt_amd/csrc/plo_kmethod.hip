@@ -33,13 +33,26 @@ namespace plo {
 struct KPlan {
     WavePlan PM, PD;               // PM: plan of M itself (Free has its layout); PD: layout of Dep's image (no template)
     uint32_t m, n, rank, ndeps, per_block;
+    uint32_t mers;                 // k when p = 2^k - 1 (shift-and-add reduction in the elimination), else 0
     uint32_t region;               // bytes of the image region of a wave (max of the two plans)
-    uint32_t off_ech, off_comb, off_depc, off_vrow, off_ord, off_piv, off_basis, off_deps, scratch_bytes;   // elimination scratch behind the region
+    uint32_t off_vc;               // elimination work arrays V, C inside the image region, behind M's template
+    uint32_t off_depc, off_vrow, off_ord, off_piv, off_basis, off_deps, scratch_bytes;   // scratch behind the region
     const uint64_t *rsD;           // row starts of Dep's image (u16, PD.rs_bytes)
 };
+#ifdef PLO_KM_PROFILE
+__device__ unsigned long long g_kprof[8];   // lane 0 of every wave: cycles in image copy + decomposition, Free build, Optimizer on Free, Dep build, Optimizer on Dep; restarts
+#define KP_T(k_) do { const unsigned long long t__ = clock64(); kp_acc[k_] += t__ - kp_t; kp_t = t__; } while (0)
+#else
+#define KP_T(k_) do { } while (0)
+#endif
 struct KInfo { uint32_t *info; };  // optional, 3 words per candidate: rank, NotIndep, dependent rows
 enum { ERR_KDEC = 5 };             // device error word: decomposition inconsistent (rank, table of M)
 
+// product mod p for the elimination: shift-and-add when p is a Mersenne prime (131071 = 2^17 - 1, the tools' usual modulus), Barrett otherwise
+__device__ __forceinline__ uint32_t kmul(uint32_t a, uint32_t b, uint32_t p, uint64_t mu, uint32_t mers) {
+    if (mers) { uint64_t x = (uint64_t)a * b; x = (x & p) + (x >> mers); x = (x & p) + (x >> mers); return (uint32_t)(x >= p ? x - p : x); }
+    return fmul<false>(a, b, p, mu);
+}
 // x^(p-2); x = +-1 are their own inverses
 __device__ __forceinline__ uint32_t kinv(uint32_t x, uint32_t p, uint64_t mu) {
     if (x == 1u || x == p - 1u) return x;
@@ -48,9 +61,9 @@ __device__ __forceinline__ uint32_t kinv(uint32_t x, uint32_t p, uint64_t mu) {
     return res;
 }
 
-struct KScratch { uint32_t *ech, *comb, *depc, *vrow; uint16_t *ord, *piv, *basis, *deps; };
+struct KScratch { uint32_t *depc, *vrow; uint16_t *ord, *piv, *basis, *deps; };
 __device__ __forceinline__ KScratch kscratch(const KPlan &K, uint8_t *scr) {
-    return KScratch{(uint32_t *)(scr + K.off_ech), (uint32_t *)(scr + K.off_comb), (uint32_t *)(scr + K.off_depc), (uint32_t *)(scr + K.off_vrow),
+    return KScratch{(uint32_t *)(scr + K.off_depc), (uint32_t *)(scr + K.off_vrow),
                     (uint16_t *)(scr + K.off_ord), (uint16_t *)(scr + K.off_piv), (uint16_t *)(scr + K.off_basis), (uint16_t *)(scr + K.off_deps)};
 }
 
@@ -61,54 +74,73 @@ __device__ uint32_t kmethod_decompose(const KPlan &K, uint8_t *reg, const KScrat
                                       uint32_t &notindep_out)
 {
     const WavePlan &PM = K.PM;
-    const uint32_t p = PM.p, m = K.m, n = K.n, R = K.rank; const uint64_t mu = PM.mu;
+    const uint32_t p = PM.p, m = K.m, n = K.n, R = K.rank, mers = K.mers; const uint64_t mu = PM.mu;
     const uint32_t *valM = (const uint32_t *)(reg + PM.off_val); const uint16_t *colM = (const uint16_t *)(reg + PM.off_col), *lenM = (const uint16_t *)(reg + PM.off_len);
+    // RIGHT-LOOKING elimination, lanes = rows: V[i] is row i minus the combination C[i] of the basis rows found so far
+    // (row_i = sum_j C[i][j] basis_j + V[i]).  When the row whose turn it is (order of the shuffle) is non-zero it becomes the next
+    // basis row: it is normalised and every row still to come is updated AT ONCE, each lane its own row -- products that do not
+    // depend on each other; the left-looking form reduced one row at a time through a chain of ~16 dependent steps (measured:
+    // 182 k of the 240 k cycles of a decomposition).  Same arithmetic, same results.  V and C live behind M's image in the
+    // wave's region, which nothing else uses before the first Optimizer call (strides n+1 and R+1: no bank conflicts).
+    const uint32_t sv = n + 1u, sc = R + 1u;
+    uint32_t *V = (uint32_t *)(reg + K.off_vc), *C = V + m * sv;
     uint32_t rng = 1u + (uint32_t)(splitmix64(dseed) % 2147483646ull);
     if (lane < m) S.ord[lane] = (uint16_t)lane;
     PLO_WAVE_SYNC();
     if (lane == 0) for (uint32_t i = m; i > 1u; --i) { const uint32_t j = rng_next(rng) % i; const uint16_t t = S.ord[i - 1u]; S.ord[i - 1u] = S.ord[j]; S.ord[j] = t; }
     rng = uni32(rng);
     PLO_WAVE_SYNC();
+    uint32_t mypos = 0xFFFFFFFFu;                                            // place of this lane's row in the order
+    if (lane < m) S.piv[S.ord[lane]] = (uint16_t)lane;                       // (piv doubles as the inverse permutation)
+    PLO_WAVE_SYNC();
+    if (lane < m) {
+        mypos = S.piv[lane];
+        for (uint32_t j = 0; j < n; ++j) V[lane * sv + j] = 0u;
+        for (uint32_t j = 0; j < R; ++j) C[lane * sc + j] = 0u;
+        const uint32_t base = rsM[lane], ln = lenM[lane];
+        for (uint32_t z = 0; z < ln; ++z) V[lane * sv + colM[base + z]] = valM[base + z];
+    }
+    PLO_WAVE_SYNC();
     uint32_t nb = 0, nd = 0;
     for (uint32_t t = 0; t < m; ++t) {
-        const uint32_t row = uni32(S.ord[t]), base = rsM[row], ln = lenM[row];
-        S.vrow[lane] = 0u;
-        PLO_WAVE_SYNC();
-        if (lane < ln) S.vrow[colM[base + lane]] = valM[base + lane];
-        PLO_WAVE_SYNC();
-        uint32_t v = S.vrow[lane], c = 0u;                                   // lanes >= n stay 0
-        for (uint32_t k = 0; k < nb; ++k) {
-            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni32(S.piv[k]));
-            if (x == 0u) continue;
-            const uint32_t e = lane < n ? S.ech[k * n + lane] : 0u, cb = lane < R ? S.comb[k * R + lane] : 0u;
-            const uint32_t xe = fmul<false>(x, e, p, mu), xc = fmul<false>(x, cb, p, mu);
-            v = v >= xe ? v - xe : v + p - xe;
-            c += xc; c -= c >= p ? p : 0u;
-        }
-        const uint64_t nz = __ballot(v != 0u);
-        if (!nz) {                                                           // row = sum_j c[j] * basis row j
-            if (nd < K.ndeps) {                                              // (always: the rank does not depend on the order; the guard keeps a wrong host rank from overrunning the scratch)
-                if (lane == 0) S.deps[nd] = (uint16_t)row;
-                if (lane < R) S.depc[nd * R + lane] = c;
-            }
+        const uint32_t L = uni32(S.ord[t]);
+        const uint32_t vj = lane < n ? V[L * sv + lane] : 0u;
+        const uint64_t nz = __ballot(vj != 0u);
+        if (!nz) {                                                           // row L = sum_j C[L][j] basis_j: dependent
+            if (lane == 0 && nd < K.ndeps) S.deps[nd] = (uint16_t)L;
             ++nd;
-        } else {                                                             // new basis row: echelon row = (row - sum c_j basis_j) / pivot
-            const uint32_t pc = (uint32_t)__builtin_ctzll(nz);
-            const uint32_t iv = kinv((uint32_t)__builtin_amdgcn_readlane((int)v, (int)pc), p, mu);
-            uint32_t cc = 0u;
-            if (lane < nb) { const uint32_t q = fmul<false>(c, iv, p, mu); cc = q ? p - q : 0u; } else if (lane == nb) cc = iv;
-            v = fmul<false>(v, iv, p, mu);
-            if (nb < R) {
-                if (lane < n) S.ech[nb * n + lane] = v;
-                if (lane < R) S.comb[nb * R + lane] = cc;
-                if (lane == 0) { S.piv[nb] = (uint16_t)pc; S.basis[nb] = (uint16_t)row; }
-            }
-            ++nb;
+            continue;
         }
+        if (nb >= R) { ++nb; continue; }                                     // (cannot happen: the rank does not depend on the order)
+        const uint32_t pc = (uint32_t)__builtin_ctzll(nz);
+        const uint32_t iv = kinv((uint32_t)__builtin_amdgcn_readlane((int)vj, (int)pc), p, mu);
+        // the new basis row number nb: echelon row = V[L] / pivot, its combination = (-C[L] / pivot, 1 / pivot at position nb)
+        if (lane < n) V[L * sv + lane] = kmul(vj, iv, p, mu, mers);
+        if (lane < nb) { const uint32_t q = kmul(C[L * sc + lane], iv, p, mu, mers); C[L * sc + lane] = q ? p - q : 0u; }
+        else if (lane == nb) C[L * sc + lane] = iv;
+        if (lane == 0) S.basis[nb] = (uint16_t)L;
+        PLO_WAVE_SYNC();
+        if (lane < m && mypos > t) {                                         // rows still to come
+            const uint32_t x = V[lane * sv + pc];
+            if (x) {
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint32_t e = V[L * sv + j];
+                    if (e) { const uint32_t xe = kmul(x, e, p, mu, mers), w = V[lane * sv + j]; V[lane * sv + j] = w >= xe ? w - xe : w + p - xe; }
+                }
+                for (uint32_t j = 0; j <= nb; ++j) {
+                    const uint32_t cb = C[L * sc + j];
+                    if (cb) { uint32_t w = C[lane * sc + j] + kmul(x, cb, p, mu, mers); w -= w >= p ? p : 0u; C[lane * sc + j] = w; }
+                }
+            }
+        }
+        ++nb;
         PLO_WAVE_SYNC();
     }
     notindep_out = 0;
-    if (nd == 0u || nb != R || nd != K.ndeps) return 0u;                     // (nb != rank(M) cannot happen: the rank does not depend on the order)
+    if (nd == 0u || nb != R || nd != K.ndeps) return 0u;
+    // combinations of the dependent rows, in elimination order, for the Dep image
+    for (uint32_t d = 0; d < nd; ++d) { const uint32_t L = uni32(S.deps[d]); if (lane < R) S.depc[d * R + lane] = C[L * sc + lane]; }
+    PLO_WAVE_SYNC();
     const uint32_t ni = uni32(rng_next(rng) % nd);                           // :792-795
     notindep_out = ni;
     return nd - ni;
@@ -136,12 +168,16 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
     const WavePlan &PM = K.PM, &PD = K.PD;
     const uint32_t p = PM.p, m = K.m, R = K.rank; const uint64_t mu = PM.mu;
     const KScratch S = kscratch(K, scr);
+#ifdef PLO_KM_PROFILE
+    unsigned long long kp_t = clock64(), kp_acc[5] = {0, 0, 0, 0, 0};
+#endif
     for (uint32_t i = lane; i < (PM.tmpl_bytes >> 3); i += 64u) ((uint64_t *)reg)[i] = PM.tmpl[i];
     PLO_WAVE_SYNC();
     uint32_t notindep = 0;
     const uint32_t kept = kmethod_decompose(K, reg, S, rsM, dseed, lane, notindep);
     if (info3 && lane == 0) { info3[0] = R; info3[1] = notindep; info3[2] = kept; }
     if (kept == 0u) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_KDEC); return 0; }
+    KP_T(0);
     bool bad = false;
     {   // ---- Free: M's image minus the kept dependent rows (their pairs retired, their mask bits cleared)
         uint64_t *tab = (uint64_t *)(reg + PM.off_tab), *cmask = (uint64_t *)(reg + PM.off_cmask), *umask = (uint64_t *)(reg + PM.off_umask);
@@ -164,9 +200,11 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
         PLO_WAVE_SYNC();
     }
     if (__ballot(bad)) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_KDEC); return 0; }
+    KP_T(1);
     PickState ps{1u + (uint32_t)(splitmix64(seed) % 2147483646ull), 0u, 0ull, 1ull, 0u};
     const uint64_t r1 = run_candidate<UNITM>(PM, reg, rsM, ps, lane, errw);
     PLO_WAVE_SYNC();
+    KP_T(2);
     {   // ---- Dep: kept rows, columns = rows of M
         uint64_t *tab = (uint64_t *)(reg + PD.off_tab), *cmask = (uint64_t *)(reg + PD.off_cmask), *umask = (uint64_t *)(reg + PD.off_umask);
         uint32_t *val = (uint32_t *)(reg + PD.off_val), *inv = (uint32_t *)(reg + PD.off_inv);
@@ -210,7 +248,12 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
         PLO_WAVE_SYNC();
     }
     if (__ballot(bad)) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_TABLE); return 0; }
+    KP_T(3);
     const uint64_t r2 = run_candidate<false>(PD, reg, rsD, ps, lane, errw);
+    KP_T(4);
+#ifdef PLO_KM_PROFILE
+    if (lane == 0) { for (int q_ = 0; q_ < 5; ++q_) atomicAdd(&g_kprof[q_], kp_acc[q_]); atomicAdd(&g_kprof[5], 1ull); }
+#endif
     return ((uint64_t)((uint32_t)(r1 >> 32) + (uint32_t)(r2 >> 32)) << 32) | ((uint32_t)r1 + (uint32_t)r2);
 }
 
