@@ -451,8 +451,8 @@ int launch(plo_plan *pl, plo::WaveJob J, plo_stats_t *st, float *ms_out)
     if (getenv("PLO_WAVE_STATS")) {
         unsigned long long g[12] = {0};
         if (hipMemcpyFromSymbol(g, HIP_SYMBOL(plo::g_wprof), sizeof g) == hipSuccess && g[9])
-            fprintf(stderr, "# wave kernel, cumulative: %llu candidates, %.1f steps each; cycles per step: max scan %.0f, tie list %.0f, tie pick %.0f, sweep 1 %.0f, sweep 2 %.0f, tail %.0f\n",
-                    g[9], (double)g[8] / g[9], (double)g[0] / g[8], (double)g[1] / g[8], (double)g[2] / g[8], (double)g[3] / g[8], (double)g[4] / g[8], (double)g[5] / g[8]);
+            fprintf(stderr, "# wave kernel, cumulative: %llu candidates, %.1f steps each; cycles per step: max scan %.0f, tie list %.0f, tie pick %.0f, sweep 1 %.0f, sweep 2 %.0f, tail %.0f; sweep 1 trips per step %.2f, per trip: loads + ballots + broadcasts %.0f, retirements %.0f\n",
+                    g[9], (double)g[8] / g[9], (double)g[0] / g[8], (double)g[1] / g[8], (double)g[2] / g[8], (double)g[3] / g[8], (double)g[4] / g[8], (double)g[5] / g[8], (double)g[11] / g[8], g[11] ? (double)g[6] / g[11] : 0.0, g[11] ? (double)g[7] / g[11] : 0.0);
     }
 #endif
     return (int)err;   // >0: device error word

@@ -169,9 +169,9 @@ __device__ __forceinline__ bool tab_dec(uint64_t *tab, uint64_t key, uint32_t ca
     return false;
 }
 // the same for two live keys at once: both probe sequences in flight together (one LDS round trip per round for the pair)
-__device__ __forceinline__ bool tab_dec2(uint64_t *tab, uint64_t k1, uint64_t k2, uint32_t cap, uint32_t hbits) {
+__device__ __forceinline__ bool tab_dec2(uint64_t *tab, uint64_t k1, uint64_t k2, uint32_t cap, uint32_t hbits, bool two = true) {
     uint32_t s1 = tab_hash(k1, hbits), s2 = tab_hash(k2, hbits);
-    bool p1 = true, p2 = true;
+    bool p1 = true, p2 = two;
     for (uint32_t pr = 0; pr < cap && (p1 || p2); ++pr) {
         const uint64_t v1 = lds_ld64(&tab[s1]), v2 = lds_ld64(&tab[s2]);
         if (p1) { if ((v1 >> PLO_VB) == k1) { atomicAdd((unsigned long long *)&tab[s1], ~0ull); p1 = false; } else s1 = (s1 + 1u) & (cap - 1u); }
@@ -472,7 +472,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
     uint32_t ncols = P.n, nbadd = 0, nbmul = 0, nmult = 0;
 
 #ifdef PLO_WAVE_PROFILE
-    unsigned long long wp_t = clock64(), wp_acc[6] = {0, 0, 0, 0, 0, 0}, wp_steps = 0;
+    unsigned long long wp_t = clock64(), wp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wp_steps = 0, wp_s = 0;
 #endif
     for (;;) {
         if (ncols >= NC) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_STEPS); break; }
@@ -536,66 +536,118 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
         if (lane < 2u * mw + 1u) affw[lane] = 0ull;
         PLO_WAVE_SYNC();
         bool bad = false;
-        // sweep 1: rows holding the triple (a,b,r); retire their old pairs (:115-118)
-        for (uint32_t w = 0; w < mw; ++w) {
-            uint64_t msk = uni64(cmask[a * ms + w] & cmask[b * ms + w]);
-            while (msk) {
-                // group g takes the g-th row of the mask (bit arithmetic per lane: no scalar loop over the groups)
-                const uint32_t pc = (uint32_t)__popcll(msk);
-                const int myrow = g < pc ? (int)(w * 64u + nth_set_bit(msk, g)) : -1;
-                if (pc <= G) msk = 0ull;
-                else msk &= ~((2ull << ((uint32_t)__builtin_amdgcn_readlane(myrow, (int)((G - 1u) << P.lpr_log2)) & 63u)) - 1ull);
-                const bool act = myrow >= 0;
-                const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
-                const bool have = t < ln;
-                const uint32_t c = have ? col[base + t] : 0xFFFFu, v = have ? val[base + t] : 0u;
-                const uint32_t iv = UNIT ? v : (have ? inv[base + t] : 0u);
-                const uint64_t ma = __ballot(have && c == a) & gmask, mb = __ballot(have && c == b) & gmask;
-                const uint32_t la = ma ? (uint32_t)__builtin_ctzll(ma) : lane, lb = mb ? (uint32_t)__builtin_ctzll(mb) : lane;
-                const uint32_t va = bcast(v, la), ia = bcast(iv, la), vb = bcast(v, lb), ib = bcast(iv, lb);
-                const bool aff = act && ma && mb && vb == fmul<UNIT>(r, va, p, mu);
-                if (aff && have) {
-                    if (lane != la && lane != lb) {
-                        uint64_t k1 = c < a ? PLO_KEY(c, a, fmul<UNIT>(va, iv, p, mu)) : PLO_KEY(a, c, fmul<UNIT>(v, ia, p, mu));
-                        uint64_t k2 = c < b ? PLO_KEY(c, b, fmul<UNIT>(vb, iv, p, mu)) : PLO_KEY(b, c, fmul<UNIT>(v, ib, p, mu));
-                        bad |= !tab_dec2(tab, k1, k2, cap, hbits);
-                    } else if (lane == la) {
-                        bad |= !tab_dec(tab, key, cap, hbits);
-                        atomicOr((unsigned long long *)&affw[(uint32_t)myrow >> 6], 1ull << ((uint32_t)myrow & 63u));
-                        if (!UNIT) affw[2u * mw] = fmul<UNIT>(va, ib, p, mu);   // 1/r, same in every affected row
-                    }
+        // Most steps touch at most G rows (G = lane groups of a wave): one trip does everything.  The lanes of a group keep their
+        // row's entries in registers across the barrier that separates the retirements (:115-118) from the insertions (:132-142)
+        // -- the table rule "no increment while a decrement is in flight" still holds -- so the row is read, searched for the two
+        // columns and broadcast once, not once per sweep.
+        const uint64_t msk0 = mw == 1u ? uni64(cmask[a * ms] & cmask[b * ms]) : 0ull;
+        if (mw == 1u && (uint32_t)__popcll(msk0) <= G) {
+            const uint32_t pc = (uint32_t)__popcll(msk0);
+            const int myrow = g < pc ? (int)nth_set_bit(msk0, g) : -1;
+            const bool act = myrow >= 0;
+            const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
+            const bool have = t < ln;
+            const uint32_t c = have ? col[base + t] : 0xFFFFu, v = have ? val[base + t] : 0u;
+            const uint32_t iv = UNIT ? v : (have ? inv[base + t] : 0u);
+            const uint64_t ma = __ballot(have && c == a) & gmask, mb = __ballot(have && c == b) & gmask;
+            const uint32_t la = ma ? (uint32_t)__builtin_ctzll(ma) : lane, lb = mb ? (uint32_t)__builtin_ctzll(mb) : lane;
+            const uint32_t va = bcast(v, la), ia = bcast(iv, la), vb = bcast(v, lb), ib = bcast(iv, lb);
+            const bool aff = act && ma && mb && vb == fmul<UNIT>(r, va, p, mu);
+            if (aff && have && lane != lb) {
+                const bool isa = lane == la;
+                const uint64_t k1 = isa ? key : (c < a ? PLO_KEY(c, a, fmul<UNIT>(va, iv, p, mu)) : PLO_KEY(a, c, fmul<UNIT>(v, ia, p, mu)));
+                const uint64_t k2 = c < b ? PLO_KEY(c, b, fmul<UNIT>(vb, iv, p, mu)) : PLO_KEY(b, c, fmul<UNIT>(v, ib, p, mu));
+                bad |= !tab_dec2(tab, k1, k2, cap, hbits, !isa);
+                if (isa) {
+                    atomicOr((unsigned long long *)&affw[0], 1ull << (uint32_t)myrow);
+                    if (!UNIT) affw[2u] = fmul<UNIT>(va, ib, p, mu);           // 1/r, same in every affected row
                 }
             }
-        }
-        PLO_WAVE_SYNC();
-        WP_T(3);
-        // sweep 2: rewrite the rows, add the pairs with the new column (:96-110, :132-142)
-        for (uint32_t w = 0; w < mw; ++w) {
-            uint64_t msk = uni64(affw[w]);
-            while (msk) {
-                // group g takes the g-th row of the mask (bit arithmetic per lane: no scalar loop over the groups)
-                const uint32_t pc = (uint32_t)__popcll(msk);
-                const int myrow = g < pc ? (int)(w * 64u + nth_set_bit(msk, g)) : -1;
-                if (pc <= G) msk = 0ull;
-                else msk &= ~((2ull << ((uint32_t)__builtin_amdgcn_readlane(myrow, (int)((G - 1u) << P.lpr_log2)) & 63u)) - 1ull);
-                const bool act = myrow >= 0;
-                const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
-                const bool have = t < ln;
-                const uint32_t c = have ? col[base + t] : 0xFFFFu, v = have ? val[base + t] : 0u;
-                const uint32_t iv = UNIT ? v : (have ? inv[base + t] : 0u);
-                const uint64_t m0 = __ballot(have && c == l0) & gmask, m1 = __ballot(have && c == l1) & gmask;
-                const uint32_t q0 = m0 ? (uint32_t)__builtin_ctzll(m0) : lane, q1 = m1 ? (uint32_t)__builtin_ctzll(m1) : lane;
-                const uint32_t coeff = bcast(v, q0), icoeff = bcast(iv, q0);
-                if (have) {
-                    if (lane != q0 && lane != q1) {
-                        bad |= !tab_inc(tab, PLO_KEY(c, lm, fmul<UNIT>(coeff, iv, p, mu)), cap, hbits);
-                        const uint32_t np = base + t - (lane > q0 ? 1u : 0u) - (lane > q1 ? 1u : 0u);
-                        col[np] = (uint16_t)c; val[np] = v; if (!UNIT) inv[np] = iv;
-                    } else if (lane == q0) {
-                        const uint32_t np = base + ln - 2u;
-                        col[np] = (uint16_t)lm; val[np] = coeff; if (!UNIT) inv[np] = icoeff;
-                        len[myrow] = (uint16_t)(ln - 1u);
-                        if (UNIT || absone(coeff, p)) atomicOr((unsigned long long *)&affw[mw + ((uint32_t)myrow >> 6)], 1ull << ((uint32_t)myrow & 63u));
+            PLO_WAVE_SYNC();
+            WP_T(3);
+            if (aff && have) {
+                const bool first = l0 == a;                                     // the entry of l0 carries the new column's coefficient
+                const uint32_t q0 = first ? la : lb, q1 = first ? lb : la;
+                const uint32_t coeff = first ? va : vb, icoeff = first ? ia : ib;
+                if (lane != q0 && lane != q1) {
+                    bad |= !tab_inc(tab, PLO_KEY(c, lm, fmul<UNIT>(coeff, iv, p, mu)), cap, hbits);
+                    const uint32_t np = base + t - (lane > q0 ? 1u : 0u) - (lane > q1 ? 1u : 0u);
+                    col[np] = (uint16_t)c; val[np] = v; if (!UNIT) inv[np] = iv;
+                } else if (lane == q0) {
+                    const uint32_t np = base + ln - 2u;
+                    col[np] = (uint16_t)lm; val[np] = coeff; if (!UNIT) inv[np] = icoeff;
+                    len[myrow] = (uint16_t)(ln - 1u);
+                    if (UNIT || absone(coeff, p)) atomicOr((unsigned long long *)&affw[1], 1ull << (uint32_t)myrow);
+                }
+            }
+        } else {
+            // sweep 1: rows holding the triple (a,b,r); retire their old pairs (:115-118)
+            for (uint32_t w = 0; w < mw; ++w) {
+                uint64_t msk = uni64(cmask[a * ms + w] & cmask[b * ms + w]);
+                while (msk) {
+                    // group g takes the g-th row of the mask (bit arithmetic per lane: no scalar loop over the groups)
+                    const uint32_t pc = (uint32_t)__popcll(msk);
+                    const int myrow = g < pc ? (int)(w * 64u + nth_set_bit(msk, g)) : -1;
+                    if (pc <= G) msk = 0ull;
+                    else msk &= ~((2ull << ((uint32_t)__builtin_amdgcn_readlane(myrow, (int)((G - 1u) << P.lpr_log2)) & 63u)) - 1ull);
+                    const bool act = myrow >= 0;
+                    const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
+                    const bool have = t < ln;
+                    const uint32_t c = have ? col[base + t] : 0xFFFFu, v = have ? val[base + t] : 0u;
+                    const uint32_t iv = UNIT ? v : (have ? inv[base + t] : 0u);
+                    const uint64_t ma = __ballot(have && c == a) & gmask, mb = __ballot(have && c == b) & gmask;
+                    const uint32_t la = ma ? (uint32_t)__builtin_ctzll(ma) : lane, lb = mb ? (uint32_t)__builtin_ctzll(mb) : lane;
+                    const uint32_t va = bcast(v, la), ia = bcast(iv, la), vb = bcast(v, lb), ib = bcast(iv, lb);
+                    const bool aff = act && ma && mb && vb == fmul<UNIT>(r, va, p, mu);
+#ifdef PLO_WAVE_PROFILE
+                    { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t__ = clock64(); wp_acc[6] += t__ - wp_t; wp_s = t__; ++wp_acc[9]; }
+#endif
+                    if (aff && have && lane != lb) {
+                        // one probe loop for every lane: the entry of a retires the chosen triple itself, the others their pairs with a and with b
+                        const bool isa = lane == la;
+                        const uint64_t k1 = isa ? key : (c < a ? PLO_KEY(c, a, fmul<UNIT>(va, iv, p, mu)) : PLO_KEY(a, c, fmul<UNIT>(v, ia, p, mu)));
+                        const uint64_t k2 = c < b ? PLO_KEY(c, b, fmul<UNIT>(vb, iv, p, mu)) : PLO_KEY(b, c, fmul<UNIT>(v, ib, p, mu));
+                        bad |= !tab_dec2(tab, k1, k2, cap, hbits, !isa);
+                        if (isa) {
+                            atomicOr((unsigned long long *)&affw[(uint32_t)myrow >> 6], 1ull << ((uint32_t)myrow & 63u));
+                            if (!UNIT) affw[2u * mw] = fmul<UNIT>(va, ib, p, mu);   // 1/r, same in every affected row
+                        }
+                    }
+#ifdef PLO_WAVE_PROFILE
+                    { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t__ = clock64(); wp_acc[7] += t__ - wp_s; wp_t = t__; }
+#endif
+                }
+            }
+            PLO_WAVE_SYNC();
+            WP_T(3);
+            // sweep 2: rewrite the rows, add the pairs with the new column (:96-110, :132-142)
+            for (uint32_t w = 0; w < mw; ++w) {
+                uint64_t msk = uni64(affw[w]);
+                while (msk) {
+                    // group g takes the g-th row of the mask (bit arithmetic per lane: no scalar loop over the groups)
+                    const uint32_t pc = (uint32_t)__popcll(msk);
+                    const int myrow = g < pc ? (int)(w * 64u + nth_set_bit(msk, g)) : -1;
+                    if (pc <= G) msk = 0ull;
+                    else msk &= ~((2ull << ((uint32_t)__builtin_amdgcn_readlane(myrow, (int)((G - 1u) << P.lpr_log2)) & 63u)) - 1ull);
+                    const bool act = myrow >= 0;
+                    const uint32_t base = act ? rs[myrow] : 0u, ln = act ? len[myrow] : 0u;
+                    const bool have = t < ln;
+                    const uint32_t c = have ? col[base + t] : 0xFFFFu, v = have ? val[base + t] : 0u;
+                    const uint32_t iv = UNIT ? v : (have ? inv[base + t] : 0u);
+                    const uint64_t m0 = __ballot(have && c == l0) & gmask, m1 = __ballot(have && c == l1) & gmask;
+                    const uint32_t q0 = m0 ? (uint32_t)__builtin_ctzll(m0) : lane, q1 = m1 ? (uint32_t)__builtin_ctzll(m1) : lane;
+                    const uint32_t coeff = bcast(v, q0), icoeff = bcast(iv, q0);
+                    if (have) {
+                        if (lane != q0 && lane != q1) {
+                            bad |= !tab_inc(tab, PLO_KEY(c, lm, fmul<UNIT>(coeff, iv, p, mu)), cap, hbits);
+                            const uint32_t np = base + t - (lane > q0 ? 1u : 0u) - (lane > q1 ? 1u : 0u);
+                            col[np] = (uint16_t)c; val[np] = v; if (!UNIT) inv[np] = iv;
+                        } else if (lane == q0) {
+                            const uint32_t np = base + ln - 2u;
+                            col[np] = (uint16_t)lm; val[np] = coeff; if (!UNIT) inv[np] = icoeff;
+                            len[myrow] = (uint16_t)(ln - 1u);
+                            if (UNIT || absone(coeff, p)) atomicOr((unsigned long long *)&affw[mw + ((uint32_t)myrow >> 6)], 1ull << ((uint32_t)myrow & 63u));
+                        }
                     }
                 }
             }
@@ -632,7 +684,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
 #endif
     }
 #ifdef PLO_WAVE_PROFILE
-    if (lane == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_wprof[q_], wp_acc[q_]); atomicAdd(&g_wprof[8], wp_steps); }
+    if (lane == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_wprof[q_], wp_acc[q_]); atomicAdd(&g_wprof[8], wp_steps); atomicAdd(&g_wprof[6], wp_acc[6]); atomicAdd(&g_wprof[7], wp_acc[7]); atomicAdd(&g_wprof[10], wp_acc[8]); atomicAdd(&g_wprof[11], wp_acc[9]); }
 #endif
 
     // ---- ProgramGen :513-611
