@@ -184,18 +184,23 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
         uint32_t *val = (uint32_t *)(reg + PM.off_val), *inv = (uint32_t *)(reg + PM.off_inv);
         uint16_t *col = (uint16_t *)(reg + PM.off_col), *len = (uint16_t *)(reg + PM.off_len);
         const uint32_t abs_ = PM.rb + PM.bb, rb = PM.rb;
-        for (uint32_t j = 0; j < kept; ++j) {
-            const uint32_t i = uni32(S.deps[j]), base = rsM[i], ln = len[i];
-            for (uint32_t x = 0; x + 1u < ln; ++x) {
-                const uint32_t y = x + 1u + lane;
-                if (y < ln) {
-                    const uint32_t r = fmul<UNITM>(val[base + y], UNITM ? val[base + x] : inv[base + x], p, mu);
-                    bad |= !tab_dec(tab, ((uint64_t)col[base + x] << abs_) | ((uint64_t)col[base + y] << rb) | r, PM.cap, PM.hbits);
+        // G rows per trip (lane groups of LPR lanes, as in the sweeps of the wave kernel): lane t of a group retires the pairs its
+        // entry forms with every earlier entry of the row, and clears its column's mask bits
+        const uint32_t LPR = 1u << PM.lpr_log2, G = 64u >> PM.lpr_log2, g = lane >> PM.lpr_log2, t = lane & (LPR - 1u);
+        for (uint32_t r0 = 0; r0 < kept; r0 += G) {
+            const bool act = r0 + g < kept;
+            const uint32_t i = act ? (uint32_t)S.deps[r0 + g] : 0u, base = act ? rsM[i] : 0u, ln = act ? (uint32_t)len[i] : 0u;
+            const bool have = t < ln;
+            const uint32_t cy = have ? col[base + t] : 0u, vy = have ? val[base + t] : 0u;
+            for (uint32_t x = 0; x + 1u < PM.maxlen; ++x) {
+                if (have && x < t) {
+                    const uint32_t r = fmul<UNITM>(vy, UNITM ? val[base + x] : inv[base + x], p, mu);
+                    bad |= !tab_dec(tab, ((uint64_t)col[base + x] << abs_) | ((uint64_t)cy << rb) | r, PM.cap, PM.hbits);
                 }
             }
-            if (lane < ln) { const uint32_t c = col[base + lane]; atomicAnd((unsigned long long *)&cmask[c * 2u], ~(1ull << i)); atomicAnd((unsigned long long *)&umask[c * 2u], ~(1ull << i)); }
+            if (have) { atomicAnd((unsigned long long *)&cmask[cy * 2u], ~(1ull << i)); atomicAnd((unsigned long long *)&umask[cy * 2u], ~(1ull << i)); }
             PLO_WAVE_SYNC();
-            if (lane == 0) len[i] = 0;
+            if (act && t == 0u) len[i] = 0;
         }
         PLO_WAVE_SYNC();
     }
@@ -214,16 +219,34 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
         if (lane < m) { cmask[lane * 2u] = 0ull; umask[lane * 2u] = 0ull; }
         if (lane < PD.m) len[lane] = 0;
         PLO_WAVE_SYNC();
-        for (uint32_t j = 0; j < kept; ++j) {
-            bool has; uint32_t pos, x;
-            const uint32_t ln = kmethod_dep_row(K, S, j, lane, has, pos, x);
-            const uint32_t base = rsD[j];
-            if (has) {
-                col[base + pos] = (uint16_t)lane; val[base + pos] = x;
-                atomicOr((unsigned long long *)&cmask[lane * 2u], 1ull << j);
-                if (absone(x, p)) atomicOr((unsigned long long *)&umask[lane * 2u], 1ull << j);
+        // Rows of Dep, G at a time (groups of LPR >= rank lanes).  The columns of Dep are the basis rows of M: lane s of a group
+        // stands for the basis row of s-th smallest index, so a row's entries come out in increasing column order and are
+        // compacted by a ballot over the group.
+        {
+            const uint32_t lprD = PD.lpr_log2, LPRD = 1u << lprD, GD = 64u >> lprD, gD = lane >> lprD, sD = lane & (LPRD - 1u);
+            const uint64_t gmD = (LPRD == 64u) ? ~0ull : (((1ull << LPRD) - 1ull) << (gD << lprD));
+            // basis position of the s-th smallest basis row (the same for every row of Dep)
+            uint32_t bpos = 0, bcol = 0;
+            if (lane < R) {                                                  // lane b: rank of basis row b among the basis rows -> vrow[rank] = b
+                const uint32_t rowb = S.basis[lane]; uint32_t rk = 0;
+                for (uint32_t b2 = 0; b2 < R; ++b2) rk += (uint32_t)S.basis[b2] < rowb ? 1u : 0u;
+                S.vrow[rk] = lane;
             }
-            if (lane == 0) len[j] = (uint16_t)ln;
+            PLO_WAVE_SYNC();
+            if (sD < R) { bpos = S.vrow[sD]; bcol = S.basis[bpos]; }
+            for (uint32_t r0 = 0; r0 < kept; r0 += GD) {
+                const uint32_t j = r0 + gD; const bool act = j < kept && sD < R;
+                const uint32_t x = act ? S.depc[j * R + bpos] : 0u;
+                const bool has = x != 0u;
+                const uint64_t mk = __ballot(has) & gmD;
+                if (has) {
+                    const uint32_t pos = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull)), base = rsD[j];
+                    col[base + pos] = (uint16_t)bcol; val[base + pos] = x;
+                    atomicOr((unsigned long long *)&cmask[bcol * 2u], 1ull << j);
+                    if (absone(x, p)) atomicOr((unsigned long long *)&umask[bcol * 2u], 1ull << j);
+                }
+                if (j < kept && sD == 0u) len[j] = (uint16_t)__popcll(mk);
+            }
         }
         PLO_WAVE_SYNC();
         for (uint32_t idx = lane; idx < kept * R; idx += 64u) {               // inverses of all entries, 64 at a time
