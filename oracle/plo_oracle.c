@@ -760,13 +760,11 @@ static void kd_solve(uint32_t *x, const uint32_t *Bt /* n x r, column j = basis 
     free(A); free(where);
 }
 static uint32_t kd_rank_with(const uint32_t *rows /* k dense rows */, uint32_t k, uint32_t n, uint32_t p) { return rank_mod((uint32_t *)rows, k, n, p); }
-int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p, uint64_t seed,
-                              uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep) {
-    if (p < 2 || m == 0) return -1;
-    uint32_t rng = plo_oracle_rng_state0(seed);
-    uint32_t *ord = (uint32_t *)malloc(m * sizeof(uint32_t));
-    for (uint32_t i = 0; i < m; i++) ord[i] = i;
-    for (uint32_t i = m; i > 1; --i) { uint32_t j = plo_oracle_rng_next(&rng) % i; uint32_t t = ord[i - 1]; ord[i - 1] = ord[j]; ord[j] = t; }
+/* core: the rows in the order `ord`, NotIndep from the stream state *rngp, the two Optimizer calls from the stream of `cseed`;
+ * dep_out (m words) receives the kept dependent rows, depcols (m*m bytes, row major) the columns of Dep's rows (may be NULL) */
+static int kernel_restart_core(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p, const uint32_t *ord, uint32_t *rngp, uint64_t seed,
+                               uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep, uint32_t *dep_out, unsigned char *depcols) {
+    uint32_t rng = *rngp;
     /* greedy basis: a row joins when it raises the rank of the chosen rows (rank by elimination of a copy, as testLinComb does) */
     uint32_t *basis = (uint32_t *)malloc(m * sizeof(uint32_t)), *deps = (uint32_t *)malloc(m * sizeof(uint32_t)); uint32_t r = 0, nd = 0;
     uint32_t *stack = (uint32_t *)calloc((size_t)(m + 1) * n, sizeof(uint32_t)), *tmp = (uint32_t *)malloc((size_t)(m + 1) * n * sizeof(uint32_t));
@@ -798,7 +796,8 @@ int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, co
             kd_solve(x, Bt, n, r, dense, p);
             memset(byrow, 0, m * sizeof(uint32_t));
             for (uint32_t b = 0; b < r; b++) byrow[basis[b]] = x[b];
-            for (uint32_t i = 0; i < m; i++) if (byrow[i]) { cD[wd] = i; vD[wd] = byrow[i]; wd++; }      /* columns ascending */
+            for (uint32_t i = 0; i < m; i++) if (byrow[i]) { cD[wd] = i; vD[wd] = byrow[i]; wd++; if (depcols) depcols[(size_t)j * m + i] = 1; }      /* columns ascending */
+            if (dep_out) dep_out[j] = deps[j];
             rpD[j + 1] = wd;
         }
         rc = plo_oracle_chain(m, n, rpF, cF, vF, kept, m, rpD, cD, vD, p, seed, adds, muls, NULL, NULL);
@@ -807,8 +806,33 @@ int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, co
         if (ndep) *ndep = kept;
         free(rpF); free(cF); free(vF); free(empt); free(Bt); free(rpD); free(cD); free(vD); free(x); free(dense); free(byrow);
     }
-    free(ord); free(basis); free(deps); free(stack); free(tmp);
+    free(basis); free(deps); free(stack); free(tmp);
+    *rngp = rng;
     return rc;
+}
+
+
+int plo_oracle_kernel_restart(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p, uint64_t seed,
+                              uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep) {
+    if (p < 2 || m == 0) return -1;
+    uint32_t rng = plo_oracle_rng_state0(seed);
+    uint32_t *ord = (uint32_t *)malloc(m * sizeof(uint32_t));
+    for (uint32_t i = 0; i < m; i++) ord[i] = i;
+    for (uint32_t i = m; i > 1; --i) { uint32_t j = plo_oracle_rng_next(&rng) % i; uint32_t t = ord[i - 1]; ord[i - 1] = ord[j]; ord[j] = t; }
+    const int rc = kernel_restart_core(m, n, rowptr, col, val, p, ord, &rng, seed, adds, muls, rank, notindep, ndep, NULL, NULL);
+    free(ord);
+    return rc;
+}
+
+/* AllKernelOpt (-N, plinopt_optimize.inl:1357-1418): the same with a PRESCRIBED order of the rows; NotIndep is the first draw of the
+ * stream of dseed, the two Optimizer calls run from the stream of cseed.  dep_out (m words): the kept dependent rows; depcols (m*m
+ * bytes, zeroed by the caller): depcols[j*m + i] = 1 when row j of Dep has an entry in column i. */
+int plo_oracle_kernel_order(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                            const uint32_t *ord, uint64_t dseed, uint64_t cseed,
+                            uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep, uint32_t *dep_out, unsigned char *depcols) {
+    if (p < 2 || m == 0) return -1;
+    uint32_t rng = plo_oracle_rng_state0(dseed);
+    return kernel_restart_core(m, n, rowptr, col, val, p, ord, &rng, cseed, adds, muls, rank, notindep, ndep, dep_out, depcols);
 }
 
 /* ---- LU factors of the -G method (see plo_oracle.h).  Dense restatement: A is eliminated in place, the multipliers of row i against

@@ -148,6 +148,13 @@ int plo_oracle_lu(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t
 int plo_oracle_ab_factor(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
                          uint64_t seed0, uint32_t loops, uint32_t k, uint32_t *Alt, uint32_t *CoB, uint32_t *score);
 
+/* One decomposition of AllKernelOpt (-N, plinopt_optimize.inl:1357-1418): the rows in the PRESCRIBED order `ord`, NotIndep = first draw of the
+ * stream of dseed, then the two Optimizer calls from the stream of cseed.  dep_out (m words) receives the kept dependent rows, depcols
+ * (m*m bytes, zeroed by the caller) the column pattern of Dep.  0, or -2 for a zero dimensional kernel. */
+int plo_oracle_kernel_order(uint32_t m, uint32_t n, const uint32_t *rowptr, const uint32_t *col, const uint32_t *val, uint32_t p,
+                            const uint32_t *ord, uint64_t dseed, uint64_t cseed,
+                            uint32_t *adds, uint32_t *muls, uint32_t *rank, uint32_t *notindep, uint32_t *ndep, uint32_t *dep_out, unsigned char *depcols);
+
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);
 

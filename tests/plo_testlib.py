@@ -396,6 +396,22 @@ class OracleMatrix:
             return OracleMatrix(rows, cols, rp, c, v, self.p)
         return csr(CoB, k, self.n), csr(Alt, self.m, k), tuple(sc)
 
+    def kernel_order(self, order, dseed, cseed):
+        """one decomposition of -N with the prescribed row order (plo_oracle_kernel_order): (adds, muls, rank, notindep, signature) where the
+        signature is the one bin/optimizer uses to recognise equal decompositions: kept dependent rows, m + NotIndep, column pattern of Dep"""
+        m = self.m
+        a, mu, r, ni, nd = (ctypes.c_uint32() for _ in range(5))
+        dep = (ctypes.c_uint32 * m)(); cols = (ctypes.c_ubyte * (m * m))()
+        rc = oracle().plo_oracle_kernel_order(self.m, self.n, _arr(self.rowptr), _arr(self.col), _arr(self.val), self.p, _arr(list(order)),
+                                              ctypes.c_uint64(dseed), ctypes.c_uint64(cseed), ctypes.byref(a), ctypes.byref(mu), ctypes.byref(r),
+                                              ctypes.byref(ni), ctypes.byref(nd), dep, cols)
+        if rc == -2:
+            return None
+        assert rc == 0, rc
+        kept = nd.value
+        sig = tuple(dep[j] for j in range(kept)) + (m + ni.value,) + tuple(i for j in range(kept) for i in range(m) if cols[j * m + i])
+        return a.value, mu.value, r.value, ni.value, sig
+
     def recsub(self):
         """literal RecSub / RecOptimizer (plinopt_optimize.inl:889-1013): (adds, muls before ProgramGen, muls after, nodes)"""
         a, mr, mf, nd = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()

@@ -219,6 +219,20 @@ def test_ab_method_on_gpu_equals_the_oracle_restatement(name):
     assert (got[:5], got[5], got[6], got[7]) == exp, (got, exp)
 
 
+@pytest.mark.parametrize("name", ["2x2x2_7_DPS-accurate_L.sms", "2x2x2_7_Winograd_L.sms"])
+def test_all_row_orders_on_gpu_equal_the_oracle(name):
+    """-N on the GPU (all distinct decompositions in one launch of the batched chain kernel) against the ORACLE's decompositions with
+    prescribed orders: distinct decompositions, restarts each, winner (counts, order, seed)"""
+    from test_host_tools import N_PAT, allkernels_oracle
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    exp = allkernels_oracle(M, 29, 4000)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "N", "-O", "4000", "--seed", "29", path])
+    assert rc == 0 and "GPU kernel" in err, err
+    g = re.search(N_PAT, err)
+    assert g and tuple(int(x) for x in g.groups()) == exp, (g and g.groups(), exp)
+
+
 def test_kernel_method_sharded_over_devices_equals_one_device():
     """-K --gpu 3: the restart range in three shards, one forked child per shard (here all on device 0: PLO_GPU_DEVICES), every shard
     = plo_kernel_search on its block; same winner, counts, decomposition and program as one device."""

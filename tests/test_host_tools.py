@@ -636,3 +636,45 @@ def test_ab_method_equals_the_oracle_restatement(name):
     assert g, err
     got = tuple(int(x) for x in g.groups())
     assert (got[:5], got[5], got[6], got[7]) == exp, (got, exp)
+
+
+# ----------------------------------------------------------------------------- -N against the oracle
+def allkernels_oracle(M, seed0, loops):
+    """AllKernelOpt as bin/optimizer runs it, from the oracle alone: every order of the rows (next_permutation order), equal
+    decompositions recognised by their signature (first order kept), the restarts shared out, best under (cmpOpCount, seed)"""
+    import itertools
+    distinct = {}
+    npi = 0
+    for pi, order in enumerate(itertools.permutations(range(M.m))):
+        r = M.kernel_order(order, seed0 + pi, seed0)
+        assert r is not None
+        distinct.setdefault(r[4], (order, pi))
+        npi = pi + 1
+    per = max(1, loops // len(distinct))
+    best = None
+    for k, sig in enumerate(sorted(distinct)):
+        order, pi = distinct[sig]
+        for j in range(per):
+            s = seed0 + k * per + j
+            a, mu, _, _, _ = M.kernel_order(order, seed0 + pi, s)
+            key = (a + mu, a, s)
+            if best is None or key < best[0]:
+                best = (key, pi)
+    return best[0][1], best[0][0] - best[0][1], best[1], best[0][2], npi, len(distinct), per
+
+
+N_PAT = r"# Found N: (\d+)\|(\d+) instead of \d+\|\d+\t\[order (\d+), seed (\d+)\] \((\d+) row orders, (\d+) distinct decompositions, (\d+) restarts each"
+
+
+@pytest.mark.parametrize("name", ["2x2x2_7_DPS-accurate_L.sms", "2x2x2_7_Winograd_L.sms"])
+def test_all_row_orders_equal_the_oracle(name):
+    """`bin/optimizer --only N` (host loop) against the oracle's decomposition with prescribed orders (plo_oracle_kernel_order): number of
+    distinct decompositions, restarts each, winner (counts, order, seed)"""
+    from plo_testlib import OracleMatrix
+    path = os.path.join(DATA, name)
+    M = OracleMatrix.from_sms(path, P)
+    exp = allkernels_oracle(M, 13, 3000)
+    rc, out, err = run([OPT, "-q", str(P), "--only", "N", "-O", "3000", "--seed", "13", "--gpu", "0", path])
+    assert rc == 0, err
+    g = re.search(N_PAT, err)
+    assert g and tuple(int(x) for x in g.groups()) == exp, (g and g.groups(), exp)
