@@ -147,7 +147,8 @@ int main(int argc, char **argv)
         if (filename.empty()) MQ = read_sms(std::cin);
         else { std::ifstream in(filename); if (!in) return -1; MQ = read_sms(in); }
         if (q != 0) {
-            if (q < 2 || q >= (1ull << 31)) { std::cerr << "# ERROR: modulus must be a prime below 2^31 in this build" << std::endl; return -1; }
+            if (q < 2 || q >= (1ull << 62)) { std::cerr << "# ERROR: modulus must be a prime below 2^62 in this build" << std::endl; return -1; }
+            if (q >= (1ull << 31)) { Zp64Field f(q); return tfactorizer(f, rebind(MQ, f), fmt, innerdim, loops, seed0, blocksize, maxnumcoeff, initialElimination, initialSparsification); }
             ZpField f((uint32_t)q);
             return tfactorizer(f, rebind(MQ, f), fmt, innerdim, loops, seed0, blocksize, maxnumcoeff, initialElimination, initialSparsification);
         }

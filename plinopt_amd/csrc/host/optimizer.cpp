@@ -799,13 +799,18 @@ int main(int argc, char **argv)
         }
         if (replay_only) {
             Ops ops;
-            if (q) { ZpField f((uint32_t)q); std::cout << replay_text(f, rebind(MQ, f), seed0, ops); }
+            if (q >= (1ull << 31)) { Zp64Field f(q); std::cout << replay_text(f, rebind(MQ, f), seed0, ops); }
+            else if (q) { ZpField f((uint32_t)q); std::cout << replay_text(f, rebind(MQ, f), seed0, ops); }
             else { QField f; std::cout << replay_text(f, rebind(MQ, f), seed0, ops); }
             std::clog << "# " << ops.first << "\tadditions\n# " << ops.second << "\tmultiplications" << std::endl;
             return 0;
         }
         if (q != 0) {
-            if (q < 3 || q >= (1ull << 31)) { std::cerr << "# ERROR: modulus must be an odd prime below 2^31 in this build" << std::endl; return -1; }
+            if (q < 3 || q >= (1ull << 62)) { std::cerr << "# ERROR: modulus must be an odd prime below 2^62 in this build" << std::endl; return -1; }
+            if (q >= (1ull << 31)) {                       // the kernels keep 31-bit residues: larger moduli run the host loops (the reference's field is Modular<Integer>, src/optimizer.cpp:131)
+                std::clog << "# modulus above 2^31: host loops (the GPU kernels hold 31-bit residues)" << std::endl;
+                return run(Zp64Field(q), MQ, loops, seed0, 0, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, kfi, verbose, 0, argv[0]);
+            }
             return run(ZpField((uint32_t)q), MQ, loops, seed0, gpu, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, kfi, verbose, (uint32_t)q, argv[0]);
         }
         return run(QField(), MQ, loops, seed0, 0, tryDirect, tryKernel, tryLU, tryAB, mostCSE, allkernels, kfi, verbose, 0, argv[0]);

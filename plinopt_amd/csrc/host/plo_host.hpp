@@ -104,6 +104,47 @@ struct ZpField {
     std::string name() const { return "Z/" + std::to_string(p) + "Z"; }
 };
 
+// Z/pZ for 2^31 <= p < 2^62 (the reference's field is Givaro::Modular<Integer>, src/optimizer.cpp:131: any modulus).  Host loops only: the
+// HIP kernels keep 31-bit residues (44-bit pair keys); the tools fall back to the host engines for these moduli and say so.
+struct Zp64Field {
+    using Elt = uint64_t;
+    uint64_t p;
+    explicit Zp64Field(uint64_t pp) : p(pp) {}
+    Elt zero() const { return 0; }
+    Elt one() const { return 1u % p; }
+    Elt mone() const { return p - 1; }
+    Elt mul(Elt a, Elt b) const { return (Elt)((unsigned __int128)a * b % p); }
+    Elt add(Elt a, Elt b) const { return (Elt)(((unsigned __int128)a + b) % p); }
+    Elt neg(Elt a) const { return a ? p - a : 0; }
+    Elt inv(Elt a) const {
+        __int128 t = 0, nt = 1, r = p, nr = a % p;
+        while (nr) { __int128 q = r / nr, x = t - q * nt; t = nt; nt = x; x = r - q * nr; r = nr; nr = x; }
+        if (r != 1) throw std::domain_error("element not invertible mod p");
+        if (t < 0) t += p;
+        return (Elt)t;
+    }
+    Elt div(Elt a, Elt b) const { return mul(a, inv(b)); }
+    bool isZero(Elt a) const { return a == 0; }
+    bool isOne(Elt a) const { return a == one(); }
+    bool isMOne(Elt a) const { return a == mone(); }
+    bool less(Elt a, Elt b) const { return a < b; }
+    Elt abs(Elt e) const { Elt a = neg(e); return a < e ? a : e; }
+    int sign(Elt e) const { if (!e) return 0; return neg(e) < e ? -1 : 1; }
+    Elt fromRat(const Rat &r) const {
+        __int128 nn = (__int128)r.n % (__int128)p; if (nn < 0) nn += p;
+        Elt dd = (Elt)((__int128)r.d % (__int128)p);
+        if (dd == 0) throw std::domain_error("denominator vanishes mod p");
+        return div((Elt)nn, dd);
+    }
+    Elt fromInt(int64_t v) const { __int128 x = (__int128)v % (__int128)p; if (x < 0) x += p; return (Elt)x; }
+    void write(std::ostream &os, Elt e) const { os << e; }
+    void print_mul(std::ostream &os, char c, size_t i, Elt e, size_t &nbmul) const {
+        os << c << i;
+        if (!(isOne(e) || isMOne(e))) { ++nbmul; os << '*' << e; }
+    }
+    std::string name() const { return "Z/" + std::to_string(p) + "Z"; }
+};
+
 struct QField {
     using Elt = Rat;
     Elt zero() const { return Rat(0); }

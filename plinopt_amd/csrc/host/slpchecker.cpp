@@ -47,6 +47,7 @@ int main(int argc, char **argv)
         else prg = a;
     }
     try {
+        if (q >= (1ull << 31)) return check(Zp64Field(q), prg, mat);
         if (q) return check(ZpField((uint32_t)q), prg, mat);
         return check(QField(), prg, mat);
     } catch (const std::exception &e) {

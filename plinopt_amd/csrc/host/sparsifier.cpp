@@ -206,7 +206,12 @@ int main(int argc, char **argv)
         if (filename.empty()) MQ = read_sms(std::cin);
         else { std::ifstream in(filename); if (!in) return -1; MQ = read_sms(in); }
         if (q != 0) {
-            if (q < 3 || q >= (1ull << 31)) { std::cerr << "# ERROR: modulus must be an odd prime below 2^31 in this build" << std::endl; return -1; }
+            if (q < 3 || q >= (1ull << 62)) { std::cerr << "# ERROR: modulus must be an odd prime below 2^62 in this build" << std::endl; return -1; }
+            if (q >= (1ull << 31)) {                       // the enumeration kernel holds 31-bit residues: host loops
+                std::clog << "# modulus above 2^31: host enumeration" << std::endl;
+                Zp64Field f(q); CobHostBackend<Zp64Field> B;
+                return tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
+            }
             ZpField f((uint32_t)q);
             if (gpu > 0) {
                 HipCob L;

@@ -678,3 +678,24 @@ def test_all_row_orders_equal_the_oracle(name):
     assert rc == 0, err
     g = re.search(N_PAT, err)
     assert g and tuple(int(x) for x in g.groups()) == exp, (g and g.groups(), exp)
+
+
+# ----------------------------------------------------------------------------- moduli above 2^31 (host loops; the reference's field is Modular<Integer>)
+@pytest.mark.parametrize("q", [4294967311, 2305843009213693951])          # just above 2^32; 2^61 - 1
+@pytest.mark.parametrize("name", ["4x4x4_48_rational_L.sms", "2x2x2_7_DPS-accurate_L.sms", "3x3x3_23_58_P.sms"])
+def test_large_moduli_run_the_host_loops_and_verify(name, q):
+    """the HIP kernels hold 31-bit residues; `-q p` with p >= 2^31 runs every method on the host over Z/pZ with 128-bit products, says so,
+    and the program verifies modulo the same p (bin/SLPchecker)"""
+    path = os.path.join(DATA, name)
+    rc, out, err = run([OPT, "-q", str(q), "-O", "40", "-A", path])
+    assert rc == 0 and "modulus above 2^31: host loops" in err and "GPU" not in err.replace("GPU kernels hold", ""), err
+    rc, _, err2 = run([CHK, "-q", str(q), "-M", path], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+
+
+def test_large_modulus_sparsifier_and_factorizer():
+    path = os.path.join(DATA, "2x2x2_7_Winograd_L.sms")
+    rc, out, err = run([SPS, "-q", "4294967311", "-c", "4", "-S", path])
+    assert rc == 0 and "host enumeration" in err and "SUCCESS: consistent factorization" in err
+    rc, out, err = run([os.path.join(ROOT, "bin", "factorizer"), "-q", "4294967311", "-O", "50", "-S", path])
+    assert rc == 0 and "SUCCESS" in err
