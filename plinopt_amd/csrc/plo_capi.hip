@@ -215,6 +215,12 @@ template <class T> int upload(plo_plan *pl, const std::vector<T> &v, const T **d
     return PLO_OK;
 }
 
+const void *big_kernel_fn(const plo::BigPlan &B)
+{
+    if (B.defer) return B.mode == 2u ? (const void *)plo::cse_big_kernel<2, true> : B.mode == 1u ? (const void *)plo::cse_big_kernel<1, true> : (const void *)plo::cse_big_kernel<0, true>;
+    return B.mode == 2u ? (const void *)plo::cse_big_kernel<2, false> : B.mode == 1u ? (const void *)plo::cse_big_kernel<1, false> : (const void *)plo::cse_big_kernel<0, false>;
+}
+
 // Plan for the HBM-resident kernel family (plo_cse_big.hip)
 int build_big_plan(plo_plan *pl)
 {
@@ -288,23 +294,66 @@ int build_big_plan(plo_plan *pl)
     if (const char *e = getenv("PLO_BIG_HBITS")) { const long hb = strtol(e, nullptr, 10); if (hb >= 10 && hb <= 30 && (1ull << hb) > keys.size() + keys.size() / 8) cap = 1ull << hb; }   // experiment knob
     const uint32_t hbits = ceil_log2((uint32_t)std::min<uint64_t>(cap, 1ull << 31));
     if (cap > (1ull << 30)) return fail(PLO_E_CAPACITY, "pair table above 2^30 slots");
-    std::vector<uint64_t> tab(cap, PLO_GEMPTY);
     std::vector<uint32_t> hist(maxf + 2, 0);
-    for (size_t k = 0; k < keys.size(); ++k) {
-        uint32_t s = (uint32_t)((keys[k] * 0x9E3779B97F4A7C15ull) >> (64u - hbits));       // == plo::ghash
-        while (tab[s] != PLO_GEMPTY) s = (s + 1) & (uint32_t)(cap - 1);
-        tab[s] = (keys[k] << PLO_GVB) | cnts[k];
-        ++hist[cnts[k]];
-    }
+    for (size_t k = 0; k < keys.size(); ++k) ++hist[cnts[k]];
     B.m = m; B.n = n; B.nnz = nnz; B.p = p; B.NCmax = (uint32_t)NC; B.hbits = hbits; B.rb = rb; B.bb = bb; B.unit = unit ? 1u : 0u;
     B.maxf0 = maxf + 1; B.M0 = maxf; B.multcap = multcap; B.scr_stride = maxlen;
     B.dmcap = (uint32_t)std::min<uint64_t>(1u << 20, cap); B.hlcap = (uint32_t)std::min<uint64_t>(1u << 18, cap);   // window list: <= hlcap/2 keys per window, ping-pong halves
     B.mu = (~0ull) / p;
     B.mers = 0; for (uint32_t k = 2; k < 31; ++k) if (p == (1u << k) - 1u) B.mers = k;     // Mersenne modulus: shift-and-add reduction
+    // Deferred cold updates (plo_cse_big.hip, "Deferred cold updates"): partitioned store + log + hot table instead of the one big table.
+    // Taken whenever its LDS budget allows (a partition and its share of the log are summed in a 2^13-slot LDS table); PLO_BIG_EAGER=1
+    // keeps the eager table (the A/B switch of the tests).
+    B.defer = 0u;
+    uint64_t topsum = 0;                                      // entries of the M0 longest rows: a step rewrites at most M0 rows
+    { std::vector<uint32_t> ls(m); for (uint32_t i = 0; i < m; ++i) ls[i] = rowptr[i + 1] - rowptr[i];
+      std::sort(ls.begin(), ls.end(), std::greater<uint32_t>());
+      for (uint32_t i = 0; i < m && i < maxf; ++i) topsum += ls[i]; }
+    std::vector<uint64_t> st0; std::vector<uint32_t> pc0;
+    if (B.prune && !getenv("PLO_BIG_EAGER")) {
+        uint32_t pbits = 0; while ((keys.size() >> pbits) > 1280u && pbits < 11u) ++pbits;
+        const uint32_t Pn = 1u << pbits;
+        pc0.assign(Pn, 0u);
+        auto part = [&](uint64_t k) { return pbits ? (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - pbits)) : 0u; };   // == plo::dpart
+        for (uint64_t k : keys) ++pc0[part(k)];
+        const uint32_t maxfill = *std::max_element(pc0.begin(), pc0.end());
+        const uint32_t capp = (maxfill + maxfill / 4u + 64u + 1u) & ~1u;
+        const uint64_t hotmax = std::min<uint64_t>(1ull << 17, pairs0);                 // triples alive at any time <= pair instances of the input
+        const uint64_t stepmax = 3ull * topsum + 3ull * 8192ull;                        // records one step can write
+        if (capp <= 5000u) {
+            const uint64_t lpp = 6400u - capp;                                            // records of a partition's log that still fit the LDS table beside its store
+            uint64_t budget = lpp * Pn * 5ull / 6ull;                                      // (hash imbalance of the partitions' shares)
+            if (budget > stepmax + hotmax + 4096ull) {
+                uint64_t trig = std::min<uint64_t>(budget - stepmax - hotmax - 4096ull, 4ull << 20);
+                if (const char *e = getenv("PLO_BIG_LOGTRIG")) trig = std::min<uint64_t>(trig, std::max<uint64_t>(1, strtoull(e, nullptr, 10)));   // test knob: merges forced by the log
+                const uint64_t logcap = trig + stepmax + hotmax + 4096ull;
+                B.defer = 1u; B.pbits = pbits; B.capp = capp; B.logtrig = (uint32_t)trig; B.logcap = (uint32_t)logcap;
+                B.plcap = (uint32_t)std::min<uint64_t>((logcap * 6ull / 5ull + Pn - 1) / Pn + 64ull, lpp + 64ull);
+                B.hwin = 8192u; if (const char *e = getenv("PLO_BIG_HWIN")) B.hwin = (uint32_t)std::max<long>(1, strtol(e, nullptr, 10));   // test knob: window size (triples kept hot)
+                B.hotbits_min = std::min(16u, std::max(10u, ceil_log2((uint32_t)(4u * std::min<uint64_t>(pairs0, 16384u)))));
+                B.hotbits_max = std::max(B.hotbits_min, std::min(19u, ceil_log2((uint32_t)(4u * hotmax + 1024u))));
+                if (const char *e = getenv("PLO_BIG_HOTBITS")) B.hotbits_min = (uint32_t)std::min<long>(B.hotbits_max, std::max<long>(6, strtol(e, nullptr, 10)));   // test knob: a full hot table is reported and the launch repeated with a larger one
+                B.lgrp = 3000u;
+                st0.assign((size_t)capp * Pn, 0ull);
+                std::vector<uint32_t> fill(Pn, 0u);
+                for (size_t k = 0; k < keys.size(); ++k) { const uint32_t q = part(keys[k]); st0[(size_t)q * capp + fill[q]++] = (keys[k] << PLO_GVB) | cnts[k]; }
+            }
+        }
+    }
     int rc;
     if ((rc = upload(pl, pl->rowptr, &B.rs)) || (rc = upload(pl, ent, &B.ent0)) || (rc = upload(pl, vt, &B.vt)) ||
         (rc = upload(pl, tptr, &B.tptr)) || (rc = upload(pl, trows, &B.trows)) ||
-        (rc = upload(pl, ucount, &B.ucount0)) || (rc = upload(pl, hist, &B.hist0)) || (rc = upload(pl, tab, &B.tab0))) return rc;
+        (rc = upload(pl, ucount, &B.ucount0)) || (rc = upload(pl, hist, &B.hist0))) return rc;
+    if (B.defer) { if ((rc = upload(pl, st0, &B.st0)) || (rc = upload(pl, pc0, &B.pcount0))) return rc; B.tab0 = nullptr; }
+    else {
+        std::vector<uint64_t> tab(cap, PLO_GEMPTY);
+        for (size_t k = 0; k < keys.size(); ++k) {
+            uint32_t s = (uint32_t)((keys[k] * 0x9E3779B97F4A7C15ull) >> (64u - hbits));       // == plo::ghash
+            while (tab[s] != PLO_GEMPTY) s = (s + 1) & (uint32_t)(cap - 1);
+            tab[s] = (keys[k] << PLO_GVB) | cnts[k];
+        }
+        if ((rc = upload(pl, tab, &B.tab0))) return rc;
+    }
     B.nv = (uint32_t)dv.size(); B.vt_lds = (dv.size() <= 512 && !getenv("PLO_BIG_VT_GLOBAL")) ? 1u : 0u;   // (test knob: the global-memory value table)
     B.mode = B.vt_lds ? 1u : 0u; B.nr = 0;
     if (dv.size() <= 32 && !getenv("PLO_BIG_VT_GLOBAL") && !getenv("PLO_BIG_NORID")) {
@@ -328,7 +377,15 @@ int build_big_plan(plo_plan *pl)
     // workspace layout of one candidate
     uint64_t off = 0;
     auto take = [&](uint64_t bytes) { uint64_t o = off; off = (off + bytes + 255) & ~255ull; return o; };
-    B.o_tab = take(cap * 8); B.o_ent = take(((uint64_t)nnz + 64) * 4); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
+    if (B.defer) {
+        // the table region only serves ProgramGen's (column, |v|) multiset: it shares the partitions' logs, idle by then
+        uint64_t pg = 1024; while (pg < 2ull * nnz + 2ull * multcap + 64ull) pg <<= 1;
+        B.hbits = ceil_log2((uint32_t)pg);
+        B.o_plog = take(std::max<uint64_t>(((uint64_t)B.plcap << B.pbits) * 8, pg * 8)); B.o_tab = B.o_plog;
+        B.o_store = take(((uint64_t)B.capp << B.pbits) * 8); B.o_pcount = take(4ull << B.pbits); B.o_ptail = take(4ull << B.pbits);
+        B.o_log = take((uint64_t)B.logcap * 8); B.o_hot = take(8ull << B.hotbits_max);
+    } else B.o_tab = take(cap * 8);
+    B.o_ent = take(((uint64_t)nnz + 64) * 4); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
     B.o_len = take((uint64_t)m * 4); B.o_ucount = take(NC * 4); B.o_cntM = take(NC * 4);
     B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 16); B.o_aff = take((uint64_t)m * 32);
     B.o_ncrptr = take((NC + 2) * 4); B.o_ncr = take(((uint64_t)nnz + 64) * 4);
@@ -345,11 +402,12 @@ int build_big_plan(plo_plan *pl)
       else { B.agg_dual = 0u; B.agg_cb = 16u; } }
     // dynamic LDS, in words: histogram, tables of the mode, then max(ProgramGen scratch, aggregation table: 2^aggbits entries of 8 bytes, 6 in mode 2)
     const uint32_t agg_words = B.mode == 2u ? (1u << B.aggbits) + (1u << B.aggbits) / 2u : 2u << B.aggbits;
-    const uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, agg_words);
-    const uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + (B.nv * B.nv + 3u) / 4u * 2u + (B.nr + 3u) / 4u * 2u + (1u << B.aggbits) / 2u : 0u;   // mode 2: ratio values, ratio ids, inverse ids, slot list of the aggregation table
+    uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, agg_words);
+    uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + (B.nv * B.nv + 3u) / 4u * 2u + (B.nr + 3u) / 4u * 2u + (B.defer ? 0u : (1u << B.aggbits) / 2u) : 0u;   // mode 2: ratio values, ratio ids, inverse ids, slot list of the aggregation table (eager flush only)
+    if (B.defer) { tab_words += PLO_DBLOOM_WORDS; scr_words = std::max<uint32_t>(scr_words, PLO_DMREG_WORDS - PLO_DBLOOM_WORDS); }   // Bloom filter, and 64 KB in all for the merge
     pl->big_lds = (((B.maxf0 + 2u) & ~1u) + tab_words + scr_words) * 4u;
     if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
-    HIPCHK(hipFuncSetAttribute(B.mode == 2u ? (const void *)plo::cse_big_kernel<2> : B.mode == 1u ? (const void *)plo::cse_big_kernel<1> : (const void *)plo::cse_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
+    HIPCHK(hipFuncSetAttribute(big_kernel_fn(B), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));
     if (!pl->d_err) HIPCHK(hipMalloc((void **)&pl->d_err, sizeof(uint32_t)));
     if (!pl->d_best) HIPCHK(hipMalloc((void **)&pl->d_best, sizeof(unsigned long long)));
     if (!pl->d_next) HIPCHK(hipMalloc((void **)&pl->d_next, sizeof(unsigned long long)));
@@ -387,9 +445,18 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, g_stream));
-    if (pl->B.mode == 2u) hipLaunchKernelGGL(plo::cse_big_kernel<2>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
-    else if (pl->B.mode == 1u) hipLaunchKernelGGL(plo::cse_big_kernel<1>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
-    else hipLaunchKernelGGL(plo::cse_big_kernel<0>, dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+    {
+        const plo::BigPlan &B = pl->B;
+        if (B.defer) {
+            if (B.mode == 2u) hipLaunchKernelGGL((plo::cse_big_kernel<2, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            else if (B.mode == 1u) hipLaunchKernelGGL((plo::cse_big_kernel<1, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            else hipLaunchKernelGGL((plo::cse_big_kernel<0, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+        } else {
+            if (B.mode == 2u) hipLaunchKernelGGL((plo::cse_big_kernel<2, false>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            else if (B.mode == 1u) hipLaunchKernelGGL((plo::cse_big_kernel<1, false>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            else hipLaunchKernelGGL((plo::cse_big_kernel<0, false>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+        }
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, g_stream));
     HIPCHK(hipEventSynchronize(e1));
@@ -399,8 +466,10 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     HIPCHK(hipMemcpy(&err, pl->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (st) { st->kernel_ms += ms; st->launches += 1; st->grid = (uint32_t)grid; st->lds_bytes = pl->lds_bytes; st->waves_per_wg = pl->waves_per_wg; st->algo_bytes = pl->algo_bytes; }
     if (getenv("PLO_BIG_STATS")) {
-        uint32_t hs[32] = {0};
+        uint32_t hs[64] = {0};
         if (hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (pl->B.defer && hs[38]) fprintf(stderr, "# big kernel, deferred updates: per candidate %.1f merges (%.2f forced by log/hot pressure), %.0f log records, %.0f hot-table updates; last candidate, merge us: hot->log %u, partition pass %u, sum + write back %u, window %u\n",
+                    (double)hs[33] / hs[38], (double)hs[39] / hs[38], ((double)hs[42] * 4294967296.0 + hs[41]) / hs[38], (double)hs[40] / hs[38], hs[44], hs[45], hs[46], hs[47]);
             fprintf(stderr, "# big kernel (last candidate): steps %u, full scans %u, level rebuilds %u; phase us: level %u select %u rows %u sweep1 %u flush1 %u sweep2 %u flush2 %u tail %u\n",
                     hs[0], hs[1], hs[2], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11]);
 #ifdef PLO_BIG_PROFILE
@@ -418,8 +487,9 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     }
     if (err) {
         static const char *names[] = {"pair table", "frequency/row-count mismatch", "column bound", "level list", "window list", "multiplier list", "tie selection", "ProgramGen"};
+        uint32_t site = 0; (void)hipMemcpy(&site, pl->d_stats + 43, sizeof site, hipMemcpyDeviceToHost);
         return fail(err == plo::BERR_COLS || err == plo::BERR_DM || err == plo::BERR_HL ? PLO_E_CAPACITY : PLO_E_INTERNAL,
-                    std::string("device (HBM variant): ") + (err >= 11 && err <= 18 ? names[err - 11] : "unknown") + " error " + std::to_string(err));
+                    std::string("device (HBM variant): ") + (err >= 11 && err <= 18 ? names[err - 11] : "unknown") + " error " + std::to_string(err) + (site ? " (site " + std::to_string(site) + ")" : ""));
     }
     return PLO_OK;
 }

@@ -78,6 +78,10 @@ struct BigPlan {
     uint8_t *ws; uint64_t ws_stride;
     uint64_t o_tab, o_ent, o_col, o_val, o_inv, o_len, o_ucount, o_cntM, o_dm, o_hl, o_aff, o_ncrptr, o_ncr, o_multc, o_multv,
              o_tcnt, o_tptr2, o_tlist, o_cols2, o_spill;
+    // deferred cold updates (DEFER, see "deferred" below): hot table + partitioned store + update log instead of one big table
+    uint32_t defer, pbits, capp, plcap, logcap, logtrig, hwin, hotbits_min, hotbits_max, lgrp;
+    const uint64_t *st0; const uint32_t *pcount0;     // store image: 2^pbits partitions of capp entries (key48<<16 | count16), entries per partition
+    uint64_t o_store, o_pcount, o_ptail, o_log, o_plog, o_hot;
 };
 
 struct BigJob {
@@ -349,7 +353,7 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_
 // (column << 10 | ratio identifier) in a u32 key array and a u16 count array -- 6 bytes per entry instead of 8, 32-bit
 // LDS operations, and no modular product in the sweep (the identifier comes from a 2-byte table lookup).
 #define PLO_RIDB 10u
-struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint16_t *list; };   // list: mode 2, one u16 per aggregation slot
+struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint16_t *list; uint32_t *bloom; };   // bloom: DEFER, followed by the scratch region   // list: mode 2, one u16 per aggregation slot
 __device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *aggn, uint16_t *agglist, uint32_t listcap) {
     const uint32_t mask = (1u << aggbits) - 1u;
     uint32_t s = (key * 0x9E3779B1u) >> (32u - aggbits);
@@ -397,6 +401,8 @@ struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r, aggn, nspill; uint64_t kprime; uint64_t selkey;
     uint32_t nbisect, spilltot, listover;   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
+    uint32_t logn, hotn, hotbits, nforced, hotops, logtot_lo, logtot_hi;   // DEFER: log fill, claimed hot slots, hot table size; diagnostics: merges forced by log/hot pressure, updates served by the hot table, log entries written
+    uint32_t derr; unsigned long long tmg[4]; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
     uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
 #ifdef PLO_BIG_PROFILE
@@ -415,13 +421,299 @@ struct BigShared {
 #define PLO_STAMP(q_) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); sh.tph[q_] += t_ - tstamp; tstamp = t_; } } while (0)
 #endif
 
+// ===========================================================================
+// Deferred cold updates (template parameter DEFER).  Measured on config 5 (tests/micro/defer_model.cpp): of the 1.2e7
+// retirements and 3.6e6 insertions of a candidate, 99.5 % touch triples whose frequency is below the current window of
+// levels [theta, M] -- only ~8 k triples are ever "hot" at a time -- yet every one of them cost a random 64-byte line of
+// a 64 MB table, both ways: 1.9 of the 3.1 GB of HBM traffic per candidate.  Decisions (max level, tie set, counts at
+// level M) need exact frequencies only inside the window.  So:
+//   hot     open-addressing table of the triples with frequency >= theta (and of spilled insertions), exact, small
+//           (2^16 slots); a Bloom filter in LDS (2^17 bits) says "certainly cold" for almost every other key.
+//   log     a retirement / insertion of a cold triple is ONE 8-byte record key48 | insert flag | d15 appended to a
+//           sequential log (wave-coalesced stores): no read, no random access.
+//   store   the cold triples, 2^pbits partitions by hash prefix, each an unordered array (key48<<16 | count16).
+//   merge   when M falls below theta (or the log / hot table fill up): hot entries go to the log; the log is split by
+//           partition through an LDS staging buffer (runs of ~64 bytes); every partition (group of partitions when they
+//           are small) is summed in an LDS hash table (counts biased by 2^15: records arrive in any order), live
+//           triples (frequency >= 2) are written back compactly and counted per level; the new window [theta', M] is
+//           chosen on the exact histogram and its triples move to the hot table.  All of it is streaming traffic.
+// Frequencies never rise after the step that creates a triple, so a cold triple stays cold until the next merge and the
+// hot table always holds every triple of frequency >= theta: levels >= theta of hist[] stay exact, lower levels are
+// not maintained between merges (never read: a scan that would go below theta triggers the merge).
+// Same results as the eager table, bit for bit (tests/test_gpu_l32cut.py, test_gpu_config5.py, test_gpu_cse_hbm.py).
+// ===========================================================================
+#define PLO_DLB 13u                 /* LDS summing table of a merge: 2^13 slots of 8 bytes */
+#define PLO_DCH 4096u               /* log records per round of the partition pass */
+#define PLO_DBIAS 0x8000u
+#define PLO_DBLOOM_WORDS 4096u      /* 2^17 bits */
+#define PLO_DMREG_WORDS 16384u      /* Bloom filter + scratch region = the merge's 64 KB of LDS */
+#define PLO_DPMAX 2048u             /* partitions: counters, offsets and tails of the partition pass live behind the staging buffer */
+#define PLO_LEMPTY (~0ull)
+static_assert(PLO_DPMAX <= 4u * PLO_BIG_THREADS && PLO_DCH % PLO_BIG_THREADS == 0u && 2u * PLO_DCH + 3u * PLO_DPMAX <= PLO_DMREG_WORDS, "merge layout");
+
+__device__ __forceinline__ uint64_t dmix(uint64_t key) { return key * 0x9E3779B97F4A7C15ull; }
+__device__ __forceinline__ uint32_t dpart(uint64_t key, uint32_t pbits) { return pbits ? (uint32_t)(dmix(key) >> (64u - pbits)) : 0u; }
+__device__ __forceinline__ uint32_t dlslot(uint64_t key, uint32_t pbits, uint32_t lb) { return (uint32_t)((dmix(key) << pbits) >> (64u - lb)); }
+__device__ __forceinline__ bool dbloom_test(const uint32_t *bl, uint64_t key) {
+    const uint64_t g = key * 0xD6E8FEB86659FD93ull;
+    const uint32_t i1 = (uint32_t)(g >> 47), i2 = (uint32_t)(g >> 30) & 0x1FFFFu;
+    const uint32_t w1 = __hip_atomic_load(&bl[i1 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), w2 = __hip_atomic_load(&bl[i2 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (((w1 >> (i1 & 31u)) & (w2 >> (i2 & 31u))) & 1u) != 0u;
+}
+__device__ __forceinline__ void dbloom_set(uint32_t *bl, uint64_t key) {
+    const uint64_t g = key * 0xD6E8FEB86659FD93ull;
+    const uint32_t i1 = (uint32_t)(g >> 47), i2 = (uint32_t)(g >> 30) & 0x1FFFFu;
+    wg_or(&bl[i1 >> 5], 1u << (i1 & 31u)); wg_or(&bl[i2 >> 5], 1u << (i2 & 31u));
+}
+// slot of `key` in the hot table (v = its word), 0xFFFFFFFF when absent.  No slot is ever emptied between merges.
+__device__ __forceinline__ uint32_t hot_slot(const uint64_t *hot, uint64_t key, uint32_t hb, uint64_t &v) {
+    const uint32_t mask = (1u << hb) - 1u;
+    uint32_t s = ghash(key, hb);
+    for (uint32_t pr = 0; pr <= mask; ++pr) {
+        v = gload64(&hot[s]);
+        if ((v >> PLO_GVB) == key) return s;
+        if (v == PLO_GEMPTY) return 0xFFFFFFFFu;
+        s = (s + 1u) & mask;
+    }
+    return 0xFFFFFFFFu;
+}
+// frequency[key] += d in the hot table, claiming EMPTY slots only; returns the frequency before (0 = new key), 0xFFFFFFFF = table full
+__device__ __forceinline__ uint32_t hot_addn(uint64_t *hot, uint64_t key, uint32_t d, uint32_t hb, uint32_t *hotn) {
+    const uint32_t mask = (1u << hb) - 1u;
+    uint32_t s = ghash(key, hb);
+    for (uint32_t pr = 0; pr <= 2u * mask + 1u; ++pr) {
+        const uint64_t v = gload64(&hot[s]);
+        if ((v >> PLO_GVB) == key) { const uint64_t old = wg_add((unsigned long long *)&hot[s], (unsigned long long)d); return (uint32_t)(old & PLO_GVMASK); }
+        if (v == PLO_GEMPTY) {
+            const uint64_t old = wg_cas((unsigned long long *)&hot[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | d));
+            if (old == v) { wg_add(hotn, 1u); return 0u; }
+            continue;                                   // somebody took it: look at the slot again
+        }
+        s = (s + 1u) & mask;
+    }
+    return 0xFFFFFFFFu;
+}
+// log records: key48 << 16 | insert flag (bit 15) | d (15 bits)
+#define PLO_DREC(key_, d_, ins_) (((uint64_t)(key_) << 16) | ((ins_) ? 0x8000ull : 0ull) | (uint64_t)((d_) & 0x7FFFu))
+// wave-collective append of up to three records per lane (all lanes of the wave call it): one counter update per wave,
+// the records of each kind are stored side by side
+__device__ __forceinline__ void dlog_append3(uint64_t *dlog, uint32_t *logn, uint32_t logcap, bool h1, uint64_t e1, bool h2, uint64_t e2, bool h3, uint64_t e3, uint32_t *errflag) {
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(h1), m2 = __builtin_amdgcn_ballot_w64(h2), m3 = __builtin_amdgcn_ballot_w64(h3);
+    const uint32_t n1 = (uint32_t)__builtin_popcountll(m1), n2 = (uint32_t)__builtin_popcountll(m2), n3 = (uint32_t)__builtin_popcountll(m3);
+    if (n1 + n2 + n3 == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t base = 0;
+    if (lane == 0u) base = wg_add(logn, n1 + n2 + n3);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base + n1 + n2 + n3 > logcap) { if (lane == 0u) wg_max(errflag, (uint32_t)BERR_TABLE); return; }
+    if (h1) dlog[base + (uint32_t)__builtin_popcountll(m1 & below)] = e1;
+    if (h2) dlog[base + n1 + (uint32_t)__builtin_popcountll(m2 & below)] = e2;
+    if (h3) dlog[base + n1 + n2 + (uint32_t)__builtin_popcountll(m3 & below)] = e3;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, o); if ((int)lane >= o) v += t; }
+    return v;
+}
+// add `delta` to the biased count of `key` in the LDS summing table (find or claim)
+__device__ __forceinline__ bool lt_put(uint64_t *ltab, uint64_t key, int32_t delta, uint32_t pbits, uint32_t lb) {
+    const uint32_t mask = (1u << lb) - 1u;
+    uint32_t s = dlslot(key, pbits, lb);
+    for (uint32_t pr = 0; pr <= 2u * mask + 1u; ++pr) {
+        const uint64_t v = __hip_atomic_load(&ltab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((v >> 16) == key) { wg_add((unsigned long long *)&ltab[s], (unsigned long long)(long long)delta); return true; }
+        if (v == PLO_LEMPTY) {
+            const uint64_t old = wg_cas((unsigned long long *)&ltab[s], (unsigned long long)PLO_LEMPTY, (unsigned long long)((key << 16) | (uint64_t)(uint32_t)((int32_t)PLO_DBIAS + delta)));
+            if (old == PLO_LEMPTY) return true;
+            continue;
+        }
+        s = (s + 1u) & mask;
+    }
+    return false;
+}
+
+// The merge (all threads of the workgroup).  `mreg` = the Bloom filter followed by the scratch region (PLO_DMREG_WORDS words).
+// first = true: the store is the plan's image and hist[] its histogram, only the window is chosen.
+__device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *hist, uint32_t *mreg, bool first)
+{
+    const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
+    uint64_t *store = (uint64_t *)(ws + P.o_store), *dlog = (uint64_t *)(ws + P.o_log), *plog = (uint64_t *)(ws + P.o_plog), *hot = (uint64_t *)(ws + P.o_hot), *HL = (uint64_t *)(ws + P.o_hl);
+    uint32_t *pcount = (uint32_t *)(ws + P.o_pcount), *ptail = (uint32_t *)(ws + P.o_ptail);
+    const uint32_t pbits = P.pbits, Pn = 1u << pbits, capp = P.capp, plcap = P.plcap;
+    unsigned long long tm0 = wall_clock64();
+#define PLO_MSTAMP(q_) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); sh.tmg[q_] += t_ - tm0; tm0 = t_; } } while (0)
+    if (!first) {
+        // ---- 0. the hot triples go back through the log (they are absent from the store)
+        {
+            const uint32_t hslots = 1u << sh.hotbits;
+            for (uint32_t s0 = 0; s0 < hslots; s0 += nth) {
+                const uint32_t s = s0 + tid;
+                const uint64_t v = s < hslots ? gload64(&hot[s]) : PLO_GEMPTY;
+                const bool have = v != PLO_GEMPTY && (uint32_t)(v & PLO_GVMASK) >= 2u;
+                dlog_append3(dlog, &sh.logn, P.logcap, have, (v & ~PLO_GVMASK) | 0x8000ull | (v & 0x7FFFull), false, 0ull, false, 0ull, &sh.errflag);
+            }
+        }
+        PLO_BIG_FENCE(); BSYNC();
+        PLO_MSTAMP(0);
+        // ---- A. partition pass: PLO_DCH records per round are ranked per partition (LDS counters), laid out by partition in the
+        // staging buffer and written behind the partitions' logs: neighbouring lanes store neighbouring words
+        {
+            uint64_t *stage = (uint64_t *)mreg; uint32_t *cnt = mreg + 2u * PLO_DCH, *pos = cnt + PLO_DPMAX, *tail = pos + PLO_DPMAX;
+            for (uint32_t q = tid; q < Pn; q += nth) tail[q] = 0u;
+            const uint32_t nlog = sh.logn < P.logcap ? sh.logn : P.logcap;
+            constexpr uint32_t U = PLO_DCH / PLO_BIG_THREADS;
+            const uint32_t K = (Pn + nth - 1u) / nth;                       // partitions per thread in the prefix sum (<= 4)
+            for (uint32_t base = 0; base < nlog; base += PLO_DCH) {
+                const uint32_t n = nlog - base < PLO_DCH ? nlog - base : PLO_DCH;
+                for (uint32_t q = tid; q < Pn; q += nth) cnt[q] = 0u;
+                BSYNC();
+                uint64_t e[U]; uint32_t pp[U], rk[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) { const uint32_t idx = u * nth + tid; e[u] = idx < n ? dlog[base + idx] : 0ull; }
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) { const uint32_t idx = u * nth + tid; pp[u] = 0u; rk[u] = 0u; if (idx < n) { pp[u] = dpart(e[u] >> 16, pbits); rk[u] = wg_add(&cnt[pp[u]], 1u); } }
+                BSYNC();
+                {   // exclusive prefix sum of the counters
+                    uint32_t loc[4] = {0u, 0u, 0u, 0u}, sum = 0u;
+                    for (uint32_t k = 0; k < K; ++k) { const uint32_t q = tid * K + k; const uint32_t v = q < Pn ? cnt[q] : 0u; loc[k & 3u] = sum; sum += v; }
+                    const uint32_t inc = wave_incl_scan(sum);
+                    if (lane == 63u) sh.part[wave] = inc;
+                    BSYNC();
+                    uint32_t woff = 0u;
+                    for (uint32_t w = 0; w < wave; ++w) woff += sh.part[w];
+                    for (uint32_t k = 0; k < K; ++k) { const uint32_t q = tid * K + k; if (q < Pn) pos[q] = woff + inc - sum + loc[k & 3u]; }
+                }
+                BSYNC();
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) { const uint32_t idx = u * nth + tid; if (idx < n) stage[pos[pp[u]] + rk[u]] = e[u]; }
+                for (uint32_t q = tid; q < Pn; q += nth) {
+                    const uint32_t c = cnt[q], t = tail[q];
+                    if (t + c > plcap) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 101u); }
+                    tail[q] = t + c; cnt[q] = t - pos[q];                  // position in the partition's log = cnt[q] + position in the staging buffer
+                }
+                BSYNC();
+                for (uint32_t j = tid; j < n; j += nth) {
+                    const uint64_t ee = stage[j];
+                    const uint32_t q = dpart(ee >> 16, pbits), o = cnt[q] + j;
+                    if (o < plcap) plog[(uint64_t)q * plcap + o] = ee;
+                }
+                BSYNC();
+            }
+            for (uint32_t q = tid; q < Pn; q += nth) ptail[q] = tail[q] < plcap ? tail[q] : plcap;
+        }
+        PLO_BIG_FENCE(); BSYNC();
+        PLO_MSTAMP(1);
+        if (sh.errflag) return;
+        // ---- B. every group of partitions is summed in LDS; live triples go back to the store, the histogram is recounted
+        {
+            for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = 0u;
+            uint64_t *ltab = (uint64_t *)mreg;
+            BSYNC();
+            uint32_t p = 0;
+            while (p < Pn) {
+                // the group [p, p + g): as many partitions as fit the table (every wave computes the same bounds)
+                const uint32_t q0 = p + lane;
+                const uint32_t cS = q0 < Pn ? pcount[q0] : 0u, cL = q0 < Pn ? ptail[q0] : 0u;
+                const uint32_t inc = wave_incl_scan(cS + cL);
+                const unsigned long long okm = __builtin_amdgcn_ballot_w64(inc <= P.lgrp);
+                uint32_t g = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
+                if (g == 0u) g = 1u;
+                if (g > Pn - p) g = Pn - p;
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(g - 1u));
+                if (tot > (7u << (PLO_DLB - 3u))) { if (tid == 0) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 102u); } break; }       // more than 7/8 of the table
+                uint32_t lb = 6u; while ((1u << lb) < 2u * tot + 64u && lb < PLO_DLB) ++lb;
+                for (uint32_t s = tid; s < (1u << lb); s += nth) ltab[s] = PLO_LEMPTY;
+                if (tid < 64u) sh.outcnt[tid] = 0u;
+                BSYNC();
+                for (uint32_t j = 0; j < g; ++j) {
+                    const uint32_t nS = (uint32_t)__builtin_amdgcn_readlane((int)cS, (int)j), nL = (uint32_t)__builtin_amdgcn_readlane((int)cL, (int)j);
+                    const uint64_t *sp = store + (uint64_t)(p + j) * capp, *lp = plog + (uint64_t)(p + j) * plcap;
+                    for (uint32_t e = tid; e < nS; e += nth) {
+                        const uint64_t v = sp[e]; const uint32_t c = (uint32_t)(v & PLO_GVMASK);
+                        if (c >= 2u) if (!lt_put(ltab, v >> 16, (int32_t)c, pbits, lb)) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 103u); }
+                    }
+                    for (uint32_t e = tid; e < nL; e += nth) {
+                        const uint64_t v = lp[e]; const int32_t d = (int32_t)(v & 0x7FFFull);
+                        if (!lt_put(ltab, v >> 16, (v & 0x8000ull) ? d : -d, pbits, lb)) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 104u); }
+                    }
+                }
+                BSYNC();
+                for (uint32_t s = tid; s < (1u << lb); s += nth) {
+                    const uint64_t v = ltab[s];
+                    if (v == PLO_LEMPTY) continue;
+                    const uint32_t cb = (uint32_t)(v & 0xFFFFull);
+                    if (cb < PLO_DBIAS + 2u) continue;                       // frequency below 2: never chosen, never rises -- dropped
+                    const uint32_t c = cb - PLO_DBIAS; const uint64_t k = v >> 16;
+                    if (c > P.maxf0) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
+                    wg_add(&hist[c], 1u);
+                    const uint32_t j = dpart(k, pbits) - p;
+                    const uint32_t idx = j < 64u ? wg_add(&sh.outcnt[j], 1u) : capp;
+                    if (idx < capp) store[(uint64_t)(p + j) * capp + idx] = (k << 16) | c; else { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 105u); }
+                }
+                BSYNC();
+                if (tid < g) pcount[p + tid] = sh.outcnt[tid] < capp ? sh.outcnt[tid] : capp;
+                p += g;
+            }
+        }
+        PLO_BIG_FENCE(); BSYNC();
+        PLO_MSTAMP(2);
+        if (sh.errflag) return;
+    }
+    // ---- the new window [theta, M]: at most hwin triples (the whole top level in any case), then the hot table of its triples
+    if (tid == 0) {
+        uint32_t Mx = P.M0; while (Mx >= 2u && hist[Mx] == 0u) --Mx;
+        uint64_t acc = 0; uint32_t th = 2u;
+        if (Mx >= 2u) { th = Mx; for (uint32_t f = Mx; f >= 2u; --f) { if (f != Mx && acc + hist[f] > P.hwin) break; acc += hist[f]; th = f; } }
+        if (acc > P.hlcap / 2u) wg_max(&sh.errflag, (uint32_t)BERR_HL);
+        uint32_t hb = P.hotbits_min; while ((1ull << hb) < 4ull * acc + 1024ull && hb < P.hotbits_max) ++hb;
+        sh.M = Mx >= 2u ? Mx : 0u; sh.theta = th; sh.hotbits = hb; sh.hotn = 0u; sh.hlcount = 0u; sh.logn = 0u; sh.hlbad = 0u; ++sh.fullscans;
+    }
+    BSYNC();
+    if (sh.errflag) return;
+    {
+        const uint32_t hb = sh.hotbits, th = sh.theta;
+        for (uint32_t s = tid; s < (1u << hb); s += nth) hot[s] = PLO_GEMPTY;
+        for (uint32_t w = tid; w < PLO_DBLOOM_WORDS; w += nth) mreg[w] = 0u;
+        PLO_BIG_FENCE(); BSYNC();
+        if (sh.M >= 2u) {
+            for (uint32_t q = wave; q < Pn; q += nwaves) {                    // a wave streams whole partitions: no barrier in this pass
+                const uint32_t n = pcount[q];
+                uint64_t *sp = store + (uint64_t)q * capp;
+                for (uint32_t e0 = 0; e0 < n; e0 += 256u) {
+                    uint64_t v[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) { const uint32_t e = e0 + u * 64u + lane; v[u] = e < n ? sp[e] : 0ull; }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t e = e0 + u * 64u + lane, c = (uint32_t)(v[u] & PLO_GVMASK);
+                        if (e < n && c >= th) {
+                            const uint64_t k = v[u] >> 16;
+                            if (hot_addn(hot, k, c, hb, &sh.hotn) != 0u) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 106u); }
+                            dbloom_set(mreg, k);
+                            const uint32_t idx = wg_add(&sh.hlcount, 1u);
+                            if (idx < P.hlcap) HL[idx] = k; else wg_max(&sh.errflag, (uint32_t)BERR_HL);
+                            sp[e] = v[u] & ~PLO_GVMASK;                       // left the store
+                        }
+                    }
+                }
+            }
+        }
+    }
+    PLO_BIG_FENCE(); BSYNC();
+    PLO_MSTAMP(3);
+#undef PLO_MSTAMP
+}
+
 // ---------------------------------------------------------------------------
 // One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
 // ---------------------------------------------------------------------------
-template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const BigTabs &TB, uint32_t *errw)
+template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const BigTabs &TB, uint32_t *errw)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
-    uint64_t *tab   = (uint64_t *)(ws + P.o_tab);
+    uint64_t *tab   = (uint64_t *)(ws + (DEFER ? P.o_hot : P.o_tab));      // the table the level code and the tie pick look triples up in (DEFER: the hot table)
+    uint64_t *dlog  = (uint64_t *)(ws + P.o_log); uint32_t *bloom = TB.bloom;   // DEFER
     uint32_t *ent   = (uint32_t *)(ws + P.o_ent);
     uint32_t *len   = (uint32_t *)(ws + P.o_len), *ucount = (uint32_t *)(ws + P.o_ucount), *cntM = (uint32_t *)(ws + P.o_cntM);
     uint64_t *DM    = (uint64_t *)(ws + P.o_dm), *HL = (uint64_t *)(ws + P.o_hl);
@@ -436,16 +728,18 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
     // slots claimed in the aggregation table by the running sweep (the flush walks this list, not the table): mode 2 has room
     // for every slot; the other modes keep a short list in the tie-selection buffer, idle during the sweeps, and walk the
     // table when a step claims more
-    uint16_t *agglist = MODE == 2 ? TB.list : (uint16_t *)sh.sel; const uint32_t listcap = MODE == 2 ? (1u << aggbits) : PLO_AGG_LIST;
+    uint16_t *agglist = (MODE == 2 && !DEFER) ? TB.list : (uint16_t *)sh.sel; const uint32_t listcap = (MODE == 2 && !DEFER) ? (1u << aggbits) : PLO_AGG_LIST;   // (DEFER: the Bloom filter has the place of mode 2's full list)
     uint64_t *spill = (uint64_t *)(ws + P.o_spill); const uint32_t spillcap = P.nnz + 64u;   // new-column pairs of entries that found no room in LDS (a step touches every entry at most once)
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
-    const uint32_t p = P.p, hbits = P.hbits, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
+    const uint32_t p = P.p, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
+    uint32_t hbits = DEFER ? P.hotbits_min : P.hbits;                                // DEFER: the hot table is sized anew at every merge
     const uint64_t mu = P.mu, cap = 1ull << P.hbits;
 #define BKEY(a_, b_, r_) (((uint64_t)(a_) << abits) | ((uint64_t)(b_) << rb) | (uint64_t)(r_))
 
     // ---- load the candidate image
     {   // 16-byte copies, 4 in flight per thread (all buffers are 256-byte aligned, sizes padded by the host)
-        const uint4 *s4 = (const uint4 *)P.tab0; uint4 *d4 = (uint4 *)tab; const uint64_t n4 = cap >> 1;
+        const uint4 *s4 = (const uint4 *)(DEFER ? P.st0 : P.tab0); uint4 *d4 = (uint4 *)(DEFER ? (uint64_t *)(ws + P.o_store) : tab);
+        const uint64_t n4 = DEFER ? ((uint64_t)P.capp << P.pbits) >> 1 : cap >> 1;                 // DEFER: the store image (capp is even)
         for (uint64_t s = tid; s < n4; s += 4ull * nth) {
             uint4 x0 = s4[s], x1, x2, x3; const bool b1 = s + nth < n4, b2 = s + 2ull * nth < n4, b3 = s + 3ull * nth < n4;
             if (b1) x1 = s4[s + nth]; if (b2) x2 = s4[s + 2ull * nth]; if (b3) x3 = s4[s + 3ull * nth];
@@ -455,6 +749,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         const uint4 *e4 = (const uint4 *)P.ent0; uint4 *de = (uint4 *)ent;
         for (uint32_t k = tid; k < q4; k += 2u * nth) { uint4 x = e4[k], y; const bool b1 = k + nth < q4; if (b1) y = e4[k + nth]; de[k] = x; if (b1) de[k + nth] = y; }
     }
+    if constexpr (DEFER) { uint32_t *pcount = (uint32_t *)(ws + P.o_pcount); for (uint32_t q = tid; q < (1u << P.pbits); q += nth) pcount[q] = P.pcount0[q]; }
     for (uint32_t i = tid; i < m; i += nth) len[i] = P.rs[i + 1] - P.rs[i];
     for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; }
     for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = P.hist0[f];
@@ -471,14 +766,43 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0; for (int q = 0; q < 16; ++q) sh.pw[q] = 0; for (int c_ = 0; c_ < 4; ++c_) for (int q = 0; q < 8; ++q) sh.tpc[c_][q] = 0;
 #endif
         sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0; sh.nbisect = 0; sh.spilltot = 0; sh.listover = 0;
+        sh.logn = 0; sh.hotn = 0; sh.hotbits = P.hotbits_min; sh.derr = 0; for (int q = 0; q < 4; ++q) sh.tmg[q] = 0; sh.nforced = 0; sh.hotops = 0; sh.logtot_lo = 0; sh.logtot_hi = 0;
     }
     PLO_BIG_FENCE(); BSYNC();
+    bool dfirst = true;                                                       // DEFER: the first merge only chooses the window
 
     bool need_rebuild = true;
     unsigned long long tstamp = wall_clock64();
     for (;;) {
         if (sh.errflag) break;
         // ---- level bookkeeping: lower M while empty (thread 0), decide on a window rescan
+        if constexpr (DEFER) {
+            // levels >= theta are exact; a scan that would go below theta, a full log or a full hot table call for a merge
+            for (;;) {
+                if (tid == 0) {
+                    uint32_t M = sh.M; const uint32_t th = sh.theta;
+                    while (M >= th && hist[M] == 0u) --M;
+                    const bool low = M < th, pressure = sh.logn > P.logtrig || sh.hotn > (1u << sh.hotbits) / 2u || sh.hlbad;
+                    sh.part[0] = (M != sh.M) ? 1u : 0u; sh.part[1] = (low || pressure) ? 1u : 0u;
+                    if (!low) { sh.M = M; if (pressure) ++sh.nforced; }
+                }
+                BSYNC();
+                const bool mg = sh.part[1] != 0u;
+                if (sh.part[0]) need_rebuild = true;
+                BSYNC();
+                if (!mg) break;
+                { const uint32_t ln_ = sh.logn; if (tid == 0) { const uint32_t lo_ = sh.logtot_lo; sh.logtot_lo = lo_ + ln_; if (sh.logtot_lo < lo_) ++sh.logtot_hi; } }
+                defer_merge(P, ws, sh, hist, bloom, dfirst);
+                if (!dfirst) {                                                // the merge worked in the scratch region: the aggregation table is empty again
+                    if constexpr (MODE == 2) { for (uint32_t s = tid; s < (1u << aggbits); s += nth) { aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0; } }
+                    else for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = AEMPTY;
+                    BSYNC();
+                }
+                dfirst = false; need_rebuild = true; hbits = sh.hotbits;
+                if (sh.errflag || sh.M <= 1u) break;
+            }
+            if (sh.errflag) break;
+        } else {
         if (tid == 0) {
             uint32_t M = sh.M;
             while (M >= 2u && hist[M] == 0u) --M;
@@ -486,12 +810,13 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
             sh.M = M;
         }
         BSYNC();
+        }
         const uint32_t M = sh.M;
         if (M <= 1u) break;                                               // OneSub :255
-        if (sh.part[0]) need_rebuild = true;
+        if (!DEFER && sh.part[0]) need_rebuild = true;
         BSYNC();
         if (need_rebuild) {
-            if (M < sh.theta || sh.hlbad) {
+            if (!DEFER && (M < sh.theta || sh.hlbad)) {
                 // full table scan: new window [theta', M] holding at most hlcap/2 keys
                 if (tid == 0) {
                     uint64_t acc = 0; uint32_t th = M;
@@ -735,6 +1060,26 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 // A triple that is not in the table had frequency 1 (pruned): nothing to do for it.
                 const uint64_t k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x);
                 const uint64_t k2 = c < b ? BKEY(c, b, q2) : BKEY(b, c, q2);
+                if constexpr (DEFER) {
+                    // one instance of each retired pair: the hot table when the triple is there, else a log record
+                    for (int w_ = 0; w_ < 2; ++w_) {
+                        const uint64_t kk = w_ ? k2 : k1; const uint32_t fc = w_ ? (c < b ? c : b) : (c < a ? c : a);
+                        bool done = false;
+                        if (dbloom_test(bloom, kk)) {
+                            uint64_t v; const uint32_t sl = hot_slot(tab, kk, hbits, v);
+                            if (sl != 0xFFFFFFFFu) {
+                                const uint32_t o = (uint32_t)(wg_add((unsigned long long *)&tab[sl], ~0ull) & PLO_GVMASK);
+                                if (o) { wg_sub(&hist[o], 1u); if (o > 1u) wg_add(&hist[o - 1u], 1u); if (o == M) { wg_sub(&cntM[fc], 1u); wg_sub(&sh.cblk[fc >> 6], 1u); } }
+                                else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
+                                done = true;
+                            }
+                        }
+                        if (!done) { const uint32_t li = wg_add(&sh.logn, 1u); if (li < P.logcap) dlog[li] = PLO_DREC(kk, 1u, false); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE); }
+                    }
+                    const uint32_t idx = wg_add(&sh.nspill, 1u);
+                    if (idx < spillcap) spill[idx] = BKEY(c, lm, ins); else wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
+                    return;
+                }
                 const uint32_t o1 = gtab_dec(tab, k1, hbits);
                 if (o1) {
                     wg_sub(&hist[o1], 1u); if (o1 > 1u) wg_add(&hist[o1 - 1u], 1u);
@@ -822,6 +1167,93 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
         if (tid == 0) { const int cl = M >= 256u ? 0 : M >= 64u ? 1 : M >= 16u ? 2 : 3; sh.tb1[cl] += wall_clock64() - tstamp; ++sh.nb[cl]; }
 #endif
         PLO_STAMP(3);
+        if constexpr (DEFER) {
+            // Flush (DEFER), ONE pass over the aggregation table: an entry (c, x) x d retires two triples and creates one.  A triple
+            // that may be hot (Bloom filter, then the hot table) is updated there, exactly; everything else is a log record.
+            const uint32_t invr = sh.invr, theta = sh.theta;
+            auto retired = [&](uint64_t k, uint32_t d, uint32_t o) {
+                if (o < d) { { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 201u); } return; }
+                wg_sub(&hist[o], 1u); if (o > d) wg_add(&hist[o - d], 1u);
+                if (o == M) { wg_sub(&cntM[(uint32_t)(k >> abits)], 1u); wg_sub(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u); }
+            };
+            auto inserted = [&](uint64_t k, uint32_t o, uint32_t d) {
+                const uint32_t nc = o + d;
+                if (nc > P.maxf0 || nc > M) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); return; }
+                if (o > 0u) wg_sub(&hist[o], 1u);
+                wg_add(&hist[nc], 1u);
+                if (o < theta && nc >= theta) { uint32_t idx = wg_add(&sh.hlcount, 1u); if (idx < P.hlcap) HL[idx] = k; else sh.hlbad = 1u; }
+                if (nc == M) {
+                    wg_add(&cntM[(uint32_t)(k >> abits)], 1u); wg_add(&sh.cblk[(uint32_t)(k >> abits) >> 6], 1u);
+                    uint32_t idx = wg_add(&sh.dmcount, 1u);
+                    if (idx < P.dmcap) DM[idx] = k; else wg_max(&sh.errflag, (uint32_t)BERR_DM);
+                }
+            };
+            if (tid == 0) {                                                   // the chosen triple loses its M instances (it is of level M >= theta: hot)
+                uint64_t v; const uint32_t sl = hot_slot(tab, key, hbits, v);
+                if (sl == 0xFFFFFFFFu || (uint32_t)(v & PLO_GVMASK) != M) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 202u); }
+                else { gstore64(&tab[sl], v - (uint64_t)M); retired(key, M, M); }
+            }
+            const uint32_t nent = sh.aggn, nslot = nent <= listcap ? nent : (1u << aggbits);     // few entries: walk the slot list, not the table
+            uint32_t nhot = 0;
+            for (uint32_t s0 = 0; s0 < nslot; s0 += nth) {
+                const uint32_t e_ = s0 + tid;
+                bool valid = e_ < nslot; uint32_t c = 0, x = 0, y = 0, d = 0;
+                const uint32_t s = valid ? (nent <= listcap ? (uint32_t)agglist[e_] : e_) : 0u;
+                if constexpr (MODE == 2) {
+                    const uint32_t kq = valid ? aggk[s] : 0xFFFFFFFFu;
+                    valid = kq != 0xFFFFFFFFu;
+                    if (valid) {
+                        d = aggc16[s]; aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0; c = kq >> PLO_RIDB;
+                        const uint32_t xid = kq & ((1u << PLO_RIDB) - 1u);
+                        x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                    }
+                } else {
+                    const uint64_t v = valid ? agg[s] : AEMPTY;
+                    valid = v != AEMPTY;
+                    if (valid) {
+                        agg[s] = AEMPTY;
+                        uint64_t k = v >> acb; d = (uint32_t)(v & ((1ull << acb) - 1ull));
+                        if (P.agg_dual) { y = (uint32_t)(k & ((1ull << rb) - 1ull)); k >>= rb; }
+                        c = (uint32_t)(k >> rb); x = (uint32_t)(k & ((1ull << rb) - 1ull));
+                        if (!P.agg_dual) y = c > a ? (P.invtab ? P.invtab[x] : binv(x, p, mu, mers)) : x;   // v_a / v_c
+                    }
+                }
+                uint64_t k1 = 0, k2 = 0, k3 = 0;
+                if (valid) {
+                    const uint32_t ry = bmul(r, y, p, mu, mers);                        // v_b / v_c
+                    const uint32_t x2 = c < b ? ry : bmul(x, invr, p, mu, mers);
+                    k1 = c < a ? BKEY(c, a, x) : BKEY(a, c, x); k2 = c < b ? BKEY(c, b, x2) : BKEY(b, c, x2);
+                    k3 = BKEY(c, lm, l0 == a ? y : ry);
+                }
+                bool c1 = valid, c2 = valid;                                            // still to be logged
+                if (valid && dbloom_test(bloom, k1)) {
+                    uint64_t v; const uint32_t sl = hot_slot(tab, k1, hbits, v);
+                    if (sl != 0xFFFFFFFFu) { const uint32_t o = (uint32_t)(v & PLO_GVMASK); if (o >= d) gstore64(&tab[sl], v - (uint64_t)d); retired(k1, d, o); c1 = false; ++nhot; }   // ONE writer per slot in this pass: a plain store
+                }
+                if (valid && dbloom_test(bloom, k2)) {
+                    uint64_t v; const uint32_t sl = hot_slot(tab, k2, hbits, v);
+                    if (sl != 0xFFFFFFFFu) { const uint32_t o = (uint32_t)(v & PLO_GVMASK); if (o >= d) gstore64(&tab[sl], v - (uint64_t)d); retired(k2, d, o); c2 = false; ++nhot; }
+                }
+                const bool h3 = valid && d >= theta, c3 = valid && !h3 && d >= 2u;       // (seen once in its only step: frequency 1 for ever, not kept)
+                if (h3) {
+                    const uint32_t o = hot_addn(tab, k3, d, hbits, &sh.hotn);
+                    if (o != 0u) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 203u); } else { inserted(k3, 0u, d); dbloom_set(bloom, k3); ++nhot; }
+                }
+                dlog_append3(dlog, &sh.logn, P.logcap, c1, PLO_DREC(k1, d, false), c2, PLO_DREC(k2, d, false), c3, PLO_DREC(k3, d, true), &sh.errflag);
+            }
+            BSYNC();
+            // entries that found no room in the LDS table: their pairs with the new column were not summed, so the hot table sums
+            // them (exact whatever the total turns out to be; the next merge sends totals below the window back to the store)
+            const uint32_t nsp = sh.nspill < spillcap ? sh.nspill : spillcap;
+            for (uint32_t e = tid; e < nsp; e += nth) {
+                const uint64_t k = spill[e];
+                const uint32_t o = hot_addn(tab, k, 1u, hbits, &sh.hotn);
+                if (o == 0xFFFFFFFFu) { { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 204u); } continue; }
+                inserted(k, o, 1u); dbloom_set(bloom, k); ++nhot;
+            }
+            if (nhot) wg_add(&sh.hotops, nhot);
+            PLO_STAMP(4);
+        } else {
         // Flush, first pass: the summed retirements, one table atomic per distinct triple; the triple itself loses all its M
         // instances.  The pair an entry forms with the NEW column has the same multiplicity as its retirements and its
         // ratio coeff/v_c is a function of (c, x) as well (x or 1/x, times r when coeff = v_b): the entry is rewritten in
@@ -994,6 +1426,7 @@ template <int MODE> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t 
                 if (o == 0xFFFFFFFFu) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); continue; }
                 inserted(k, o, 1u);
             }
+        }
         }
         PLO_STAMP(6);
         BSYNC();
@@ -1274,14 +1707,14 @@ __device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh
     return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | (sh.nbmul + sh.acc1);
 }
 
-template <int MODE> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_big_kernel(BigPlan P, BigJob J)
+template <int MODE, bool DEFER> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_big_kernel(BigPlan P, BigJob J)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bigdyn[];                 // hist[maxf0+1], the value / ratio tables, then per-wave scratch (nwaves * stride)
     __shared__ BigShared sh;
     __shared__ unsigned long long cur;
     uint32_t *hist = bigdyn;
     uint32_t *nextw = bigdyn + ((P.maxf0 + 2u) & ~1u);
-    BigTabs TB{nullptr, nullptr, nullptr, nullptr, nullptr};
+    BigTabs TB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if constexpr (MODE == 1) {                                     // {value, inverse} per value index
         uint2 *vts = (uint2 *)nextw; nextw += 2u * ((P.nv + 1u) & ~1u);
         for (uint32_t k = threadIdx.x; k < P.nv; k += blockDim.x) vts[k] = P.vt[k];
@@ -1294,8 +1727,9 @@ template <int MODE> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_bi
         for (uint32_t k = threadIdx.x; k < P.nr; k += blockDim.x) { rv[k] = P.rval[k]; iv[k] = P.invid[k]; }
         for (uint32_t k = threadIdx.x; k < P.nv * P.nv; k += blockDim.x) rt[k] = P.rtid[k];
         TB.rval = rv; TB.rtid = rt; TB.invid = iv;
-        TB.list = (uint16_t *)nextw; nextw += (1u << P.aggbits) / 2u;
+        if constexpr (!DEFER) { TB.list = (uint16_t *)nextw; nextw += (1u << P.aggbits) / 2u; }
     }
+    if constexpr (DEFER) { TB.bloom = nextw; nextw += PLO_DBLOOM_WORDS; }           // Bloom filter of the hot triples; with the scratch region behind it: the merge's 64 KB
     uint32_t *scratch = nextw;                                     // ProgramGen scratch and the CSE aggregation table share this space
     uint64_t *agg = (uint64_t *)scratch;
     __syncthreads();
@@ -1308,7 +1742,7 @@ template <int MODE> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_bi
         __syncthreads();
         if (c >= J.ncand) break;
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
-        uint64_t ok = big_candidate<MODE>(P, ws, seed, sh, hist, agg, P.aggbits, TB, J.err);
+        uint64_t ok = big_candidate<MODE, DEFER>(P, ws, seed, sh, hist, agg, P.aggbits, TB, J.err);
         uint64_t res = 0;
         __syncthreads();
         if (ok) res = big_program_gen(P, ws, sh, scratch, J.err);
@@ -1318,7 +1752,7 @@ template <int MODE> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_bi
             const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
-            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u);
+            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u); atomicAdd(&J.stats[39], sh.nforced); atomicMax(&J.stats[43], sh.derr); for (int q = 0; q < 4; ++q) J.stats[44 + q] = (uint32_t)(sh.tmg[q] / 100ull); atomicAdd(&J.stats[40], sh.hotops); { const uint32_t lo_ = atomicAdd(&J.stats[41], sh.logtot_lo); if (lo_ + sh.logtot_lo < lo_) atomicAdd(&J.stats[42], 1u); atomicAdd(&J.stats[42], sh.logtot_hi); }
                 J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull);
 #ifdef PLO_BIG_PROFILE
                 for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }
