@@ -386,6 +386,28 @@ __device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, ui
     return done;
 }
 
+// The same probe loop for the staged sweep (mode 2 with deferred updates): a claimed slot sets its bit in a bitmap with a
+// fire-and-forget atomic -- no counter with a returned value, no slot list (two LDS round trips less on the claim path).
+__device__ __forceinline__ bool agg_add_rid_bm(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *bm) {
+    const uint32_t mask = (1u << aggbits) - 1u;
+    uint32_t s = (key * 0x9E3779B1u) >> (32u - aggbits);
+    for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
+        const uint32_t s1 = (s + 1u) & mask;
+        const uint32_t k0 = __hip_atomic_load(&aggk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k1 = __hip_atomic_load(&aggk[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool hit0 = k0 == key, emp0 = k0 == 0xFFFFFFFFu, first = hit0 || emp0;
+        const bool hit = hit0 || (!emp0 && k1 == key), emp = emp0 || (!hit && k1 == 0xFFFFFFFFu);
+        const uint32_t t = first ? s : s1;
+        if (hit) { wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); return true; }
+        if (emp) {
+            const uint32_t old = wg_cas(&aggk[t], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) { if (old != key) wg_or(&bm[t >> 5], 1u << (t & 31u)); wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); return true; }
+            continue;
+        }
+        s = (s + 2u) & mask; pr += 2u;
+    }
+    return false;
+}
+
 // packed row entry: column (15 bits) | +-1 flag (bit 15) | value index (16 bits)
 #define PLO_ECOL(e_) ((e_) & 0x7FFFu)
 #define PLO_EUNIT(e_) (((e_) >> 15) & 1u)
@@ -400,6 +422,7 @@ __device__ __forceinline__ int row_find(const uint32_t *ent, uint32_t base, uint
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r, aggn, nspill; uint64_t kprime; uint64_t selkey;
+    uint32_t sb, sl0;              // the step's second column and the column whose entry the new column takes (for the out-of-line paths)
     uint32_t nbisect, spilltot, listover;   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
     uint32_t logn, hotn, hotbits, nforced, hotops, logtot_lo, logtot_hi;   // DEFER: log fill, claimed hot slots, hot table size; diagnostics: merges forced by log/hot pressure, updates served by the hot table, log entries written
     uint32_t derr; unsigned long long tmg[4]; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
@@ -728,6 +751,8 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
     // slots claimed in the aggregation table by the running sweep (the flush walks this list, not the table): mode 2 has room
     // for every slot; the other modes keep a short list in the tie-selection buffer, idle during the sweeps, and walk the
     // table when a step claims more
+    constexpr bool FAST = MODE == 2 && DEFER;                                  // staged aggregation with deferred claims, bitmap of claimed slots
+    uint32_t *aggbm = (uint32_t *)sh.sel;                                       // FAST: one bit per aggregation slot (2^aggbits <= 2^14 bits; the tie-selection buffer is idle during the sweeps)
     uint16_t *agglist = (MODE == 2 && !DEFER) ? TB.list : (uint16_t *)sh.sel; const uint32_t listcap = (MODE == 2 && !DEFER) ? (1u << aggbits) : PLO_AGG_LIST;   // (DEFER: the Bloom filter has the place of mode 2's full list)
     uint64_t *spill = (uint64_t *)(ws + P.o_spill); const uint32_t spillcap = P.nnz + 64u;   // new-column pairs of entries that found no room in LDS (a step touches every entry at most once)
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
@@ -959,7 +984,8 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
         // ---- RemOneCSE :60-194
         const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
-        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; }
+        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; sh.sb = b; sh.sl0 = l0; }
+        if constexpr (FAST) { for (uint32_t w = tid; w < ((1u << aggbits) + 31u) / 32u; w += nth) aggbm[w] = 0u; }      // (the tie pick used the buffer)
         BSYNC();
 #define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
         {   // rows holding the triple: walk the shorter row list of the two columns
@@ -1039,7 +1065,8 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
                 if constexpr (MODE == 2) {
                     const uint32_t vi = PLO_EVI(e), via = PLO_EVI(ea_);
                     const uint32_t yid = rtid[via * nv + vi], xid = c < a ? yid : (uint32_t)rtid[vi * nv + via];
-                    if (agg_add_rid(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, &sh.aggn, agglist, listcap)) return;
+                    if constexpr (FAST) { if (agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm)) return; }
+                    else if (agg_add_rid(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, &sh.aggn, agglist, listcap)) return;
                     const uint32_t vib = PLO_EVI(eb_), bc = rval[rtid[vib * nv + vi]];                       // v_b / v_c
                     x = rval[xid]; y = rval[yid];
                     q2 = c < b ? bc : rval[rtid[vi * nv + vib]];
@@ -1193,12 +1220,17 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
                 if (sl == 0xFFFFFFFFu || (uint32_t)(v & PLO_GVMASK) != M) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 202u); }
                 else { gstore64(&tab[sl], v - (uint64_t)M); retired(key, M, M); }
             }
-            const uint32_t nent = sh.aggn, nslot = nent <= listcap ? nent : (1u << aggbits);     // few entries: walk the slot list, not the table
+            const uint32_t nent = sh.aggn, nslot = FAST ? (1u << aggbits) / 16u : nent <= listcap ? nent : (1u << aggbits);     // few entries: walk the slot list, not the table (FAST: the bitmap, 16 slots per thread and round)
             uint32_t nhot = 0;
             for (uint32_t s0 = 0; s0 < nslot; s0 += nth) {
-                const uint32_t e_ = s0 + tid;
-                bool valid = e_ < nslot; uint32_t c = 0, x = 0, y = 0, d = 0;
-                const uint32_t s = valid ? (nent <= listcap ? (uint32_t)agglist[e_] : e_) : 0u;
+              const uint32_t e_ = s0 + tid;
+              uint32_t bits_ = 0;
+              if constexpr (FAST) { if (e_ < nslot) bits_ = (aggbm[e_ >> 1] >> ((e_ & 1u) << 4)) & 0xFFFFu; }
+              for (bool more_ = true; more_;) {
+                bool valid; uint32_t s;
+                if constexpr (FAST) { valid = bits_ != 0u; s = valid ? e_ * 16u + (uint32_t)__builtin_ctz(bits_) : 0u; bits_ &= bits_ - 1u; }
+                else { valid = e_ < nslot; s = valid ? (nent <= listcap ? (uint32_t)agglist[e_] : e_) : 0u; }
+                uint32_t c = 0, x = 0, y = 0, d = 0;
                 if constexpr (MODE == 2) {
                     const uint32_t kq = valid ? aggk[s] : 0xFFFFFFFFu;
                     valid = kq != 0xFFFFFFFFu;
@@ -1240,6 +1272,8 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
                     if (o != 0u) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 203u); } else { inserted(k3, 0u, d); dbloom_set(bloom, k3); ++nhot; }
                 }
                 dlog_append3(dlog, &sh.logn, P.logcap, c1, PLO_DREC(k1, d, false), c2, PLO_DREC(k2, d, false), c3, PLO_DREC(k3, d, true), &sh.errflag);
+                if constexpr (FAST) more_ = __builtin_amdgcn_ballot_w64(bits_ != 0u) != 0ull; else more_ = false;
+              }
             }
             BSYNC();
             // entries that found no room in the LDS table: their pairs with the new column were not summed, so the hot table sums
