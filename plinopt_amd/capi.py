@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PLO_HIP_LIB") or os.path.join(_HERE, "libplinopt_hip.so")   # PLO_HIP_LIB: another build of the same library (profiling variants)
+LIB_PATH = os.environ.get("PLO_HIP_LIB") or os.environ.get("PLINOPT_HIP_LIB") or os.path.join(_HERE, "libplinopt_hip.so")   # PLO_HIP_LIB: another build of the same library (profiling variants)
 
 PLO_OK = 0
 PLO_E_ARG, PLO_E_HIP, PLO_E_CAPACITY, PLO_E_UNSUPPORTED, PLO_E_INTERNAL = -1, -2, -3, -4, -5

@@ -47,7 +47,7 @@ struct HipLib {
     decltype(&plo_kernel_search) kernel_search = nullptr;   // optional: -K with the decompositions on the device
     bool load(const char *argv0) {
         std::vector<std::string> cand;
-        if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
+        for (const char *v : {"PLO_HIP_LIB", "PLINOPT_HIP_LIB"}) if (const char *e = getenv(v)) cand.emplace_back(e);   // (one name for the tools and plinopt_amd/capi.py; the older one still works)
         char buf[4096]; ssize_t k = readlink("/proc/self/exe", buf, sizeof buf - 1);
         if (k > 0) { buf[k] = 0; std::string d = dirname(buf); cand.push_back(d + "/../plinopt_amd/libplinopt_hip.so"); cand.push_back(d + "/libplinopt_hip.so"); }
         cand.emplace_back("libplinopt_hip.so");
@@ -594,17 +594,26 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
                 plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
                 plo_best_t b{}; plo_stats_t st{};
                 const int rc = L.kernel_search(&A, q, s0, cnt, 1u, PLO_COST_SUM_THEN_ADD, nullptr, nullptr, nullptr, &b, &st);
-                if (rc != PLO_OK) { snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error()); return o; }
+                if (rc != PLO_OK) { o.rc = rc; snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error()); return o; }
                 o.ok = 1; o.a = b.adds; o.b = b.muls; o.seed = b.seed; o.candidates = st.candidates; o.kernel_ms = st.kernel_ms;
                 L.shutdown();
                 return o;
             };
             std::vector<ShardOut> outs;
-            if (!forked_shards(gpu, seed0, loops, shard, outs)) {
-                for (auto &o : outs) if (!o.ok) ++g_failures, std::cerr << "# \033[1;31mERROR: -K shard failed: " << o.msg << "\033[0m" << std::endl;
-                return 2;
+            bool kshards_ok = forked_shards(gpu, seed0, loops, shard, outs), refused = false;
+            if (!kshards_ok) {
+                // A shard whose plan the device refuses (PLO_E_UNSUPPORTED / PLO_E_CAPACITY: state beyond LDS, table bounds) is what the
+                // single-device path answers with host decompositions + the batched chain kernel: leave the method to kernel_method then.
+                refused = true;
+                for (auto &o : outs) if (!o.ok && o.rc != PLO_E_UNSUPPORTED && o.rc != PLO_E_CAPACITY) refused = false;
+                if (!refused) {
+                    for (auto &o : outs) if (!o.ok) ++g_failures, std::cerr << "# \033[1;31mERROR: -K shard failed: " << o.msg << "\033[0m" << std::endl;
+                    return 2;
+                }
+                if (verbose > 0) std::clog << "# -K: the device refused the one-wave restart (" << outs[0].msg << "): host decompositions + batched chain kernel on one device" << std::endl;
             }
             bool have = false;
+            if (!refused)
             for (auto &o : outs) {
                 g_kshard.ncand += o.candidates; g_kshard.kms = std::max(g_kshard.kms, o.kernel_ms);
                 if (o.a == 0xFFFFFFFFu && o.b == 0xFFFFFFFFu) continue;

@@ -16,6 +16,9 @@
 #include <algorithm>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <signal.h>
+#include <cerrno>
+#include <cstring>
 #include <array>
 #include <cstdint>
 #include <cstdlib>
@@ -841,7 +844,7 @@ inline bool cmp_op_count(std::pair<size_t, size_t> a, std::pair<size_t, size_t> 
 // single device finds.  Children are forked BEFORE this process touches the HIP runtime (a runtime does not survive
 // fork) and each opens its own device; results come back over a pipe as plain structs.
 // PLO_GPU_DEVICES="0,0,1": device ordinal per shard (default: shard r on device r) -- lets a one-GPU box run N shards.
-struct ShardOut { int32_t ok; uint32_t a, b, c; uint64_t seed; uint64_t variant; uint64_t candidates; double kernel_ms; char msg[192]; };
+struct ShardOut { int32_t ok; int32_t rc; uint32_t a, b, c; uint64_t seed; uint64_t variant; uint64_t candidates; double kernel_ms; char msg[192]; };   // rc: the library's return code of a failed shard (0 otherwise)
 inline void shard_block(uint64_t seed0, uint64_t n, int rank, int world, uint64_t &s, uint64_t &cnt) {
     const uint64_t q = n / (uint64_t)world, r = n % (uint64_t)world;
     s = seed0 + (uint64_t)rank * q + std::min<uint64_t>((uint64_t)rank, r); cnt = q + ((uint64_t)rank < r ? 1 : 0);
@@ -857,11 +860,19 @@ inline int shard_device(int rank) {
 template <class Fn> bool forked_shards(int world, uint64_t seed0, uint64_t n, Fn fn, std::vector<ShardOut> &out) {
     out.assign((size_t)world, ShardOut{});
     std::vector<int> fds((size_t)world, -1); std::vector<pid_t> pids((size_t)world, -1);
+    // a failed pipe() or fork(): close what was opened, reap the children already started (they finish their shard: a child is never
+    // left running on its GPU as an orphan) and say why
+    auto abandon = [&](int upto, const char *what) {
+        const int err = errno;
+        for (int k = 0; k < upto; ++k) { if (fds[(size_t)k] >= 0) close(fds[(size_t)k]); if (pids[(size_t)k] > 0) { kill(pids[(size_t)k], SIGTERM); int st = 0; waitpid(pids[(size_t)k], &st, 0); } }
+        for (auto &o : out) { o.ok = 0; snprintf(o.msg, sizeof o.msg, "%s: %s", what, strerror(err)); }
+        return false;
+    };
     for (int r = 0; r < world; ++r) {
-        int pfd[2]; if (pipe(pfd) != 0) return false;
+        int pfd[2]; if (pipe(pfd) != 0) return abandon(r, "pipe");
         std::cout.flush(); std::clog.flush();
         const pid_t pid = fork();
-        if (pid < 0) return false;
+        if (pid < 0) { close(pfd[0]); close(pfd[1]); return abandon(r, "fork"); }
         if (pid == 0) {
             close(pfd[0]);
             uint64_t s, cnt; shard_block(seed0, n, r, world, s, cnt);

@@ -29,7 +29,7 @@ struct HipCob {
     decltype(&plo_cob_search) cob_search = nullptr;
     bool load() {
         std::vector<std::string> cand;
-        if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
+        for (const char *v : {"PLO_HIP_LIB", "PLINOPT_HIP_LIB"}) if (const char *e = getenv(v)) cand.emplace_back(e);   // (one name for the tools and plinopt_amd/capi.py; the older one still works)
         char buf[4096]; ssize_t k = readlink("/proc/self/exe", buf, sizeof buf - 1);
         if (k > 0) { buf[k] = 0; std::string d = dirname(buf); cand.push_back(d + "/../plinopt_amd/libplinopt_hip.so"); cand.push_back(d + "/libplinopt_hip.so"); }
         cand.emplace_back("libplinopt_hip.so");
@@ -94,6 +94,7 @@ struct CobGpuQBackend : CobBackend<QField> {
                 for (size_t k = 0; k < n * n; ++k) cd[k] = red(cdi[k]);
                 for (size_t k = 0; k < C; ++k) cf[k] = red(cfi[k]);
                 const int rc = L.cob_search((uint32_t)n, (uint32_t)m, tm.data(), cd.data(), (uint32_t)row, (uint32_t)off, cf.data(), (uint32_t)C, primes[q], w0, w1, &b[q], &st[q]);
+                if (rc == PLO_E_CAPACITY || rc == PLO_E_UNSUPPORTED) throw std::range_error(std::string("the device refused this enumeration (") + L.last_error() + ")");   // e.g. more than 255 coefficients: the host enumerates, as it does for entries too large for the primes
                 if (rc != PLO_OK) throw std::runtime_error(std::string("GPU CoB search failed: ") + L.last_error());
                 kernel_ms += st[q].kernel_ms;
             }

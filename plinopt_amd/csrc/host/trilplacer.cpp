@@ -27,7 +27,7 @@ struct HipTril {
     decltype(&plo_tril_plan_create_x) create = nullptr; decltype(&plo_tril_plan_destroy) destroy = nullptr; decltype(&plo_tril_search) search = nullptr;
     bool load() {
         std::vector<std::string> cand;
-        if (const char *e = getenv("PLINOPT_HIP_LIB")) cand.emplace_back(e);
+        for (const char *v : {"PLO_HIP_LIB", "PLINOPT_HIP_LIB"}) if (const char *e = getenv(v)) cand.emplace_back(e);   // (one name for the tools and plinopt_amd/capi.py; the older one still works)
         char buf[4096]; ssize_t k = readlink("/proc/self/exe", buf, sizeof buf - 1);
         if (k > 0) { buf[k] = 0; std::string d = dirname(buf); cand.push_back(d + "/../plinopt_amd/libplinopt_hip.so"); cand.push_back(d + "/libplinopt_hip.so"); }
         cand.emplace_back("libplinopt_hip.so");

@@ -321,7 +321,7 @@ int build_big_plan(plo_plan *pl)
         const uint64_t hotmax = std::min<uint64_t>(1ull << 17, pairs0);                 // triples alive at any time <= pair instances of the input
         const uint64_t stepmax = 3ull * topsum + 3ull * 8192ull;                        // records one step can write
         if (capp <= 5000u) {
-            const uint64_t lpp = 6400u - capp;                                            // records of a partition's log that still fit the LDS table beside its store
+            const uint64_t lpp = 6080u - capp;                                            // records of a partition's log that still fit the merge beside its live triples (12 records per thread, an LDS table of 2^13 slots)
             uint64_t budget = lpp * Pn * 5ull / 6ull;                                      // (hash imbalance of the partitions' shares)
             if (budget > stepmax + hotmax + 4096ull) {
                 uint64_t trig = std::min<uint64_t>(budget - stepmax - hotmax - 4096ull, 4ull << 20);
@@ -336,7 +336,7 @@ int build_big_plan(plo_plan *pl)
                 B.lgrp = 3000u;
                 st0.assign((size_t)capp * Pn, 0ull);
                 std::vector<uint32_t> fill(Pn, 0u);
-                for (size_t k = 0; k < keys.size(); ++k) { const uint32_t q = part(keys[k]); st0[(size_t)q * capp + fill[q]++] = (keys[k] << PLO_GVB) | cnts[k]; }
+                for (size_t k = 0; k < keys.size(); ++k) { const uint32_t q = part(keys[k]); st0[(size_t)q * capp + fill[q]++] = (keys[k] << PLO_GVB) | 0x8000ull | cnts[k]; }   // a record: key | insert flag | frequency
             }
         }
     }
@@ -381,8 +381,8 @@ int build_big_plan(plo_plan *pl)
         // the table region only serves ProgramGen's (column, |v|) multiset: it shares the partitions' logs, idle by then
         uint64_t pg = 1024; while (pg < 2ull * nnz + 2ull * multcap + 64ull) pg <<= 1;
         B.hbits = ceil_log2((uint32_t)pg);
-        B.o_plog = take(std::max<uint64_t>(((uint64_t)B.plcap << B.pbits) * 8, pg * 8)); B.o_tab = B.o_plog;
-        B.o_store = take(((uint64_t)B.capp << B.pbits) * 8); B.o_pcount = take(4ull << B.pbits); B.o_ptail = take(4ull << B.pbits);
+        B.o_store = take(std::max<uint64_t>(((uint64_t)(B.capp + B.plcap) << B.pbits) * 8, pg * 8)); B.o_tab = B.o_store; B.o_plog = 0;
+        B.o_pcount = take(4ull << B.pbits); B.o_ptail = take(4ull << B.pbits);
         B.o_log = take((uint64_t)B.logcap * 8); B.o_hot = take(8ull << B.hotbits_max);
     } else B.o_tab = take(cap * 8);
     B.o_ent = take(((uint64_t)nnz + 64) * 4); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);

@@ -558,6 +558,8 @@ __device__ __forceinline__ bool lt_put(uint64_t *ltab, uint64_t key, int32_t del
 }
 
 // The merge (all threads of the workgroup).  `mreg` = the Bloom filter followed by the scratch region (PLO_DMREG_WORDS words).
+// A partition is ONE array of records (key48 << 16 | insert flag | d15) of capacity rcap = capp + plcap: its live triples first
+// (flagged records carrying the frequency), the log records of the running merge behind them.
 // first = true: the store is the plan's image and hist[] its histogram, only the window is chosen.
 __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *hist, uint32_t *mreg, bool first)
 {
@@ -581,20 +583,24 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
         PLO_BIG_FENCE(); BSYNC();
         PLO_MSTAMP(0);
         // ---- A. partition pass: PLO_DCH records per round are ranked per partition (LDS counters), laid out by partition in the
-        // staging buffer and written behind the partitions' logs: neighbouring lanes store neighbouring words
+        // staging buffer and written behind the partitions' records: neighbouring lanes store neighbouring words.  The records of
+        // the next round are requested before the current round is worked on.
         {
             uint64_t *stage = (uint64_t *)mreg; uint32_t *cnt = mreg + 2u * PLO_DCH, *pos = cnt + PLO_DPMAX, *tail = pos + PLO_DPMAX;
             for (uint32_t q = tid; q < Pn; q += nth) tail[q] = pcount[q];
             const uint32_t nlog = sh.logn < P.logcap ? sh.logn : P.logcap;
             constexpr uint32_t U = PLO_DCH / PLO_BIG_THREADS;
             const uint32_t K = (Pn + nth - 1u) / nth;                       // partitions per thread in the prefix sum (<= 4)
+            uint64_t e[U], en[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) { const uint32_t idx = u * nth + tid; e[u] = idx < nlog ? dlog[idx] : 0ull; }
             for (uint32_t base = 0; base < nlog; base += PLO_DCH) {
                 const uint32_t n = nlog - base < PLO_DCH ? nlog - base : PLO_DCH;
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) { en[u] = 0ull; }
                 for (uint32_t q = tid; q < Pn; q += nth) cnt[q] = 0u;
                 BSYNC();
-                uint64_t e[U]; uint32_t pp[U], rk[U];
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) { const uint32_t idx = u * nth + tid; e[u] = idx < n ? dlog[base + idx] : 0ull; }
+                uint32_t pp[U], rk[U];
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) { const uint32_t idx = u * nth + tid; pp[u] = 0u; rk[u] = 0u; if (idx < n) { pp[u] = dpart(e[u] >> 16, pbits); rk[u] = wg_add(&cnt[pp[u]], 1u); } }
                 BSYNC();
@@ -614,7 +620,7 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
                 for (uint32_t q = tid; q < Pn; q += nth) {
                     const uint32_t c = cnt[q], t = tail[q];
                     if (t + c > rcap) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 101u); }
-                    tail[q] = t + c; cnt[q] = t - pos[q];                  // position in the partition's log = cnt[q] + position in the staging buffer
+                    tail[q] = t + c; cnt[q] = t - pos[q];                  // position among the partition's records = cnt[q] + position in the staging buffer
                 }
                 BSYNC();
                 for (uint32_t j = tid; j < n; j += nth) {
@@ -623,42 +629,58 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
                     if (o < rcap) store[(uint64_t)q * rcap + o] = ee;
                 }
                 BSYNC();
+#pragma unroll
+                for (uint32_t u = 0; u < U; ++u) { const uint32_t idx = base + PLO_DCH + u * nth + tid; e[u] = idx < nlog ? dlog[idx] : 0ull; }
             }
             for (uint32_t q = tid; q < Pn; q += nth) ptail[q] = tail[q] < rcap ? tail[q] : rcap;
         }
         PLO_BIG_FENCE(); BSYNC();
         PLO_MSTAMP(1);
         if (sh.errflag) return;
-        // ---- B. every group of partitions is summed in LDS; live triples go back to the store, the histogram is recounted
+        // ---- B. every group of partitions is summed in LDS; live triples go back to the store, the histogram is recounted.
+        // The records of the next group are requested (8 per thread) while the table of the current one is scanned and written back.
         {
             for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = 0u;
             uint64_t *ltab = (uint64_t *)mreg;
-            BSYNC();
-            uint32_t p = 0;
-            while (p < Pn) {
-                // the group [p, p + g): as many partitions as fit the table (every wave computes the same bounds)
-                const uint32_t q0 = p + lane;
-                const uint32_t cT = q0 < Pn ? ptail[q0] : 0u;               // records of the partition: live triples + log
-                const uint32_t inc = wave_incl_scan(cT);
+            uint32_t *goff = sh.cblk;                                        // 2 x 65 exclusive offsets of the partitions of a group (the block sums are rebuilt after the merge)
+            constexpr uint32_t NR = 12u;
+            // bounds of the group starting at partition q0 (every wave computes the same), offsets to goff[sel]
+            auto group_of = [&](uint32_t q0, uint32_t sel, uint32_t &g, uint32_t &tot) {
+                const uint32_t q = q0 + lane;
+                const uint32_t c = q < Pn ? ptail[q] : 0u;
+                const uint32_t inc = wave_incl_scan(c);
                 const unsigned long long okm = __builtin_amdgcn_ballot_w64(inc <= P.lgrp);
-                uint32_t g = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
+                g = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
                 if (g == 0u) g = 1u;
-                if (g > Pn - p) g = Pn - p;
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(g - 1u));
-                if (tot > (7u << (PLO_DLB - 3u))) { if (tid == 0) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 102u); } break; }       // more than 7/8 of the table
+                if (q0 < Pn && g > Pn - q0) g = Pn - q0;
+                tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(g - 1u));
+                if (wave == 0u) { goff[sel * 65u + lane] = inc - c; if (lane == 63u) goff[sel * 65u + 64u] = inc; }
+            };
+            auto fetch = [&](uint32_t q0, uint32_t sel, uint32_t g, uint32_t tot, uint32_t i) -> uint64_t {
+                if (i >= tot) return 0ull;                                   // (a flagged record of frequency 0 is skipped below; this one is not flagged: d = 0 adds nothing)
+                uint32_t j = 0;
+                if (g > 1u) { uint32_t lo = 0, hi = g; while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (goff[sel * 65u + mid] <= i) lo = mid; else hi = mid; } j = lo; }
+                return store[(uint64_t)(q0 + j) * rcap + (i - goff[sel * 65u + j])];
+            };
+            auto put = [&](uint64_t v, uint32_t lb) {
+                const int32_t d = (int32_t)(v & 0x7FFFull);
+                if (d != 0) if (!lt_put(ltab, v >> 16, (v & 0x8000ull) ? d : -d, pbits, lb)) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 103u); }
+            };
+            uint32_t p = 0, g = 0, tot = 0, sel = 0;
+            BSYNC();
+            group_of(0u, 0u, g, tot);
+            while (p < Pn) {
+                if (tot > NR * nth || tot > (7u << (PLO_DLB - 3u))) { if (tid == 0) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 102u); } break; }
                 uint32_t lb = 6u; while ((1u << lb) < 2u * tot + 64u && lb < PLO_DLB) ++lb;
                 for (uint32_t s = tid; s < (1u << lb); s += nth) ltab[s] = PLO_LEMPTY;
                 if (tid < 64u) sh.outcnt[tid] = 0u;
                 BSYNC();
-                for (uint32_t j = 0; j < g; ++j) {
-                    const uint32_t nT = (uint32_t)__builtin_amdgcn_readlane((int)cT, (int)j);
-                    const uint64_t *sp = store + (uint64_t)(p + j) * rcap;
-                    for (uint32_t e = tid; e < nT; e += 4u * nth) {               // four records of a thread in flight together
-                        const uint64_t v0 = sp[e], v1 = e + nth < nT ? sp[e + nth] : 0ull, v2 = e + 2u * nth < nT ? sp[e + 2u * nth] : 0ull, v3 = e + 3u * nth < nT ? sp[e + 3u * nth] : 0ull;
-#define PLO_PUT(v_) do { const int32_t d_ = (int32_t)((v_) & 0x7FFFull); if (d_) if (!lt_put(ltab, (v_) >> 16, ((v_) & 0x8000ull) ? d_ : -d_, pbits, lb)) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 103u); } } while (0)
-                        PLO_PUT(v0); PLO_PUT(v1); PLO_PUT(v2); PLO_PUT(v3);
-#undef PLO_PUT
-                    }
+                const uint32_t pn = p + g;
+                uint32_t gn = 0, totn = 0;
+                group_of(pn, sel ^ 1u, gn, totn);                           // (counts of the next group: their load overlaps the table work)
+                for (uint32_t i0 = tid; i0 < tot; i0 += 4u * nth) {          // four records of a thread in flight together
+                    const uint64_t v0 = fetch(p, sel, g, tot, i0), v1 = fetch(p, sel, g, tot, i0 + nth), v2 = fetch(p, sel, g, tot, i0 + 2u * nth), v3 = fetch(p, sel, g, tot, i0 + 3u * nth);
+                    put(v0, lb); put(v1, lb); put(v2, lb); put(v3, lb);
                 }
                 BSYNC();
                 for (uint32_t s = tid; s < (1u << lb); s += nth) {
@@ -671,11 +693,11 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
                     wg_add(&hist[c], 1u);
                     const uint32_t j = dpart(k, pbits) - p;
                     const uint32_t idx = j < 64u ? wg_add(&sh.outcnt[j], 1u) : capp;
-                    if (idx < capp) store[(uint64_t)(p + j) * rcap + idx] = (k << 16) | 0x8000ull | c; else { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 105u); }
+                    if (idx < capp) store[(uint64_t)(p + j) * rcap + idx] = (k << 16) | 0x8000ull | c; else { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 104u); }
                 }
                 BSYNC();
-                if (tid < g) { const uint32_t c_ = sh.outcnt[tid] < capp ? sh.outcnt[tid] : capp; pcount[p + tid] = c_; ptail[p + tid] = c_; }
-                p += g;
+                if (tid < g) { const uint32_t c = sh.outcnt[tid] < capp ? sh.outcnt[tid] : capp; pcount[p + tid] = c; ptail[p + tid] = c; }
+                p = pn; g = gn; tot = totn; sel ^= 1u;
             }
         }
         PLO_BIG_FENCE(); BSYNC();
@@ -711,7 +733,7 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
                         const uint32_t e = e0 + u * 64u + lane, c = (uint32_t)(v[u] & 0x7FFFull);
                         if (e < n && c >= th) {
                             const uint64_t k = v[u] >> 16;
-                            if (hot_addn(hot, k, c, hb, &sh.hotn) != 0u) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 106u); }
+                            if (hot_addn(hot, k, c, hb, &sh.hotn) != 0u) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 105u); }
                             dbloom_set(mreg, k);
                             const uint32_t idx = wg_add(&sh.hlcount, 1u);
                             if (idx < P.hlcap) HL[idx] = k; else wg_max(&sh.errflag, (uint32_t)BERR_HL);
@@ -778,7 +800,13 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
         uint64_t *store = (uint64_t *)(ws + P.o_store); const uint32_t rcap = P.capp + P.plcap;
         for (uint32_t q = wave; q < (1u << P.pbits); q += nwaves) {           // a wave copies whole partitions of the image (stride capp) to the store (stride capp + plcap)
             const uint32_t nq = P.pcount0[q]; const uint64_t *sp = P.st0 + (uint64_t)q * P.capp; uint64_t *dp = store + (uint64_t)q * rcap;
-            for (uint32_t e = lane; e < nq; e += 128u) { const uint64_t x0 = sp[e], x1 = e + 64u < nq ? sp[e + 64u] : 0ull; dp[e] = x0; if (e + 64u < nq) dp[e + 64u] = x1; }
+            for (uint32_t e0 = 0; e0 < nq; e0 += 512u) {
+                uint64_t v[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; ++u) { const uint32_t e = e0 + u * 64u + lane; v[u] = e < nq ? sp[e] : 0ull; }
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; ++u) { const uint32_t e = e0 + u * 64u + lane; if (e < nq) dp[e] = v[u]; }
+            }
         }
     }
     for (uint32_t i = tid; i < m; i += nth) len[i] = P.rs[i + 1] - P.rs[i];
