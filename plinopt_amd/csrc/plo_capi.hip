@@ -333,7 +333,7 @@ int build_big_plan(plo_plan *pl)
                 B.hotbits_min = std::min(16u, std::max(10u, ceil_log2((uint32_t)(4u * std::min<uint64_t>(pairs0, 16384u)))));
                 B.hotbits_max = std::max(B.hotbits_min, std::min(19u, ceil_log2((uint32_t)(4u * hotmax + 1024u))));
                 if (const char *e = getenv("PLO_BIG_HOTBITS")) B.hotbits_min = (uint32_t)std::min<long>(B.hotbits_max, std::max<long>(6, strtol(e, nullptr, 10)));   // test knob: a full hot table is reported and the launch repeated with a larger one
-                B.lgrp = 3000u;
+                B.lgrp = 3000u; if (const char *e = getenv("PLO_BIG_LGRP")) B.lgrp = (uint32_t)std::min<long>(7000, std::max<long>(64, strtol(e, nullptr, 10)));   // experiment knob: records per group of partitions summed together
                 st0.assign((size_t)capp * Pn, 0ull);
                 std::vector<uint32_t> fill(Pn, 0u);
                 for (size_t k = 0; k < keys.size(); ++k) { const uint32_t q = part(keys[k]); st0[(size_t)q * capp + fill[q]++] = (keys[k] << PLO_GVB) | 0x8000ull | cnts[k]; }   // a record: key | insert flag | frequency
@@ -470,6 +470,7 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
         if (hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess) {
             if (pl->B.defer && hs[38]) fprintf(stderr, "# big kernel, deferred updates: per candidate %.1f merges (%.2f forced by log/hot pressure), %.0f log records, %.0f hot-table updates; last candidate, merge us: hot->log %u, partition pass %u, sum + write back %u, window %u\n",
                     (double)hs[33] / hs[38], (double)hs[39] / hs[38], ((double)hs[42] * 4294967296.0 + hs[41]) / hs[38], (double)hs[40] / hs[38], hs[44], hs[45], hs[46], hs[47]);
+            if (pl->B.defer && hs[52]) fprintf(stderr, "#   merge, sum + write back of the last candidate: %u groups; us: sum (loads + table) %u, scan + write back %u, clear + bounds %u\n", hs[52], hs[48], hs[49], hs[51]);
             fprintf(stderr, "# big kernel (last candidate): steps %u, full scans %u, level rebuilds %u; phase us: level %u select %u rows %u sweep1 %u flush1 %u sweep2 %u flush2 %u tail %u\n",
                     hs[0], hs[1], hs[2], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11]);
 #ifdef PLO_BIG_PROFILE

@@ -425,7 +425,7 @@ struct BigShared {
     uint32_t sb, sl0;              // the step's second column and the column whose entry the new column takes (for the out-of-line paths)
     uint32_t nbisect, spilltot, listover;   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
     uint32_t logn, hotn, hotbits, nforced, hotops, logtot_lo, logtot_hi;   // DEFER: log fill, claimed hot slots, hot table size; diagnostics: merges forced by log/hot pressure, updates served by the hot table, log entries written
-    uint32_t derr; unsigned long long tmg[4]; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
+    uint32_t derr; unsigned long long tmg[4], tmb[4]; uint32_t ngrp; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
     uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
     unsigned long long tph[8];     // phase clocks (100 MHz ticks): level, select, rows, sweep1, flush1, sweep2, flush2, tail
 #ifdef PLO_BIG_PROFILE
@@ -559,7 +559,7 @@ __device__ __forceinline__ bool lt_put(uint64_t *ltab, uint64_t key, int32_t del
 
 // The merge (all threads of the workgroup).  `mreg` = the Bloom filter followed by the scratch region (PLO_DMREG_WORDS words).
 // first = true: the store is the plan's image and hist[] its histogram, only the window is chosen.
-__device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *hist, uint32_t *mreg, bool first)
+__device__ __forceinline__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *hist, uint32_t *mreg, bool first)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
     uint64_t *store = (uint64_t *)(ws + P.o_store), *dlog = (uint64_t *)(ws + P.o_log), *hot = (uint64_t *)(ws + P.o_hot), *HL = (uint64_t *)(ws + P.o_hl);
@@ -634,33 +634,58 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
             for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = 0u;
             uint64_t *ltab = (uint64_t *)mreg;
             BSYNC();
-            uint32_t p = 0;
-            while (p < Pn) {
-                // the group [p, p + g): as many partitions as fit the table (every wave computes the same bounds)
-                const uint32_t q0 = p + lane;
-                const uint32_t cT = q0 < Pn ? ptail[q0] : 0u;               // records of the partition: live triples + log
+            // Counts of 128 partitions ahead live in two registers (lane i: partition W + i, W + 64 + i); the bounds of a group come from
+            // them without a memory round trip.  The first four records of a thread for the NEXT group are requested while the table of
+            // the current group is scanned and written back.
+            uint32_t W = 0, cW = lane < Pn ? ptail[lane] : 0u, cW2 = 64u + lane < Pn ? ptail[64u + lane] : 0u;
+            auto bounds = [&](uint32_t p_, uint32_t &cT, uint32_t &g, uint32_t &tot) {
+                const uint32_t o = p_ - W + lane;                                  // 0 .. 127
+                const uint32_t x0 = (uint32_t)__shfl((int)cW, (int)(o & 63u)), x1 = (uint32_t)__shfl((int)cW2, (int)(o & 63u));
+                cT = o < 64u ? x0 : x1;
                 const uint32_t inc = wave_incl_scan(cT);
                 const unsigned long long okm = __builtin_amdgcn_ballot_w64(inc <= P.lgrp);
-                uint32_t g = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
+                g = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
                 if (g == 0u) g = 1u;
-                if (g > Pn - p) g = Pn - p;
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(g - 1u));
+                if (g > Pn - p_) g = Pn - p_;
+                tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(g - 1u));
+            };
+            uint32_t p = 0, cT = 0, g = 0, tot = 0;
+            bounds(0u, cT, g, tot);
+            // records tid, tid + nth, tid + 2 nth, tid + 3 nth of the group's FIRST partition (the others, and anything beyond, are loaded in the loop)
+            uint64_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+            auto first4 = [&](uint32_t p_, uint32_t n0) {
+                const uint64_t *sp = store + (uint64_t)p_ * rcap;
+                f0 = tid < n0 ? sp[tid] : 0ull; f1 = tid + nth < n0 ? sp[tid + nth] : 0ull; f2 = tid + 2u * nth < n0 ? sp[tid + 2u * nth] : 0ull; f3 = tid + 3u * nth < n0 ? sp[tid + 3u * nth] : 0ull;
+            };
+            first4(0u, (uint32_t)__builtin_amdgcn_readlane((int)cT, 0));
+#define PLO_PUT(v_) do { const int32_t d_ = (int32_t)((v_) & 0x7FFFull); if (d_) if (!lt_put(ltab, (v_) >> 16, ((v_) & 0x8000ull) ? d_ : -d_, pbits, lb)) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 103u); } } while (0)
+            unsigned long long tbl = wall_clock64();
+            while (p < Pn) {
                 if (tot > (7u << (PLO_DLB - 3u))) { if (tid == 0) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 102u); } break; }       // more than 7/8 of the table
                 uint32_t lb = 6u; while ((1u << lb) < 2u * tot + 64u && lb < PLO_DLB) ++lb;
                 for (uint32_t s = tid; s < (1u << lb); s += nth) ltab[s] = PLO_LEMPTY;
                 if (tid < 64u) sh.outcnt[tid] = 0u;
                 BSYNC();
+                unsigned long long tb0 = wall_clock64();
+#define PLO_BSTAMP(q_) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); sh.tmb[q_] += t_ - tb0; tb0 = t_; } } while (0)
+                if (tid == 0) { sh.tmb[3] += tb0 - tbl; ++sh.ngrp; }
+                PLO_PUT(f0); PLO_PUT(f1); PLO_PUT(f2); PLO_PUT(f3);
                 for (uint32_t j = 0; j < g; ++j) {
                     const uint32_t nT = (uint32_t)__builtin_amdgcn_readlane((int)cT, (int)j);
                     const uint64_t *sp = store + (uint64_t)(p + j) * rcap;
-                    for (uint32_t e = tid; e < nT; e += 4u * nth) {               // four records of a thread in flight together
+                    for (uint32_t e = tid + (j == 0u ? 4u * nth : 0u); e < nT; e += 4u * nth) {
                         const uint64_t v0 = sp[e], v1 = e + nth < nT ? sp[e + nth] : 0ull, v2 = e + 2u * nth < nT ? sp[e + 2u * nth] : 0ull, v3 = e + 3u * nth < nT ? sp[e + 3u * nth] : 0ull;
-#define PLO_PUT(v_) do { const int32_t d_ = (int32_t)((v_) & 0x7FFFull); if (d_) if (!lt_put(ltab, (v_) >> 16, ((v_) & 0x8000ull) ? d_ : -d_, pbits, lb)) { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 103u); } } while (0)
                         PLO_PUT(v0); PLO_PUT(v1); PLO_PUT(v2); PLO_PUT(v3);
-#undef PLO_PUT
                     }
                 }
+                // the next group: slide the window of counts, bounds, first records
+                const uint32_t pn = p + g;
+                if (pn >= W + 64u) { W += 64u; cW = cW2; const uint32_t q = W + 64u + lane; cW2 = q < Pn ? ptail[q] : 0u; }
+                uint32_t cTn = 0, gn = 1, totn = 0;
+                if (pn < Pn) bounds(pn, cTn, gn, totn);
                 BSYNC();
+                PLO_BSTAMP(0);
+                if (pn < Pn) first4(pn, (uint32_t)__builtin_amdgcn_readlane((int)cTn, 0)); else { f0 = f1 = f2 = f3 = 0ull; }
                 for (uint32_t s = tid; s < (1u << lb); s += nth) {
                     const uint64_t v = ltab[s];
                     if (v == PLO_LEMPTY) continue;
@@ -671,12 +696,15 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
                     wg_add(&hist[c], 1u);
                     const uint32_t j = dpart(k, pbits) - p;
                     const uint32_t idx = j < 64u ? wg_add(&sh.outcnt[j], 1u) : capp;
-                    if (idx < capp) store[(uint64_t)(p + j) * rcap + idx] = (k << 16) | 0x8000ull | c; else { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 105u); }
+                    if (idx < capp) store[(uint64_t)(p + j) * rcap + idx] = (k << 16) | 0x8000ull | c; else { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 104u); }
                 }
                 BSYNC();
+                PLO_BSTAMP(1);
                 if (tid < g) { const uint32_t c_ = sh.outcnt[tid] < capp ? sh.outcnt[tid] : capp; pcount[p + tid] = c_; ptail[p + tid] = c_; }
-                p += g;
+                tbl = wall_clock64();
+                p = pn; cT = cTn; g = gn; tot = totn;
             }
+#undef PLO_PUT
         }
         PLO_BIG_FENCE(); BSYNC();
         PLO_MSTAMP(2);
@@ -730,7 +758,7 @@ __device__ void defer_merge(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32
 // ---------------------------------------------------------------------------
 // One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
 // ---------------------------------------------------------------------------
-template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const BigTabs &TB, uint32_t *errw)
+template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const BigTabs &TB, uint32_t *errw)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
     uint64_t *tab   = (uint64_t *)(ws + (DEFER ? P.o_hot : P.o_tab));      // the table the level code and the tie pick look triples up in (DEFER: the hot table)
@@ -797,7 +825,7 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
         for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0; for (int q = 0; q < 16; ++q) sh.pw[q] = 0; for (int c_ = 0; c_ < 4; ++c_) for (int q = 0; q < 8; ++q) sh.tpc[c_][q] = 0;
 #endif
         sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0; sh.nbisect = 0; sh.spilltot = 0; sh.listover = 0;
-        sh.logn = 0; sh.hotn = 0; sh.hotbits = P.hotbits_min; sh.derr = 0; for (int q = 0; q < 4; ++q) sh.tmg[q] = 0; sh.nforced = 0; sh.hotops = 0; sh.logtot_lo = 0; sh.logtot_hi = 0;
+        sh.logn = 0; sh.hotn = 0; sh.hotbits = P.hotbits_min; sh.derr = 0; for (int q = 0; q < 4; ++q) { sh.tmg[q] = 0; sh.tmb[q] = 0; } sh.ngrp = 0; sh.nforced = 0; sh.hotops = 0; sh.logtot_lo = 0; sh.logtot_hi = 0;
     }
     PLO_BIG_FENCE(); BSYNC();
     bool dfirst = true;                                                       // DEFER: the first merge only chooses the window
@@ -1509,7 +1537,7 @@ template <int MODE, bool DEFER> __device__ uint64_t big_candidate(const BigPlan 
 // count; the Triangle pass walks, with one wave, only the columns that still hold
 // two or more non +-1 entries (after FactorOutColumns those have pairwise distinct
 // |values|, so they are few and short).
-__device__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *scratch, uint32_t *errw)
+__device__ __forceinline__ uint64_t big_program_gen(const BigPlan &P, uint8_t *ws, BigShared &sh, uint32_t *scratch, uint32_t *errw)
 {
     // (the {value, inverse} table is read from global memory here: `scratch` may overlap its LDS copy)
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
@@ -1792,7 +1820,7 @@ template <int MODE, bool DEFER> __global__ __launch_bounds__(PLO_BIG_THREADS, 4)
             const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
-            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u); atomicAdd(&J.stats[39], sh.nforced); atomicMax(&J.stats[43], sh.derr); for (int q = 0; q < 4; ++q) J.stats[44 + q] = (uint32_t)(sh.tmg[q] / 100ull); atomicAdd(&J.stats[40], sh.hotops); { const uint32_t lo_ = atomicAdd(&J.stats[41], sh.logtot_lo); if (lo_ + sh.logtot_lo < lo_) atomicAdd(&J.stats[42], 1u); atomicAdd(&J.stats[42], sh.logtot_hi); }
+            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u); atomicAdd(&J.stats[39], sh.nforced); atomicMax(&J.stats[43], sh.derr); for (int q = 0; q < 4; ++q) { J.stats[44 + q] = (uint32_t)(sh.tmg[q] / 100ull); J.stats[48 + q] = (uint32_t)(sh.tmb[q] / 100ull); } J.stats[52] = sh.ngrp; atomicAdd(&J.stats[40], sh.hotops); { const uint32_t lo_ = atomicAdd(&J.stats[41], sh.logtot_lo); if (lo_ + sh.logtot_lo < lo_) atomicAdd(&J.stats[42], 1u); atomicAdd(&J.stats[42], sh.logtot_hi); }
                 J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull);
 #ifdef PLO_BIG_PROFILE
                 for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }
