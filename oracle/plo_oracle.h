@@ -158,6 +158,15 @@ int plo_oracle_kernel_order(uint32_t m, uint32_t n, const uint32_t *rowptr, cons
 void plo_oracle_free(void *ptr);
 int plo_oracle_max_threads(void);
 
+/* ---- bin/sparsifier as a whole (plo_sparsify_oracle.c; reference include/plinopt_sparsify.inl) */
+/* the coefficient set of localSparsifier (:256-268, augment :21-35) for the n x m matrix TM (dense, row major) */
+int plo_oracle_sp_coeffs(uint32_t n, uint32_t m, const uint32_t *TM, uint32_t p, uint32_t maxnumcoeff, uint32_t *out, uint32_t *ncoeffs);
+/* one localSparsifier call (:206-347: nullspace seed, enumeration through testLinComb, canonical fallback): TM (n x m) and TCoB (n x n) are updated */
+int plo_oracle_sp_local(uint32_t n, uint32_t m, uint32_t *TM, uint32_t *TCoB, uint32_t p, uint32_t maxnumcoeff);
+/* blockSparsifier (:667-748) with sparseAlternate / SparseFactor / FactorDiagonals / sparseLU: M (m x n) -> CoB (n x n), Res (m x n), M == Res . CoB */
+int plo_oracle_sparsify(uint32_t m, uint32_t n, const uint32_t *M, uint32_t p, uint32_t blocksize, uint32_t maxnumcoeff, int initial_elimination,
+                        uint32_t *CoB, uint32_t *Res, uint64_t *candidates);
+
 #ifdef __cplusplus
 }
 #endif

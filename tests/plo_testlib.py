@@ -281,6 +281,9 @@ def oracle():
                                                 u32p, u32p, u64p, ctypes.POINTER(ctypes.c_void_p)]
         L.plo_oracle_enum_cost_many.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, u32p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
                                                 u32p, u32p, u64p, ctypes.c_int]
+        L.plo_oracle_sp_coeffs.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p]
+        L.plo_oracle_sp_local.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32]
+        L.plo_oracle_sparsify.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, u32p, u32p, u64p]
         L.plo_oracle_naive_ops.argtypes = [ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p, u32p]
         L.plo_oracle_naive_ops.restype = None
         L.plo_oracle_free.argtypes = [ctypes.c_void_p]
@@ -472,6 +475,50 @@ def oracle_cob_search(n, m, TM, Cand, row, off, coeffs, p, w0=-1, w1=-1):
                                         ctypes.byref(zv), ctypes.byref(zw), ctypes.byref(idx), ctypes.byref(fnd))
     assert rc == 0
     return zv.value, zw.value, idx.value, fnd.value
+
+
+def oracle_sp_coeffs(TM, p, maxnumcoeff):
+    """Coefficient set of localSparsifier (plinopt_sparsify.inl:256-268) for the dense matrix TM (list of rows)."""
+    n, m = len(TM), len(TM[0])
+    out = (ctypes.c_uint32 * (maxnumcoeff + 8))()
+    cnt = ctypes.c_uint32()
+    assert oracle().plo_oracle_sp_coeffs(n, m, _arr([x for r in TM for x in r]), p, maxnumcoeff, out, ctypes.byref(cnt)) == 0
+    return list(out[:cnt.value])
+
+
+def oracle_sparsify(M, p, blocksize=4, maxnumcoeff=11, initial_elimination=True):
+    """blockSparsifier (plinopt_sparsify.inl:667-748) of the dense m x n matrix M (list of rows) over Z_p: (CoB, Res, candidates)."""
+    m, n = len(M), len(M[0])
+    cob = (ctypes.c_uint32 * (n * n))()
+    res = (ctypes.c_uint32 * (m * n))()
+    cand = ctypes.c_uint64()
+    rc = oracle().plo_oracle_sparsify(m, n, _arr([x for r in M for x in r]), p, blocksize, maxnumcoeff, 1 if initial_elimination else 0, cob, res, ctypes.byref(cand))
+    assert rc == 0
+    return [list(cob[i * n:(i + 1) * n]) for i in range(n)], [list(res[i * n:(i + 1) * n]) for i in range(m)], cand.value
+
+
+def dense_mod(path, p):
+    """dense image mod p of an SMS file (list of rows)"""
+    m, n, ent = read_sms(path)
+    rp, c, v = to_csr_mod(m, n, ent, p)
+    D = [[0] * n for _ in range(m)]
+    for i in range(m):
+        for k in range(rp[i], rp[i + 1]):
+            D[i][c[k]] = v[k]
+    return D
+
+
+def parse_sms_text(text, p=None):
+    """dense matrix (list of rows) of an SMS text as the tools print it"""
+    lines = [ln for ln in text.splitlines() if ln.strip() and not ln.lstrip().startswith("#")]
+    m, n = int(lines[0].split()[0]), int(lines[0].split()[1])
+    D = [[0] * n for _ in range(m)]
+    for ln in lines[1:]:
+        t = ln.split()
+        if len(t) < 3 or (t[0] == "0" and t[1] == "0"):
+            break
+        D[int(t[0]) - 1][int(t[1]) - 1] = int(t[2]) if p is None else int(t[2]) % p
+    return D
 
 
 # ----------------------------------------------------------------------------- trilplacer

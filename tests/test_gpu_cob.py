@@ -89,6 +89,24 @@ def test_sparsifier_cli_gpu_equals_host(hip, name):
     assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)
 
 
+@pytest.mark.parametrize("name,b,c", [("4x4x4_49_156_L.sms", 4, 4), ("2x2x2_7_Winograd_L.sms", 4, 6), ("2x2x2_7_DPS-accurate_L.sms", 4, 7), ("3x3x3_23_58_P.sms", 4, 6),
+                                      ("4x4x4_48_rational_L.sms", 4, 5), ("3x3x6_40_R.sms", 3, 5)])
+def test_sparsifier_cli_on_gpu_prints_the_oracles_basis(hip, name, b, c):
+    """bin/sparsifier -q p on the GPU against the ORACLE's restatement of the whole tool (oracle/plo_sparsify_oracle.c: coefficient
+    set, seed vector, enumeration through a literal testLinComb, fallback, FactorDiagonals, SparseFactor, sparseLU, blocks): the
+    printed change of basis, the residue and the number of candidate rows are the oracle's."""
+    from plo_testlib import dense_mod, oracle_sparsify, parse_sms_text
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+    path = os.path.join(DATA, name)
+    CoB, Res, cand = oracle_sparsify(dense_mod(path, P), P, b, c, True)
+    g = subprocess.run([SPS, "-q", str(P), "-b", str(b), "-c", str(c), "-S", path], capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0 and "SUCCESS: consistent factorization" in g.stderr and "# GPU: enumeration kernels" in g.stderr, g.stderr
+    assert parse_sms_text(g.stdout) == CoB
+    tail = g.stderr.split("residuum profile:")[1]
+    assert parse_sms_text(tail[tail.index("\n") + 1:]) == Res
+    assert ("# CoB enumeration: %d candidate rows" % cand) in g.stderr
+
+
 @pytest.mark.parametrize("name,c", [("4x4x4_49_156_L.sms", "4"), ("2x2x2_7_Winograd_L.sms", "6"), ("2x2x2_7_DPS-accurate_L.sms", "6"), ("4x4x4_48_rational_L.sms", "5"),
                                     ("3x3x3_23_58_P.sms", "6")])
 def test_sparsifier_over_the_rationals_on_gpu_equals_host(hip, name, c):
