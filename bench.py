@@ -436,17 +436,24 @@ def main():
     launches = 0
     best_word = None
     stats = None
+    search_s = 0.0                                 # wall time of this rank's searches (library call) and of the all-reduces, timed steps only
+    reduce_s = 0.0
 
     def step(k, timed):
-        nonlocal kernel_ms, launches, best_word, stats
+        nonlocal kernel_ms, launches, best_word, stats, search_s, reduce_s
         s0 = seed_base + k * global_batch          # this step's global seed range
         my0 = s0 + rank * batch                    # this rank's shard (independent candidates, no exchange)
+        t_a = time.perf_counter()
         local = plan.search(my0, batch, capi.COST_SUM_THEN_ADD)
+        t_b = time.perf_counter()
         stats = plan.last_stats
         if timed:
             kernel_ms += stats["kernel_ms"]
             launches += stats["launches"]
-        seed, word = allreduce_best(local, s0, capi.COST_SUM_THEN_ADD, device=dev)   # one 8-byte MIN all-reduce
+        seed, word = allreduce_best(local, s0, capi.COST_SUM_THEN_ADD, device=dev)   # one MIN all-reduce of 16 bytes (cost word + "fits one word" flag)
+        if timed:
+            search_s += t_b - t_a
+            reduce_s += time.perf_counter() - t_b
         if best_word is None or (word >> 32, seed) < (best_word[0] >> 32, best_word[1]):
             best_word = (word, seed)
         return seed
@@ -466,6 +473,14 @@ def main():
 
     total = float(global_batch) * args.steps
     value = total / dt
+    # where a loss of scaling would come from: every rank's kernel time, search wall time and time inside the all-reduce
+    per_rank = torch.tensor([kernel_ms, search_s * 1e3, reduce_s * 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)
+    else:
+        gathered = [per_rank]
+    per_rank_ms = [[round(float(x), 3) for x in g.tolist()] for g in gathered]
     if rank == 0:
         # dominant kernel: cse_wave_kernel; algorithmic bytes per candidate B_cand
         per_launch_ms = kernel_ms / max(launches, 1)
@@ -482,6 +497,8 @@ def main():
                        "global_batch": global_batch, "parallelism": "seed-shard x%d + 1 MIN all-reduce/step" % world,
                        "nnz": len(c), "rows": m, "cols": n},
             "best": {"packed": best_word[0], "seed": best_word[1]},
+            "per_rank_ms": {"columns": ["kernel (HIP events)", "search wall (library call)", "all-reduce wall (includes waiting for the slowest rank)"],
+                            "rows": per_rank_ms, "steps": args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "plo::cse_wave_kernel", "kernel_ms_per_launch": search_ms,
@@ -491,7 +508,8 @@ def main():
             "kernel": {"lds_bytes": stats["lds_bytes"], "waves_per_wg": stats["waves_per_wg"], "grid": stats["grid"]},
         }
         try:    # measured HBM bytes (PMC) from the committed profile of this workload, scaled to one launch
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(args.workload)
+            tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
+            tr = json.load(open(tj if os.path.exists(tj) else os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(args.workload)
             if tr:
                 out["roofline"]["traffic"] = (tr["fetch_bytes_per_candidate"] + tr["write_bytes_per_candidate"]) * batch
                 out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " + tr["source"]
@@ -504,11 +522,12 @@ def main():
         except Exception:
             pass
         if plan.is_hbm:
-            out["roofline"]["note"] = ("candidate state (64 MB pair table + 5 MB packed rows + lists, 140 MB workspace) is HBM-resident; measured HBM traffic "
-                                       "is 3.1 GB per candidate = 51x the algorithmic bytes (round 1: 91x), 1.9-2.0 TB/s (rocprofv3 PMC, profiles/r02j_*). The traffic "
-                                       "is random 8-byte accesses to the table and the rows: tests/micro/random_access.hip measures 49 G such loads/s chip-wide "
-                                       "(3.1 TB/s of 64-byte lines) whatever the number in flight, and this kernel issues about 45 G L2 requests/s -- it runs at "
-                                       "the memory system's random-access rate, not at the streaming peak this `frac` is priced against (DESIGN.md 2.3, 6)")
+            out["roofline"]["note"] = ("candidate state (5 MB packed rows, 27 MB partitioned triple store + update log, lists) is HBM-resident. Round 3: updates of triples "
+                                       "below the window of top frequency levels are deferred (8-byte log records, merged per partition in LDS) instead of random "
+                                       "read-modify-writes of a 64 MB table: measured HBM traffic 1.88 GB per candidate = 31x the algorithmic bytes (round 2: 51x), "
+                                       "4.7e7 L2 requests per candidate (round 2: 6.9e7) (rocprofv3 PMC, profiles/r03a_*). A candidate ALONE on the chip needs 0.48 s, "
+                                       "512 together 0.68 s each: the kernel is bound by the dependent chain of one workgroup per candidate (8 waves; the sweep's "
+                                       "LDS aggregation is VALU-issue bound at 16 waves per CU), not by this streaming `frac` (DESIGN.md 2.3, 6)")
             out["kernel"]["family"] = "plo::cse_big_kernel (one workgroup per candidate)"
             out["roofline"]["kernel"] = "plo::cse_big_kernel"
         if not plan.is_hbm:

@@ -101,6 +101,15 @@ int plo_cse_search_plan(plo_plan_t *plan, uint64_t seed0, uint64_t nseeds,
                         int cost_mode, plo_best_t *out, plo_stats_t *stats);
 int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds,
                    int cost_mode, plo_best_t *out, plo_stats_t *stats);
+/* The same search over `ndev` devices of one node from ONE process: the restart range in ndev contiguous shards (the blocks
+ * bin/optimizer --gpu N uses), one host thread and one device per shard (devices[k], or 0..ndev-1 when devices is NULL;
+ * the same ordinal may be listed twice), each thread with its own stream and plan; the result is the minimum under the
+ * total order (cmpOpCount key of include/plinopt_optimize.h:53-64, seed) -- what the `#pragma omp critical` of
+ * include/plinopt_optimize.inl:1214-1237 keeps.  stats->kernel_ms is the slowest shard's kernel time.  The exchange is ndev
+ * 16-byte results on the host (inside one process there is nothing for RCCL to move; across processes bench.py and
+ * plinopt_amd/dist.py reduce the same word with one RCCL MIN all-reduce). */
+int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode,
+                         int ndev, const int *devices, plo_best_t *out, plo_stats_t *stats);
 
 /* Same candidates, every (adds, muls) written back: the parity-test entry.
  * seeds == NULL means seed0, seed0+1, ... */

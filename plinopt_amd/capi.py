@@ -18,7 +18,7 @@ PLAN_HBM = 1
 EXPORTS = [
     "plo_init", "plo_shutdown", "plo_last_error", "plo_device_count",
     "plo_cse_plan_create", "plo_cse_plan_create_ex", "plo_cse_plan_is_hbm", "plo_cse_plan_hbm_counters", "plo_cse_plan_destroy",
-    "plo_cse_search_plan", "plo_cse_search",
+    "plo_cse_search_plan", "plo_cse_search", "plo_cse_search_multi",
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch", "plo_kernel_search",
     "plo_cse_enum_cost_many_plan", "plo_cse_enum_search_plan",
@@ -97,6 +97,8 @@ def lib():
                                           ctypes.POINTER(Best), ctypes.POINTER(Stats)]
         L.plo_cse_search.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
                                      ctypes.c_int, ctypes.POINTER(Best), ctypes.POINTER(Stats)]
+        L.plo_cse_search_multi.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                                           ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(Best), ctypes.POINTER(Stats)]
         L.plo_cse_cost_many_plan.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p,
                                              ctypes.POINTER(Stats)]
         L.plo_cse_cost_many.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, u64p, ctypes.c_uint64,

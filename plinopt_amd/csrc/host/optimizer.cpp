@@ -36,6 +36,7 @@ struct HipLib {
     decltype(&plo_init) init = nullptr;
     decltype(&plo_last_error) last_error = nullptr;
     decltype(&plo_cse_search) cse_search = nullptr;
+    decltype(&plo_cse_search_multi) cse_search_multi = nullptr;
     decltype(&plo_cse_chain_create) chain_create = nullptr;
     decltype(&plo_cse_chain_search) chain_search = nullptr;
     decltype(&plo_cse_chain_destroy) chain_destroy = nullptr;
@@ -55,7 +56,7 @@ struct HipLib {
         (void)argv0;
         if (!h) { ++g_failures, std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
         init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
-        cse_search = (decltype(cse_search))dlsym(h, "plo_cse_search"); shutdown = (decltype(shutdown))dlsym(h, "plo_shutdown");
+        cse_search = (decltype(cse_search))dlsym(h, "plo_cse_search"); cse_search_multi = (decltype(cse_search_multi))dlsym(h, "plo_cse_search_multi"); shutdown = (decltype(shutdown))dlsym(h, "plo_shutdown");
         chain_create = (decltype(chain_create))dlsym(h, "plo_cse_chain_create"); chain_search = (decltype(chain_search))dlsym(h, "plo_cse_chain_search");
         chain_destroy = (decltype(chain_destroy))dlsym(h, "plo_cse_chain_destroy");
         plan_create = (decltype(plan_create))dlsym(h, "plo_cse_plan_create"); plan_destroy = (decltype(plan_destroy))dlsym(h, "plo_cse_plan_destroy");
@@ -66,6 +67,7 @@ struct HipLib {
     }
 };
 
+bool g_fork_shards = false;   // --fork-shards: --gpu N with one forked child per device instead of one thread per device
 int g_engine = 0;   // 0 auto (scalable engine over Z_p), 1 literal std::map replay, 2 scalable engine
 
 template <class F> std::string replay_text(const F &f, const SparseMat<typename F::Elt> &lM, uint64_t seed, Ops &ops) {
@@ -541,7 +543,23 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
     // --gpu N, N >= 2: the direct method's seed range in N contiguous shards, one forked child and one device per shard,
     // minimum under (cmpOpCount, seed) in the parent -- before anything in this process touches the HIP runtime.
     struct { bool done = false; Ops ops; uint64_t seed = 0; } sharded;
-    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0) {
+    // Default since round 3: ONE process, one host thread and one device per shard inside the library (plo_cse_search_multi) -- the
+    // seed space sharded over the GPUs of the node as north_star names it; --fork-shards keeps the forked children (one process per
+    // device), which is also what the host-engine test knob uses.
+    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0 && !g_fork_shards && !(getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host")) {
+        HipLib L;
+        if (!L.load(argv0) || !L.cse_search_multi) { ++g_failures; std::cerr << "# \033[1;31mERROR: shard failed: libplinopt_hip.so " << (L.cse_search ? "lacks plo_cse_search_multi" : "cannot be loaded") << "\033[0m" << std::endl; return 2; }
+        std::vector<uint32_t> rp(1, 0), cc, vv;
+        for (auto &r : lM.rows) { for (auto &e : r) { cc.push_back((uint32_t)e.first); vv.push_back((uint32_t)e.second); } rp.push_back((uint32_t)cc.size()); }
+        std::vector<int> devs((size_t)gpu); for (int r = 0; r < gpu; ++r) devs[(size_t)r] = shard_device(r);
+        plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
+        plo_best_t b{}; plo_stats_t st{};
+        const int rc = L.cse_search_multi(&A, q, seed0, loops, PLO_COST_SUM_THEN_ADD, gpu, devs.data(), &b, &st);
+        if (rc != PLO_OK) { ++g_failures; std::cerr << "# \033[1;31mERROR: shard failed: " << L.last_error() << "\033[0m" << std::endl; return 2; }
+        sharded.ops = {b.adds, b.muls}; sharded.seed = b.seed; sharded.done = b.seed != ~0ull;
+        if (verbose > 0) std::clog << "# " << gpu << " shards (one GPU and one host thread each, one process): " << st.candidates << " candidates, slowest kernel " << st.kernel_ms << " ms" << std::endl;
+    }
+    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0 && !sharded.done) {
         const bool host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob: every shard on the host engine
         std::vector<uint32_t> rp(1, 0), cc, vv;
         for (auto &r : lM.rows) { for (auto &e : r) { cc.push_back((uint32_t)e.first); vv.push_back((uint32_t)e.second); } rp.push_back((uint32_t)cc.size()); }
@@ -776,6 +794,7 @@ int main(int argc, char **argv)
         else if (a == "--engine" && i + 1 < argc) { std::string e(argv[++i]); g_engine = e == "literal" ? 1 : e == "fast" ? 2 : 0; }
         else if (a == "--replay") replay_only = true;    // print the program of candidate --seed, no search
         else if (a == "--host-decomp") g_host_decomp = true;
+        else if (a == "--fork-shards") g_fork_shards = true;
         else if (a == "--kernel-block" && i + 1 < argc) g_kernel_block = std::max<uint64_t>(1, strtoull(argv[++i], nullptr, 10));
         else if (a == "--recsub") g_recsub_order = true;
         else if (a == "--only" && i + 1 < argc) { only = argv[++i]; }   // run exactly one method (D, G or A): for tests and timing

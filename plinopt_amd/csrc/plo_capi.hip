@@ -28,10 +28,16 @@
 namespace {
 
 thread_local std::string g_err;
-int g_device = -1;
-hipStream_t g_stream = nullptr;
-int g_cus = 0;
-size_t g_lds_max = 0;
+// The device context of the calling thread: the process-wide one set by plo_init (one process per GPU is the model of the
+// tools and of bench.py), or a thread's own inside plo_cse_search_multi (one host thread per device).
+struct DevCtx { int device = -1; hipStream_t stream = nullptr; int cus = 0; size_t lds_max = 0; };
+DevCtx g_ctx0;
+thread_local DevCtx *t_ctx = nullptr;
+inline DevCtx &cur_ctx() { return t_ctx ? *t_ctx : g_ctx0; }
+#define g_device (cur_ctx().device)
+#define g_stream (cur_ctx().stream)
+#define g_cus (cur_ctx().cus)
+#define g_lds_max (cur_ctx().lds_max)
 
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(PLO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -897,6 +903,48 @@ int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nsee
     rc = plo_cse_search_plan(pl, seed0, nseeds, cost_mode, out, stats);
     plo_cse_plan_destroy(pl);
     return rc;
+}
+
+// The restart range in `ndev` contiguous shards, one host thread and one device per shard; the minimum under (cost, seed).
+int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode, int ndev, const int *devices,
+                         plo_best_t *out, plo_stats_t *stats)
+{
+    if (!A || !out) return fail(PLO_E_ARG, "null argument");
+    if (ndev < 1 || ndev > 64) return fail(PLO_E_ARG, "device count outside [1,64]");
+    if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
+    struct Shard { int rc = PLO_OK; std::string msg; plo_best_t b{}; plo_stats_t st{}; uint64_t cnt = 0; };
+    std::vector<Shard> sh((size_t)ndev);
+    std::vector<std::thread> th;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < ndev; ++r) th.emplace_back([&, r]() {
+        Shard &S = sh[(size_t)r];
+        const uint64_t q = nseeds / (uint64_t)ndev, rem = nseeds % (uint64_t)ndev;                // the same blocks as the forked shards of the tools
+        const uint64_t s0 = seed0 + (uint64_t)r * q + std::min<uint64_t>((uint64_t)r, rem), cnt = q + ((uint64_t)r < rem ? 1 : 0);
+        S.cnt = cnt; S.b.adds = S.b.muls = 0xFFFFFFFFu; S.b.seed = ~0ull;
+        if (cnt == 0) return;
+        DevCtx ctx; t_ctx = &ctx;                                                                 // this thread's device, stream and limits
+        S.rc = plo_init(devices ? devices[r] : r);
+        if (S.rc == PLO_OK) S.rc = plo_cse_search(A, p, s0, cnt, cost_mode, &S.b, &S.st);
+        if (S.rc != PLO_OK) S.msg = "device " + std::to_string(devices ? devices[r] : r) + ": " + g_err;
+        plo_shutdown();
+        t_ctx = nullptr;
+    });
+    for (auto &t : th) t.join();
+    for (auto &S : sh) if (S.rc != PLO_OK) return fail(S.rc, S.msg);
+    auto key = [&](const plo_best_t &b) -> std::pair<uint64_t, uint64_t> {                        // cmpOpCount orders of plinopt_optimize.h:53-64, then the seed
+        switch (cost_mode) { case PLO_COST_ADD_THEN_MUL: return {b.adds, b.muls}; case PLO_COST_SUM: return {(uint64_t)b.adds + b.muls, 0}; default: return {(uint64_t)b.adds + b.muls, b.adds}; } };
+    out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull; bool have = false;
+    plo_stats_t agg{};
+    for (auto &S : sh) {
+        if (S.cnt == 0) continue;
+        agg.candidates += S.st.candidates; agg.launches += S.st.launches; agg.kernel_ms = std::max(agg.kernel_ms, S.st.kernel_ms);
+        agg.grid = S.st.grid; agg.lds_bytes = S.st.lds_bytes; agg.waves_per_wg = S.st.waves_per_wg; agg.algo_bytes = S.st.algo_bytes;
+        if (S.b.seed == ~0ull) continue;
+        if (!have || key(S.b) < key(*out) || (key(S.b) == key(*out) && S.b.seed < out->seed)) { *out = S.b; have = true; }
+    }
+    agg.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = agg;
+    return PLO_OK;
 }
 
 int plo_cse_chain_destroy(plo_chain_t *ch)

@@ -87,6 +87,18 @@ class CSEPlan:
         return (b.adds, b.muls, b.seed), mp.value
 
 
+def cse_search_multi(m, n, rowptr, col, val, p, seed0, nseeds, devices, cost_mode=capi.COST_SUM_THEN_ADD):
+    """One process, several devices (plo_cse_search_multi): the restart range in len(devices) contiguous shards, one host thread and
+    one device each; (adds, muls, seed) of the minimum under (cmpOpCount key, seed) and the aggregated stats."""
+    L = capi.lib()
+    csr, keep = capi.make_csr(m, n, rowptr, col, val)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    b, st = capi.Best(), capi.Stats()
+    capi.check(L.plo_cse_search_multi(ctypes.byref(csr), p, seed0, nseeds, cost_mode, len(devices), devs, ctypes.byref(b), ctypes.byref(st)))
+    del keep
+    return (b.adds, b.muls, b.seed), {"seconds": st.seconds, "kernel_ms": st.kernel_ms, "candidates": st.candidates, "launches": st.launches}
+
+
 def cmp_op_count_key(adds, muls, cost_mode=capi.COST_SUM_THEN_ADD):
     """Sort key equivalent to cmpOpCount (include/plinopt_optimize.h:53-64)."""
     if cost_mode == capi.COST_ADD_THEN_MUL:

@@ -65,7 +65,25 @@ def test_optimizer_two_shards_on_the_gpu(hip):
     rc2, out2, err2 = _run([OPT, "-q", str(P), "-D", "-O", "20001", "--seed", "3", "--gpu", "2", path], {"PLO_GPU_DEVICES": "0,0"})
     assert rc1 == 0 and rc2 == 0, err1 + err2
     assert out1 == out2 and _found(err1, "# Found D") == _found(err2, "# Found D")
-    assert "# 2 shards (one GPU each): 20001 candidates" in err2
+    assert "# 2 shards (one GPU and one host thread each, one process): 20001 candidates" in err2       # plo_cse_search_multi
+    rc3, out3, err3 = _run([OPT, "-q", str(P), "-D", "-O", "20001", "--seed", "3", "--gpu", "2", "--fork-shards", path], {"PLO_GPU_DEVICES": "0,0"})
+    assert rc3 == 0 and out3 == out1 and "# 2 shards (one GPU each): 20001 candidates" in err3, err3                     # one forked child per device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndev", [1, 2, 3])
+def test_in_library_multi_device_search_equals_one_device(hip, ndev):
+    """plo_cse_search_multi: one process, ndev host threads, one device each (all device 0 on the test box), contiguous seed
+    blocks, minimum under (cmpOpCount key, seed) -- the same winner as the search on one device and as the oracle."""
+    from plinopt_amd import CSEPlan, cse_search_multi
+    from plo_testlib import OracleMatrix
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), P)
+    for mode in (0, 1, 2):
+        got, st = cse_search_multi(M.m, M.n, M.rowptr, M.col, M.val, P, 7, 3001, [0] * ndev, cost_mode=mode)
+        assert got == M.search(7, 3001, cost_mode=mode, nthreads=8)
+        assert st["candidates"] == 3001
+    plan = CSEPlan(M.m, M.n, M.rowptr, M.col, M.val, P)          # the process-wide context still works after the threads' own
+    assert plan.search(7, 3001) == cse_search_multi(M.m, M.n, M.rowptr, M.col, M.val, P, 7, 3001, [0, 0])[0]
 
 
 @pytest.mark.gpu

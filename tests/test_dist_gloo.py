@@ -56,7 +56,7 @@ from plinopt_amd.dist import allreduce_cob_best
 got = allreduce_cob_best((30, 2, 5000 + rank, 1), 16)
 assert got == (30, 2, 5000, 1), got
 got = allreduce_cob_best((30, 2 + rank, 7, 1), 16)
-assert got == (30, 3, 7, 1), got
+assert got == (30, 1 + world, 7, 1), got
 got = allreduce_cob_best((29, 15, 1, 1) if rank == 0 else None, 16)
 assert got == (29, 15, 1, 1), got
 assert allreduce_cob_best((0, 0, 0, 0), 16) is None
@@ -65,15 +65,25 @@ print("rank", rank, "ok")
 """
 
 
-def test_two_rank_seed_shard_min_allreduce(tmp_path):
+def _run_world(tmp_path, world, port):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
-                       env=env, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1" if world > 2 else "2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
+
+
+def test_two_rank_seed_shard_min_allreduce(tmp_path):
+    _run_world(tmp_path, 2, 29533)
+
+
+def test_eight_rank_seed_shard_min_allreduce(tmp_path):
+    """the world size of the 8-GPU configs of BASELINE.json (configs[3], configs[4]): eight gloo ranks, the same single MIN
+    (MAX for the change-of-basis enumeration) all-reduce, empty shards included (a 1-seed range over 8 ranks)"""
+    _run_world(tmp_path, 8, 29541)
 
 
 def test_shard_range_partitions_exactly():
