@@ -1496,7 +1496,7 @@ int plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_i
         for (uint32_t e = 0; e < nnz; ++e) { cl[e] = (uint16_t)M->col[e]; vl[e] = (int8_t)M->val[e]; }
     }
     pl->P.cap = cap; pl->P.expanded = expanded ? 1u : 0u;
-    pl->P.lds_per_wave = round_up(8u * cap + 2u * ((A->m + 1u) & ~1u) + A->m, 16);
+    pl->P.lds_per_wave = round_up(8u * cap + 2u * ((A->m + 1u) & ~1u) + A->m, 16) + 16u * ((cap + 63u) / 64u);   // atoms, permutation, signs; masks of a pushvariables pass
     pl->algo_bytes = algo;
     pl->waves_per_wg = 4;
     pl->lds_bytes = pl->P.lds_per_wave * pl->waves_per_wg;

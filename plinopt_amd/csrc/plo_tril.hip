@@ -173,8 +173,121 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
     return false;
 }
 
-// :322-393
-__device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane) {
+// :322-393, one pass per variable instead of one (find, find, rotate) trip per couple.
+// Within the pass of variable i the reference looks for the next atom f of the variable from e + 1, the atom e that stops the
+// push of f depends only on atoms after f, and std::rotate(f, f+1, e) touches [f, e): the couples (f, e) of a pass can all be
+// found on the list as it stands and their rotations, which are disjoint, applied as ONE permutation.
+//   1. the atoms of the variable, in order, one per lane (ballots + prefix popcount);
+//   2. every such lane walks from its atom to its stopper (lock step, then the whole wave finishes the long walks);
+//   3. the chain f_1, e_1, f_2 = first atom of the variable behind e_1, ... is followed on the lanes' registers;
+//   4. the selected intervals become two bit masks (starts f+1, ends e) in LDS: position x moves down one slot iff
+//      #starts <= x exceeds #ends <= x; the atoms f are written to e - 1 at the end.
+// bm: 4 * ceil(cap/64) words of LDS (start and end masks).  Same result as t_pushvariables_ref below (bit-exact on the 49 cases
+// of tests/test_gpu_tril.py) -- and NOT faster: measured on 4x4x4_49_156 {L,R,P} (MI355X, -DPLO_TRIL_PROFILE) 11.35 M cycles of
+// pushvariables per candidate against 9.42 M for the literal form (5.13e5 against 5.70e5 candidates/s).  A pass costs ~1,300
+// wave instructions whichever way it is organised (gather 270, lock-step walks 500, chain 340, permutation 225) and the kernel
+// is bound by instruction issue at 8 waves per SIMD: the couples were never the cost, the 71 fixpoint trips x 16 passes are.
+// Built with -DPLO_TRIL_PASSPUSH; the default is the literal form.
+__device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane, uint32_t *bm) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t i = 0; i < numout; ++i) {
+        uint32_t pos = 0;
+        for (;;) {                                                              // (one round per 64 atoms of the variable: almost always one)
+            const uint32_t n = P.n, nch = (n + 63u) >> 6;
+            // 1. atoms of the variable at positions >= pos: lane j gets the j-th
+            uint32_t c = n, cnt = 0; uint64_t fa = 0;
+            for (uint32_t b = pos & ~63u; b < n && cnt < 64u; b += 64u) {
+                const uint32_t k = b + lane;
+                uint64_t a = 0; bool is = false;
+                if (k < n && k >= pos) { a = P.at[k]; is = ta_ope(a) != T_BAR && ta_src(a) == (int)i; }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(is);
+                if (!m) continue;
+                // lane (cnt + rank) takes the atom of the lane with that rank in m
+                const uint32_t want = lane - cnt;                              // rank this lane would take (if < popcount)
+                const uint32_t np = (uint32_t)__builtin_popcountll(m);
+                // source lane of rank `want`: select the want-th set bit of m
+                uint32_t srcl = 0; { unsigned long long mm = m; uint32_t w = want < np ? want : 0u; while (w--) mm &= mm - 1ull; srcl = (uint32_t)__builtin_ctzll(mm); }
+                const uint32_t ak = (uint32_t)__shfl((int)k, (int)srcl);
+                const uint32_t alo = (uint32_t)__shfl((int)(uint32_t)a, (int)srcl), ahi = (uint32_t)__shfl((int)(uint32_t)(a >> 32), (int)srcl);
+                if (lane >= cnt && want < np) { c = ak; fa = ((uint64_t)ahi << 32) | alo; }
+                cnt += np;
+            }
+            if (cnt == 0) break;
+            const uint32_t ncand = cnt < 64u ? cnt : 64u;
+            const bool have = lane < ncand;
+            // 2. stoppers
+            const uint32_t fo = ta_ope(fa); const int fd = ta_des(fa); const bool fas = t_as(fo);
+            auto stops = [&](uint64_t a) -> bool {
+                const int sa = ta_src(a);
+                return fas ? (fd == sa || (sa == (int)i && (fd == ta_des(a) || t_md(ta_ope(a))))) : (ta_des(a) == (int)i || sa == (int)i);
+            };
+            uint32_t k = c + 1u, e = n; int res = have ? 0 : 2;               // 0 walking, 2 done (e = stopper or n)
+            for (uint32_t step = 0; step < PLO_TRIL_LOCKSTEPS && __builtin_amdgcn_ballot_w64(res == 0); ++step) {
+                if (res == 0) {
+                    if (k >= n) res = 2;
+                    else if (stops(P.at[k])) { e = k; res = 2; }
+                    else ++k;
+                }
+            }
+            {
+                unsigned long long und = __builtin_amdgcn_ballot_w64(res == 0);
+                while (und) {
+                    const int L = __builtin_ctzll(und); und &= und - 1ull;
+                    const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
+                    const int bfd = __builtin_amdgcn_readlane(fd, L); const bool bfas = __builtin_amdgcn_readlane((int)fas, L) != 0;
+                    const uint32_t ee = t_find(P, bk, n, lane, [&](uint64_t a) { const int sa = ta_src(a);
+                        return bfas ? (bfd == sa || (sa == (int)i && (bfd == ta_des(a) || t_md(ta_ope(a))))) : (ta_des(a) == (int)i || sa == (int)i); });
+                    if ((int)lane == L) { e = ee; res = 2; }
+                }
+            }
+            bool rot = false;
+            if (have && e < n) { const uint64_t ea = P.at[e]; rot = fas ? (!(fd == ta_src(ea)) && fd == ta_des(ea)) : (!(ta_des(ea) == (int)i) && t_md(ta_ope(ea))); }
+            // 3. the chain of couples
+            unsigned long long sel = 0; uint32_t cur = 0, nextpos = n; bool passdone = false;
+            for (;;) {
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)cur), ee = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)cur);
+                const bool rr = __builtin_amdgcn_readlane((int)rot, (int)cur) != 0;
+                if (ee >= n) { if (f + 1u != n) sel |= 1ull << cur; passdone = true; break; }     // can be moved to the end (:381-391)
+                if (rr && f + 1u != ee) sel |= 1ull << cur;
+                const unsigned long long nx = __builtin_amdgcn_ballot_w64(have && c > ee);
+                if (!nx) { nextpos = ee + 1u; passdone = cnt <= 64u; break; }                      // no further atom of the variable in this round
+                cur = (uint32_t)__builtin_ctzll(nx);
+            }
+            // 4. one permutation for the selected couples
+            if (sel) {
+                const bool mine = (sel >> lane) & 1ull;
+                for (uint32_t w = lane; w < 4u * nch; w += 64u) bm[w] = 0u;
+                TW_SYNC();
+                if (mine) {
+                    const uint32_t st = c + 1u;
+                    atomicOr(&bm[st >> 5], 1u << (st & 31u));
+                    if (e < n) atomicOr(&bm[2u * nch + (e >> 5)], 1u << (e & 31u));
+                }
+                TW_SYNC();
+                uint32_t carry = 0;
+                for (uint32_t ch = 0; ch < nch; ++ch) {
+                    const uint32_t x = (ch << 6) + lane;
+                    const unsigned long long S = ((unsigned long long)bm[2u * ch + 1u] << 32) | bm[2u * ch], E = ((unsigned long long)bm[2u * nch + 2u * ch + 1u] << 32) | bm[2u * nch + 2u * ch];
+                    const unsigned long long upto = below | (1ull << lane);
+                    const bool inside = (int)(carry + (uint32_t)__builtin_popcountll(S & upto)) - (int)__builtin_popcountll(E & upto) > 0;
+                    uint64_t a = 0;
+                    if (x < n && inside) a = P.at[x];
+                    TW_SYNC();
+                    if (x < n && inside) P.at[x - 1u] = a;
+                    TW_SYNC();
+                    carry += (uint32_t)__builtin_popcountll(S) - (uint32_t)__builtin_popcountll(E);
+                }
+                if (mine) P.at[(e < n ? e : n) - 1u] = fa;
+                TW_SYNC();
+            }
+            if (passdone) break;
+            pos = nextpos;
+        }
+    }
+}
+
+// the literal form: one (find, find, rotate) trip per couple
+__device__ void t_pushvariables_ref(TrilProg &P, uint32_t numout, uint32_t lane) {
     for (uint32_t i = 0; i < numout; ++i) {
         uint32_t pos = 0;
         for (;;) {
@@ -199,7 +312,7 @@ __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane) {
 
 // :400-502 for +-1 matrices without empty rows; perm/sign describe the candidate's rows
 __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, bool transposed,
-                         bool oriented, uint32_t &rng, uint32_t lane, uint32_t ops[3], uint32_t cap, uint32_t *errw) {
+                         bool oriented, uint32_t &rng, uint32_t lane, uint32_t ops[3], uint32_t cap, uint32_t *errw, uint32_t *bm) {
     P.n = 0;
     const unsigned long long tb0 = clock64(); (void)tb0;
     uint32_t preci = M.n;
@@ -254,7 +367,11 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
     bool simp;
     do {
         unsigned long long t1 = clock64();
-        if (transposed) t_pushvariables(P, M.n, lane);
+#ifdef PLO_TRIL_PASSPUSH
+        if (transposed) t_pushvariables(P, M.n, lane, bm);
+#else
+        if (transposed) t_pushvariables_ref(P, M.n, lane);
+#endif
         TP_ADD(2, t1); t1 = clock64();
         simp = t_simplify(P, transposed, lane);
         TP_ADD(3, t1);
@@ -279,7 +396,7 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
 // of expanded rows: see oracle/plo_tril_oracle.c).  a = +-1, so y = 1/a = a, z = -c and no scaling atom exists.  No random
 // draw: the first entry is the pivot.
 __device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, uint32_t lane,
-                         uint32_t ops[3], uint32_t cap, uint32_t *errw) {
+                         uint32_t ops[3], uint32_t cap, uint32_t *errw, uint32_t *bm) {
     P.n = 0;
     for (uint32_t l = 0; l < M.m; ++l) {
         const uint32_t r = perm[l], b = M.rp[r], len = (uint32_t)M.rp[r + 1u] - b;
@@ -318,7 +435,11 @@ __device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
         TW_SYNC();
     }
     bool simp;
-    do { t_pushvariables(P, M.n + 1u, lane); simp = t_simplify(P, true, lane); } while (simp);
+#ifdef PLO_TRIL_PASSPUSH
+    do { t_pushvariables(P, M.n + 1u, lane, bm); simp = t_simplify(P, true, lane); } while (simp);
+#else
+    do { t_pushvariables_ref(P, M.n + 1u, lane); simp = t_simplify(P, true, lane); } while (simp);
+#endif
     uint32_t ad = 0, sc = 0, mu = 0;                                                                   // :133-144
     for (uint32_t k = lane; k < P.n; k += 64u) {
         const uint64_t at = P.at[k]; const uint32_t o = ta_ope(at); const int v = ta_val(at);
@@ -340,6 +461,7 @@ __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
     G.at = (uint64_t *)reg; G.n = 0;
     uint16_t *perm = (uint16_t *)(reg + 8u * cap);
     uint8_t *sgn = reg + 8u * cap + 2u * ((m + 1u) & ~1u);
+    uint32_t *bm = (uint32_t *)(reg + ((8u * cap + 2u * ((m + 1u) & ~1u) + m + 15u) & ~15u));   // start / end masks of a pushvariables pass: 4 words per 64 atoms
     unsigned long long best = ~0ull;
     const uint64_t stride = (uint64_t)gridDim.x * nw;
     for (uint64_t cnd = (uint64_t)blockIdx.x * nw + wave; cnd < J.ncand; cnd += stride) {
@@ -367,8 +489,8 @@ __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
             if (basec && variant == 1u) { tot[3] = tot[0]; tot[4] = tot[1]; tot[5] = tot[2]; break; }
             for (uint32_t w = 0; w < 3u; ++w) {
                 uint32_t o[3] = {0, 0, 0};
-                if (w == 2u && P.expanded) t_double(G, P.M[2], perm, sgn, 2u, lane, o, cap, J.err);
-                else t_linear(G, P.M[w], perm, sgn, w, w == 2u, variant == 0u, rng, lane, o, cap, J.err);
+                if (w == 2u && P.expanded) t_double(G, P.M[2], perm, sgn, 2u, lane, o, cap, J.err, bm);
+                else t_linear(G, P.M[w], perm, sgn, w, w == 2u, variant == 0u, rng, lane, o, cap, J.err, bm);
                 tot[3u * variant] += o[0]; tot[3u * variant + 1u] += o[1]; tot[3u * variant + 2u] += o[2];
             }
             tot[3u * variant + 2u] /= 3u;                                                            // :801-803
