@@ -30,7 +30,12 @@ namespace {
 thread_local std::string g_err;
 // The device context of the calling thread: the process-wide one set by plo_init (one process per GPU is the model of the
 // tools and of bench.py), or a thread's own inside plo_cse_search_multi (one host thread per device).
-struct DevCtx { int device = -1; hipStream_t stream = nullptr; int cus = 0; size_t lds_max = 0; };
+struct DevCtx {
+    int device = -1; hipStream_t stream = nullptr; int cus = 0; size_t lds_max = 0;
+    // scratch of the change-of-basis enumeration, kept between calls (bin/sparsifier -c 4 makes dozens of 256-candidate enumerations:
+    // four allocations, four frees and two event objects per call cost more than the kernel)
+    uint32_t *cob_buf = nullptr; size_t cob_words = 0; hipEvent_t cob_e0 = nullptr, cob_e1 = nullptr;
+};
 DevCtx g_ctx0;
 thread_local DevCtx *t_ctx = nullptr;
 inline DevCtx &cur_ctx() { return t_ctx ? *t_ctx : g_ctx0; }
@@ -638,6 +643,7 @@ int plo_init(int device)
         return fail(PLO_E_HIP, std::string("no HIP device visible (") + hipGetErrorString(ce) + "): libplinopt_hip has no CPU fallback");
     if (device < 0 || device >= n) return fail(PLO_E_ARG, "device ordinal out of range");
     if (g_device == device && g_stream) return PLO_OK;
+    if (g_device >= 0 && g_device != device) plo_shutdown();          // scratch and stream of the device left behind
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -652,6 +658,9 @@ int plo_init(int device)
 
 int plo_shutdown(void)
 {
+    DevCtx &cx = cur_ctx();
+    if (cx.cob_buf) { (void)hipFree(cx.cob_buf); cx.cob_buf = nullptr; cx.cob_words = 0; }
+    if (cx.cob_e0) { (void)hipEventDestroy(cx.cob_e0); (void)hipEventDestroy(cx.cob_e1); cx.cob_e0 = cx.cob_e1 = nullptr; }
     if (g_stream) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
     g_device = -1;
     return PLO_OK;
@@ -1372,20 +1381,26 @@ int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint3
     const unsigned long long init = ((unsigned long long)(thr + 1) << 32) | 0xFFFFFFFFull;
     const size_t lds = (4 * (size_t)m + 4 * (size_t)qn + ncoeffs) * 4;
     if (lds > g_lds_max) return fail(PLO_E_CAPACITY, "block of TM does not fit LDS");
-    uint32_t *d_tm = nullptr, *d_nb = nullptr, *d_cf = nullptr; unsigned long long *d_best = nullptr;
-    HIPCHK(hipMalloc((void **)&d_tm, tmb.size() * 4)); HIPCHK(hipMalloc((void **)&d_nb, nb.size() * 4));
-    HIPCHK(hipMalloc((void **)&d_cf, (size_t)ncoeffs * 4)); HIPCHK(hipMalloc((void **)&d_best, 8));
-    HIPCHK(hipMemcpy(d_tm, tmb.data(), tmb.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_nb, nb.data(), nb.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_cf, coeffs, (size_t)ncoeffs * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_best, &init, 8, hipMemcpyHostToDevice));
+    // one device buffer kept by the context, one upload: [best word (2) | TM block | nullspace block | coefficients]
+    DevCtx &cx = cur_ctx();
+    const size_t o_tm = 2, o_nb = o_tm + tmb.size(), o_cf = o_nb + nb.size(), words = o_cf + ncoeffs;
+    if (cx.cob_words < words) {
+        if (cx.cob_buf) (void)hipFree(cx.cob_buf);
+        cx.cob_buf = nullptr; cx.cob_words = 0;
+        HIPCHK(hipMalloc((void **)&cx.cob_buf, (words + 1024) * 4)); cx.cob_words = words + 1024;
+    }
+    if (!cx.cob_e0) { HIPCHK(hipEventCreate(&cx.cob_e0)); HIPCHK(hipEventCreate(&cx.cob_e1)); }
+    std::vector<uint32_t> up(words);
+    memcpy(up.data(), &init, 8); memcpy(up.data() + o_tm, tmb.data(), tmb.size() * 4); memcpy(up.data() + o_nb, nb.data(), nb.size() * 4); memcpy(up.data() + o_cf, coeffs, (size_t)ncoeffs * 4);
+    HIPCHK(hipMemcpyAsync(cx.cob_buf, up.data(), words * 4, hipMemcpyHostToDevice, g_stream));
+    uint32_t *d_tm = cx.cob_buf + o_tm, *d_nb = cx.cob_buf + o_nb, *d_cf = cx.cob_buf + o_cf; unsigned long long *d_best = (unsigned long long *)cx.cob_buf;
     plo::CobJob J{}; J.n = n; J.m = m; J.qn = qn; J.fb = fb; J.C = ncoeffs; J.p = p; J.mu = (~0ull) / p; J.first = first; J.total = total;
     J.tm = d_tm; J.nb = d_nb; J.coeffs = d_cf; J.best = d_best;
     // table form when 4*C*(m+qn) products fit LDS (odd strides: the lanes of a wave read rows l, l+1, ... of one column)
     const uint32_t mstride = m | 1u, qstride = std::max<uint32_t>(qn, 1u) | 1u;
     const size_t lds_tab = 4ull * ncoeffs * ((size_t)mstride + qstride) * 4;
     const bool use_tab = lds_tab <= 72u * 1024u && !getenv("PLO_COB_GENERIC");
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipEvent_t e0 = cx.cob_e0, e1 = cx.cob_e1;
     uint64_t grid;
     if (use_tab) {
         HIPCHK(hipFuncSetAttribute((const void *)plo::cob_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tab));
@@ -1401,10 +1416,8 @@ int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint3
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, g_stream)); HIPCHK(hipEventSynchronize(e1));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     unsigned long long w = 0;
     HIPCHK(hipMemcpy(&w, d_best, 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d_tm); (void)hipFree(d_nb); (void)hipFree(d_cf); (void)hipFree(d_best);
     out->found = w != init ? 1u : 0u;
     if (out->found) { const uint32_t sc = (uint32_t)(w >> 32) - 1u; out->zeros_v = (int32_t)(sc / (n + 1)); out->zeros_w = (int32_t)(sc % (n + 1)); out->index = (uint32_t)~(uint32_t)w; }
     else { out->zeros_v = w0; out->zeros_w = w1; out->index = 0; }
