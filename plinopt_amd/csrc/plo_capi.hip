@@ -117,8 +117,8 @@ int build_plan(plo_plan *pl, std::vector<uint8_t> *img_out = nullptr)
     for (uint32_t i = 0; i < m; ++i) { uint32_t l = rowptr[i + 1] - rowptr[i]; if (l > 1) naive += l - 1; }
     const uint64_t NC = (uint64_t)n + naive / 2 + 2;
     const uint32_t rb = ceil_log2(p), bb = ceil_log2((uint32_t)NC);     // residues < 2^rb, columns < 2^bb
-    if (NC >= 0xFFFFull || 2u * bb + rb > 44u)
-        return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) does not fit 44 bits for this matrix/modulus");
+    if (NC >= 0xFFFFull || 2u * bb + rb > 51u)
+        return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) does not fit 51 bits for this matrix/modulus");
     if (2ull * nnz >= 65535ull) return fail(PLO_E_CAPACITY, "op-count may exceed 16 bits");
 
     std::vector<uint32_t> inv(nnz);
@@ -1105,7 +1105,7 @@ int layout_plan(plo::WavePlan &P, uint32_t m, uint32_t n, uint32_t nnz, uint32_t
     const uint32_t mw = 1;
     const uint64_t NC = (uint64_t)n + naive / 2 + 2;
     const uint32_t rb = ceil_log2(p), bb = ceil_log2((uint32_t)NC);
-    if (NC >= 0xFFFFull || 2u * bb + rb > 44u) return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) of the dependent part does not fit 44 bits");
+    if (NC >= 0xFFFFull || 2u * bb + rb > 51u) return fail(PLO_E_CAPACITY, "pair key (col,col,ratio) of the dependent part does not fit 51 bits");
     if (2ull * nnz >= 65535ull || cap > 65536u) return fail(PLO_E_CAPACITY, "dependent part too large for the wave kernel");
     P.m = m; P.n = n; P.nnz = nnz; P.p = p; P.NC = (uint32_t)NC; P.cap = cap; P.hbits = ceil_log2(cap);
     P.lpr_log2 = std::max(2u, ceil_log2(std::max(maxlen, 1u))); P.mw = mw; P.unit = 0u;

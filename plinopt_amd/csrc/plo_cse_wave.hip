@@ -15,8 +15,8 @@
 //
 // Data layout (per wave, all in LDS; the matrix image is fetched from an
 // L2-resident template at the start of every candidate):
-//   tab[cap]      u64  open-addressing pair table: key<<20 | count, key =
-//                      col_a<<(bb+rb) | col_b<<rb | ratio (44 bits), so integer order of
+//   tab[cap]      u64  open-addressing pair table: key<<13 | count, key =
+//                      col_a<<(bb+rb) | col_b<<rb | ratio (<= 51 bits), so integer order of
 //                      keys == std::map order of the reference's (size_t,size_t,Element)
 //   masks[NC*2mw] u64  per column c: cmask (bit i: row i holds column c) then umask
 //                      (bit i: that entry is +-1); mw = ceil(m/64) words each
@@ -49,7 +49,7 @@ __device__ unsigned long long g_wprof[12];   // lane 0 of every wave: cycles in 
 
 struct WavePlan {
     uint32_t m, n, nnz, p, NC, cap, hbits, lpr_log2, mw, unit, multcap, maxlen;
-    uint32_t rb, bb;        // bits of a ratio (p-1) and of a column index (NC-1): 2*bb+rb <= 44
+    uint32_t rb, bb;        // bits of a ratio (p-1) and of a column index (NC-1): 2*bb+rb <= 51
     uint32_t off_tab, off_cmask, off_umask, off_val, off_inv, off_col, off_len;   // template part
     uint32_t tmpl_bytes;                                                          // multiple of 8
     uint32_t off_aff, off_ties, off_mult, region_bytes;                           // scratch part
@@ -146,9 +146,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-#define PLO_VB 20u                                  // value bits of a table slot
-#define PLO_VMASK 0xFFFFFull
-#define PLO_EMPTY 0xFFFFFFFFFFF00000ull             // key all ones, value 0
+// value bits of a table slot: a frequency is a number of rows (<= 1984) and ProgramGen's multiset counts are too: 12 bits and one flag;
+// the key has 51 bits, so that any odd prime below 2^31 leaves 10 bits per column (round 2: 20 value bits, 44-bit keys)
+#define PLO_VB 13u
+#define PLO_VMASK 0x1FFFull
+#define PLO_EMPTY 0xFFFFFFFFFFFFE000ull             // key all ones, value 0
 __device__ __forceinline__ uint32_t tab_hash(uint64_t key, uint32_t hbits) {
     uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
     return (x * 0x9E3779B1u) >> (32u - hbits);
@@ -243,7 +245,8 @@ __device__ __forceinline__ uint32_t tab_find(const uint64_t *tab, uint64_t key, 
 }
 
 #define PLO_FRESH 0xFFFFu       // column id of a variable created inside ProgramGen (never looked up by index)
-#define PLO_MFLAG 0x10000u      // "in multiples" flag in the table value
+#define PLO_MFLAG 0x1000u       // "in multiples" flag in the table value (bit 12, above the 12-bit count)
+#define PLO_PGCMASK 0xFFFu
 
 // ProgramGen for general coefficients, counts only (reference
 // include/plinopt_optimize.inl:513-611).  Counting semantics, derived from the
@@ -299,7 +302,7 @@ __device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const u
         uint32_t cnt = 0;
         for (uint32_t s = lane; s < cap; s += 64u) {
             uint64_t v = tab[s];
-            if (v != PLO_EMPTY && ((uint32_t)v & 0xFFFFu) >= 2u && !((uint32_t)v & PLO_MFLAG)) { ++cnt; tab[s] = v | PLO_MFLAG; }
+            if (v != PLO_EMPTY && ((uint32_t)v & PLO_PGCMASK) >= 2u && !((uint32_t)v & PLO_MFLAG)) { ++cnt; tab[s] = v | PLO_MFLAG; }
         }
         nbmul += wave_sum(cnt);
     }
@@ -310,7 +313,7 @@ __device__ uint64_t program_gen_general(const WavePlan &P, uint8_t *reg, const u
         const uint32_t base = act ? rs[row] : 0u, ln = act ? len[row] : 0u;
         if (t < ln) {
             const uint32_t v = val[base + t], e = fabsp(v, p), c = col[base + t];
-            if (!absone(e, p) && (tab_find(tab, ((uint64_t)c << rb) | e, cap, hbits) & 0xFFFFu) >= 2u) {
+            if (!absone(e, p) && (tab_find(tab, ((uint64_t)c << rb) | e, cap, hbits) & PLO_PGCMASK) >= 2u) {
                 const uint32_t u = (v == e) ? 1u : p - 1u;                 // Fsign >= 0 ? one : mOne
                 col[base + t] = (uint16_t)PLO_FRESH; val[base + t] = u; inv[base + t] = u;
                 atomicAnd((unsigned long long *)&cmask[c * ms], ~(1ull << row));
@@ -512,7 +515,7 @@ __device__ uint64_t run_candidate(const WavePlan &P, uint8_t *reg, const uint16_
                 uint64_t w = __ballot(lane < T && rank == k);
                 key = rdlane64(mine, (uint32_t)__builtin_ctzll(w));
             } else {
-                uint64_t lo = 0ull, hi = (1ull << 44) - 1ull;             // k-th smallest by bisection on the key value
+                uint64_t lo = 0ull, hi = (1ull << (64u - PLO_VB)) - 1ull;  // k-th smallest by bisection on the key value (keys have at most 64 - PLO_VB bits)
                 while (lo < hi) {
                     uint64_t mid = lo + ((hi - lo) >> 1); uint32_t c = 0;
                     for (uint32_t s0 = 0; s0 < T; s0 += 64u) {

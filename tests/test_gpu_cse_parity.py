@@ -58,12 +58,34 @@ def test_other_modulus(hip):
         assert plan.cost_many(seed0=5, n=500) == tuple(M.cost_many(seed0=5, nseeds=500, nthreads=8))
 
 
+@pytest.mark.parametrize("name", ["4x4x4_49_156_P.sms", "4x4x4_49_156_L.sms", "3x3x6_40_P.sms", "4x4x4_48_rational_P.sms"])
+def test_largest_31_bit_prime_on_wide_matrices(hip, name):
+    """Round 3: 51-bit pair keys (13 value bits per slot instead of 20): a 31-bit ratio leaves 10 bits per column, so the largest
+    prime below 2^31 works on every LDS-sized matrix of the data set -- 4x4x4_49_156_P (49 columns, up to 141 with the created
+    ones) was PLO_E_CAPACITY with the 44-bit key of round 2 (reference field: Modular<Integer>, src/optimizer.cpp:125-139)."""
+    p = 2147483629
+    M = OracleMatrix.from_sms(os.path.join(DATA, name), p)
+    plan = _plan(M)
+    assert not plan.is_hbm
+    assert plan.cost_many(seed0=9, n=400) == tuple(M.cost_many(seed0=9, nseeds=400, nthreads=8))
+    assert plan.search(9, 400) == M.search(9, 400, nthreads=8)
+
+
 def test_capacity_error_is_loud(hip):
-    """A modulus whose pair key needs more than 44 bits is refused, never silently rerouted."""
-    from plinopt_amd import capi
-    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_P.sms"), 2147483629)
+    """A pair key beyond 51 bits (more than 1024 columns with a 31-bit modulus) is refused by the LDS kernel, and the HBM family
+    refuses 31-bit ratios in its 48-bit key: the plan fails loudly, nothing is rerouted silently."""
+    import random
+    from plinopt_amd import CSEPlan, capi
+    p = 2147483629
+    rng = random.Random(1)
+    rows = [sorted(rng.sample(range(1100), 6)) for _ in range(40)]
+    rp, c, v = [0], [], []
+    for r in rows:
+        for j in r:
+            c.append(j); v.append(rng.choice([1, p - 1, 2]))
+        rp.append(len(c))
     with pytest.raises(capi.PloError) as e:
-        _plan(M)
+        CSEPlan(40, 1100, rp, c, v, p)
     assert e.value.code == capi.PLO_E_CAPACITY
 
 
