@@ -169,18 +169,36 @@ def dist_setup(args):
 
 def issue_roofline(name, kernel, per_launch_ms):
     """For the kernels whose state lives in LDS the HBM roofline says nothing: report instruction issue instead, from the
-    committed rocprofv3 counters of the same workload (profiles/r02_issue.json: SQ_INSTS_* / SQ_BUSY_CYCLES)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_issue.json")))[name]
-    except Exception:
+    committed rocprofv3 counters of the same workload (profiles/r03_issue.json, else r02_issue.json: SQ_INSTS_* / SQ_BUSY_CYCLES).
+    The counters belong to one version of the kernel: `stale` says whether the source has changed since; `achieved` is scaled by
+    profiled kernel time / this run's kernel time (the instruction count of a launch does not change with the clock)."""
+    d = None
+    for fn in ("r03_issue.json", "r02_issue.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn))).get(name)
+        except Exception:
+            d = None
+        if d:
+            break
+    if not d:
         return None
     unit = d["bound_unit"]
     ach = d["salu_per_clk_cu"] if unit == "scalar" else d["valu_per_clk_cu"]
     peak = 1.0 if unit == "scalar" else 2.0
-    return {"bound": "issue", "achieved": ach, "peak": peak, "unit": "%s wave-instructions/clk/CU" % unit, "frac": ach / peak, "traffic": None,
-            "kernel": kernel, "kernel_ms_per_launch": per_launch_ms, "source": d["source"],
-            "all_units_per_clk_cu": {k: d[k] for k in ("valu_per_clk_cu", "salu_per_clk_cu", "lds_per_clk_cu", "vmem_per_clk_cu")},
-            "note": "achieved/peak from the profile of this workload, not from this run; the run's own kernel time is kernel_ms_per_launch"}
+    out = {"bound": "issue", "achieved": ach, "peak": peak, "unit": "%s wave-instructions/clk/CU" % unit, "frac": ach / peak, "traffic": None,
+           "kernel": kernel, "kernel_ms_per_launch": per_launch_ms, "source": d["source"],
+           "all_units_per_clk_cu": {k: d[k] for k in ("valu_per_clk_cu", "salu_per_clk_cu", "lds_per_clk_cu", "vmem_per_clk_cu")},
+           "note": "achieved/peak from the profile of this workload, not from this run; the run's own kernel time is kernel_ms_per_launch"}
+    if "kernel_source_sha16" in d:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            from make_issue_json import sources_sha16
+            out["stale"] = sources_sha16(name) != d["kernel_source_sha16"]
+        except Exception:
+            out["stale"] = None
+    else:
+        out["stale"] = None                          # a round-2 entry: no hash was recorded
+    return out
 
 
 def bench_cob(args):
@@ -307,8 +325,8 @@ def bench_tril(args):
     def one(k):
         s0 = k * gb
         r = G.search(s0 + rank * batch, batch)       # ((ADD, SCA, MUL), seed, variant) of this rank's shard
-        seed, variant, word = allreduce_tril_best(r, s0, device=dev)      # ONE 8-byte MIN all-reduce (order ADD, SCA, seed, variant)
-        return r, seed, variant, word
+        seed, variant, word, fl = allreduce_tril_best(r, s0, device=dev, fields=True)      # ONE MIN all-reduce (order ADD, SCA, seed, variant)
+        return r, seed, variant, fl
 
     for k in range(warm):
         one(k)
@@ -317,9 +335,9 @@ def bench_tril(args):
     best = None
     t0 = time.perf_counter()
     for k in range(steps):
-        r, seed, variant, word = one(warm + k)
+        r, seed, variant, fl = one(warm + k)
         kms += G.last_stats["kernel_ms"]
-        key = (word >> 43, (word >> 23) & 0xFFFFF, seed, variant)
+        key = (fl[0], fl[1], seed, variant)                 # (ADD, SCA) decoded by the reduction itself, whichever word layout it used
         best = key if best is None or key < best else best
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
@@ -370,8 +388,8 @@ def bench_kmethod(args):
     def one(k):
         s0 = 1 + k * gb
         _, _, _, b, st = kernel_search((m, n, rp, c, v), p, s0 + rank * batch, batch, want_costs=False)
-        seed, word = allreduce_best((b[0], b[1], b[2]), s0, device=dev)
-        return b, seed, word, st
+        seed, word, fl = allreduce_best((b[0], b[1], b[2]), s0, device=dev, fields=True)
+        return b, seed, fl, st
 
     for k in range(warm):
         one(k)
@@ -380,7 +398,7 @@ def bench_kmethod(args):
     best = None
     t0 = time.perf_counter()
     for k in range(steps):
-        b, seed, word, st = one(warm + k)
+        b, seed, word, st = one(warm + k)                   # word: the decoded cost fields (sum, adds), comparable across steps whatever layout was reduced
         kms += st["kernel_ms"]
         best = (word, seed) if best is None or (word, seed) < best else best
     barrier()
@@ -479,12 +497,12 @@ def main():
         if timed:
             kernel_ms += stats["kernel_ms"]
             launches += stats["launches"]
-        seed, word = allreduce_best(local, s0, capi.COST_SUM_THEN_ADD, device=dev)   # one MIN all-reduce of 16 bytes (cost word + "fits one word" flag)
+        seed, word, fl = allreduce_best(local, s0, capi.COST_SUM_THEN_ADD, device=dev, fields=True)   # one MIN all-reduce of 16 bytes (cost word + "fits one word" flag)
         if timed:
             search_s += t_b - t_a
             reduce_s += time.perf_counter() - t_b
-        if best_word is None or (word >> 32, seed) < (best_word[0] >> 32, best_word[1]):
-            best_word = (word, seed)
+        if best_word is None or (fl, seed) < (best_word[2], best_word[1]):
+            best_word = (word, seed, fl)
         return seed
 
     for k in range(args.warmup):
@@ -525,7 +543,7 @@ def main():
             "config": {"workload": desc, "matrix": fname, "modulus": p, "per_gpu_batch": batch,
                        "global_batch": global_batch, "parallelism": "seed-shard x%d + 1 MIN all-reduce/step" % world,
                        "nnz": len(c), "rows": m, "cols": n},
-            "best": {"packed": best_word[0], "seed": best_word[1]},
+            "best": {"packed": best_word[0], "seed": best_word[1], "adds_plus_muls": best_word[2][0], "adds": best_word[2][1]},
             "per_rank_ms": {"columns": ["kernel (HIP events)", "search wall (library call)", "all-reduce wall (includes waiting for the slowest rank)"],
                             "rows": per_rank_ms, "steps": args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

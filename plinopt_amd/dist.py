@@ -43,8 +43,10 @@ def cost_word(adds, muls, cost_mode=capi.COST_SUM_THEN_ADD):
     return ((adds + muls) << 31) | adds
 
 
-def allreduce_best(local, seed0, cost_mode=capi.COST_SUM_THEN_ADD, group=None, device=None):
-    """local = (adds, muls, seed) or None.  Returns (winning seed, reduced word).
+def allreduce_best(local, seed0, cost_mode=capi.COST_SUM_THEN_ADD, group=None, device=None, fields=False):
+    """local = (adds, muls, seed) or None.  Returns (winning seed, reduced word); with fields=True a third element (f1, f2): the two
+    cost fields of the order (sum, adds / adds, muls / sum, 0 by cost mode) decoded for whichever of the two word layouts was reduced --
+    callers that compare or print costs use these, never bits of `word`.
     ONE all_reduce(MIN) of a single int64 when (cost, seed offset) packs into 63 bits on every rank
     (always the case for the workloads of bench.py); otherwise two 8-byte MIN all-reduces
     (cost first, then the smallest seed among the ranks holding that cost)."""
@@ -66,7 +68,10 @@ def allreduce_best(local, seed0, cost_mode=capi.COST_SUM_THEN_ADD, group=None, d
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     if int(t[1].item()) == 1:
         w = int(t[0].item())
-        return (None, w) if w == INF else (seed0 + unpack_seed_off(w), w)
+        if w == INF:
+            return (None, w, None) if fields else (None, w)
+        r = (seed0 + unpack_seed_off(w), w)
+        return r + ((w >> 43, (w >> 23) & 0xFFFFF),) if fields else r
     # two-stage fallback: wide costs or far-apart seeds
     c = INF if local is None else cost_word(local[0], local[1], cost_mode)
     tc = torch.tensor([c], dtype=torch.int64, device=dev)
@@ -74,15 +79,16 @@ def allreduce_best(local, seed0, cost_mode=capi.COST_SUM_THEN_ADD, group=None, d
         dist.all_reduce(tc, op=dist.ReduceOp.MIN, group=group)
     best_c = int(tc.item())
     if best_c == INF:
-        return None, INF
+        return (None, INF, None) if fields else (None, INF)
     sd = local[2] - seed0 if (local is not None and c == best_c) else INF
     ts = torch.tensor([sd], dtype=torch.int64, device=dev)
     if multi:
         dist.all_reduce(ts, op=dist.ReduceOp.MIN, group=group)
-    return seed0 + int(ts.item()), best_c
+    r = (seed0 + int(ts.item()), best_c)
+    return r + ((best_c >> 31, best_c & ((1 << 31) - 1)),) if fields else r
 
 
-def allreduce_tril_best(local, seed0, group=None, device=None):
+def allreduce_tril_best(local, seed0, group=None, device=None, fields=False):
     """Same single MIN all-reduce for the in-place trilinear search (`SearchTriLinearAlgorithm`'s critical sections,
     include/plinopt_inplace.inl:891-921): local = ((ADD, SCA, MUL), seed, variant) or None; order (ADD, SCA, seed, variant).
     Returns (seed, variant, word) or (None, None, INF)."""
@@ -90,11 +96,12 @@ def allreduce_tril_best(local, seed0, group=None, device=None):
     if local is not None:
         (add, sca, _mul), seed, variant = local
         pseudo = (add, sca, seed0 + (((seed - seed0) << 1) | variant))
-    s, w = allreduce_best(pseudo, seed0, capi.COST_ADD_THEN_MUL, group=group, device=device)
+    s, w, fl = allreduce_best(pseudo, seed0, capi.COST_ADD_THEN_MUL, group=group, device=device, fields=True)
     if s is None:
-        return None, None, INF
+        return (None, None, INF, None) if fields else (None, None, INF)
     off = s - seed0
-    return seed0 + (off >> 1), off & 1, w
+    r = (seed0 + (off >> 1), off & 1, w)
+    return r + (fl,) if fields else r                     # fl = (ADD, SCA) of the winner
 
 
 def allreduce_cob_best(local, n, group=None, device=None):
