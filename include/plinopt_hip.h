@@ -189,8 +189,8 @@ int plo_cse_enum_search_plan(plo_plan_t *plan, uint64_t first, uint64_t count, i
  * coherent row negations drawn from the seed's stream, then the oriented (variant 0) and the unoriented (variant 1)
  * in-place program of TriLinearProgram :732-806; cost = (ADD, SCA) lexicographic as :893-897, ties to the smaller
  * (seed, variant).  seed == PLO_TRIL_BASE_SEED is the unpermuted oriented program of :829.  The device path takes
- * matrices with entries +-1, no empty row and rows of at most 64 entries (PLO_E_UNSUPPORTED otherwise: such inputs
- * stay on the host).  The host replays the winning (seed, variant) to print the program. */
+ * matrices without empty row and with rows of at most 64 entries (PLO_E_UNSUPPORTED otherwise: such inputs stay on the
+ * host); integer entries here, rationals through plo_tril_plan_create_q.  The host replays the winning (seed, variant) to print the program. */
 #define PLO_TRIL_BASE_SEED 0xFFFFFFFFFFFFFFFFull
 typedef struct { uint32_t m, n; const uint32_t *rowptr; const uint32_t *col; const int32_t *val; } plo_icsr_t;
 typedef struct { uint32_t add, sca, mul; uint32_t variant; uint64_t seed; } plo_tril_best_t;
@@ -200,6 +200,13 @@ int  plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_ic
  * (include/plinopt_inplace.inl:507-598) on DoubleExpand(T) (:676-716, built on the device from the m-row T); a candidate
  * returns (ADD, SCA) of that variant and MUL = m double-size AXPYs (:799). */
 int  plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, int expanded, plo_tril_plan_t **plan);
+/* Rational coefficients num/den (den == NULL: all 1), as the reference's matrices are (Givaro::Rational, include/plinopt_inplace.inl:19):
+ * the atoms of the device programs carry the coefficients' images modulo the 31-bit prime 2147483629 (an additive atom its signed
+ * coefficient, a multiplicative atom its factor: what cumulate/isnoop/complexity, :96-144, depend on); the tool replays and checks the
+ * winner over Q.  All entries +-1: the kernel of rounds 1-2.  PLO_E_UNSUPPORTED: an empty row, a row of more than 64 entries, an
+ * entry that vanishes modulo the prime, or expanded != 0 with coefficients other than +-1. */
+typedef struct { uint32_t m, n; const uint32_t *rowptr; const uint32_t *col; const int64_t *num; const int64_t *den; } plo_qcsr_t;
+int  plo_tril_plan_create_q(const plo_qcsr_t *A, const plo_qcsr_t *B, const plo_qcsr_t *T, int expanded, plo_tril_plan_t **plan);
 void plo_tril_plan_destroy(plo_tril_plan_t *plan);
 /* ops6[6k..6k+5] = ADD,SCA,MUL of variant 0 then of variant 1 for candidate k (seeds[k], or seed0+k when seeds==NULL) */
 int  plo_tril_cost_many(plo_tril_plan_t *plan, const uint64_t *seeds, uint64_t seed0, uint64_t n, uint32_t *ops6, plo_stats_t *stats);

@@ -27,28 +27,31 @@
 #include <stdarg.h>
 
 /* ---------------------------------------------------------------- rationals */
-typedef struct { int64_t n, d; } rat;
+/* 128-bit numerator and denominator, overflow-checked (the reference's Givaro::Rational is arbitrary precision: the fixtures with
+ * decimal coefficients such as 12.0695 overflow 64 bits in cumulate :96-122 after a few merges, not 128) */
+typedef __int128 i128;
+typedef struct { i128 n, d; } rat;
 static int g_overflow;
-static int64_t gcd64(int64_t a, int64_t b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { int64_t t = a % b; a = b; b = t; } return a; }
-static rat rmake(int64_t n, int64_t d) {
+static i128 gcd128(i128 a, i128 b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { i128 t = a % b; a = b; b = t; } return a; }
+static rat rmake(i128 n, i128 d) {
     if (d == 0) { g_overflow = 1; rat z = {0, 1}; return z; }
     if (d < 0) { n = -n; d = -d; }
-    int64_t g = gcd64(n, d); if (g > 1) { n /= g; d /= g; }
+    i128 g = gcd128(n, d); if (g > 1) { n /= g; d /= g; }
     rat r = {n, d}; return r;
 }
-static int64_t mulck(int64_t a, int64_t b) { int64_t r; if (__builtin_mul_overflow(a, b, &r)) g_overflow = 1; return r; }
-static int64_t addck(int64_t a, int64_t b) { int64_t r; if (__builtin_add_overflow(a, b, &r)) g_overflow = 1; return r; }
-static rat radd(rat a, rat b) { return rmake(addck(mulck(a.n, b.d), mulck(b.n, a.d)), mulck(a.d, b.d)); }
+static i128 mulck(i128 a, i128 b) { i128 r; if (__builtin_mul_overflow(a, b, &r)) g_overflow = 1; return r; }
+static i128 addck(i128 a, i128 b) { i128 r; if (__builtin_add_overflow(a, b, &r)) g_overflow = 1; return r; }
+static rat radd(rat a, rat b) { const i128 g = gcd128(a.d, b.d); const i128 bd = b.d / g, ad = a.d / g; return rmake(addck(mulck(a.n, bd), mulck(b.n, ad)), mulck(a.d, bd)); }
 static rat rneg(rat a) { rat r = {-a.n, a.d}; return r; }
 static rat rsub(rat a, rat b) { return radd(a, rneg(b)); }
-static rat rmul(rat a, rat b) { return rmake(mulck(a.n, b.n), mulck(a.d, b.d)); }
+static rat rmul(rat a, rat b) { const i128 g1 = gcd128(a.n, b.d), g2 = gcd128(b.n, a.d); return rmake(mulck(a.n / (g1 ? g1 : 1), b.n / (g2 ? g2 : 1)), mulck(a.d / (g2 ? g2 : 1), b.d / (g1 ? g1 : 1))); }
 static rat rinv(rat a) { return rmake(a.d, a.n); }
 static rat rdiv(rat a, rat b) { return rmul(a, rinv(b)); }
 static int rsign(rat a) { return a.n > 0 ? 1 : a.n < 0 ? -1 : 0; }
 static int risone(rat a) { return a.n == 1 && a.d == 1; }
 static int rismone(rat a) { return a.n == -1 && a.d == 1; }
 static int riszero(rat a) { return a.n == 0; }
-static int rabslt1(rat a) { int64_t n = a.n < 0 ? -a.n : a.n; return n < a.d; }      /* |a| < 1 */
+static int rabslt1(rat a) { i128 n = a.n < 0 ? -a.n : a.n; return n < a.d; }      /* |a| < 1 */
 
 /* -------------------------------------------------------------------- atoms */
 typedef struct { char var; uint32_t src; char ope; rat val; long des; } atom;   /* plinopt_inplace.inl:15-24 */
@@ -289,11 +292,17 @@ static void sput(sbuf *b, const char *fmt, ...) {
     if (b->n + (size_t)k + 1 > b->cap) { b->cap = 2 * (b->cap + (size_t)k) + 256; b->s = (char *)realloc(b->s, b->cap); }
     memcpy(b->s + b->n, tmp, (size_t)k + 1); b->n += (size_t)k;
 }
-static void put_rat(sbuf *b, rat r) { if (r.d == 1) sput(b, "%lld", (long long)r.n); else sput(b, "%lld/%lld", (long long)r.n, (long long)r.d); }
+static void put_i128(sbuf *b, i128 v) {
+    char t[48]; int k = 47; t[k] = 0; const int neg = v < 0; unsigned __int128 u = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    do { t[--k] = (char)('0' + (int)(u % 10)); u /= 10; } while (u);
+    if (neg) t[--k] = '-';
+    sput(b, "%s", t + k);
+}
+static void put_rat(sbuf *b, rat r) { put_i128(b, r.n); if (r.d != 1) { sput(b, "/"); put_i128(b, r.d); } }
 /* printmulorjustdiv, rational specialisation: plinopt_library.inl:360-374 */
 static void put_mulordiv(sbuf *b, char c, long i, rat r) {
     sput(b, "%c%ld", c, i);
-    if (!risone(r)) { if (r.n == 1) sput(b, "/%lld", (long long)r.d); else { sput(b, "*"); put_rat(b, r); } }
+    if (!risone(r)) { if (r.n == 1) { sput(b, "/"); put_i128(b, r.d); } else { sput(b, "*"); put_rat(b, r); } }
 }
 /* Atom operator<< :43-78 (barriers are consumed by the AXPY lines of the caller) */
 static void put_atom(sbuf *b, const atom *p) {

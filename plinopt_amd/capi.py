@@ -23,7 +23,7 @@ EXPORTS = [
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch", "plo_kernel_search",
     "plo_cse_enum_cost_many_plan", "plo_cse_enum_search_plan",
     "plo_cob_search", "plo_cob_search_range",
-    "plo_tril_plan_create", "plo_tril_plan_create_x", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
+    "plo_tril_plan_create", "plo_tril_plan_create_x", "plo_tril_plan_create_q", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
     "plo_pack_cost",
 ]
 
@@ -56,6 +56,11 @@ class CobBest(ctypes.Structure):
 
 class ICSR(ctypes.Structure):
     _fields_ = [("m", ctypes.c_uint32), ("n", ctypes.c_uint32), ("rowptr", u32p), ("col", u32p), ("val", ctypes.POINTER(ctypes.c_int32))]
+
+
+class QCSR(ctypes.Structure):
+    _fields_ = [("m", ctypes.c_uint32), ("n", ctypes.c_uint32), ("rowptr", u32p), ("col", u32p),
+                ("num", ctypes.POINTER(ctypes.c_int64)), ("den", ctypes.POINTER(ctypes.c_int64))]
 
 
 class TrilBest(ctypes.Structure):
@@ -123,6 +128,7 @@ def lib():
         L.plo_cse_enum_search_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(Best), u64p, ctypes.POINTER(Stats)]
         L.plo_tril_plan_create.argtypes = [ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ctypes.c_void_p)]
         L.plo_tril_plan_create_x.argtypes = [ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.plo_tril_plan_create_q.argtypes = [ctypes.POINTER(QCSR), ctypes.POINTER(QCSR), ctypes.POINTER(QCSR), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.plo_tril_plan_destroy.argtypes = [ctypes.c_void_p]
         L.plo_tril_plan_destroy.restype = None
         L.plo_tril_cost_many.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, ctypes.POINTER(Stats)]

@@ -37,24 +37,37 @@
 namespace plo {
 
 // ------------------------------------------------------------------ rationals
+// 128-bit numerator and denominator, overflow-checked (round 3; rounds 1-2: 64 bits).  The reference's Givaro::Rational is arbitrary
+// precision; the fixtures with decimal coefficients (e.g. 2x2x2_7_DPS-intermediate-12.0695) overflow 64 bits after a few merges of
+// the in-place programs, not 128.  An overflow is an exception, never a wrong value.
 struct Rat {
-    int64_t n = 0, d = 1;
+    __int128 n = 0, d = 1;
     Rat() = default;
     Rat(int64_t nn, int64_t dd = 1) { set((__int128)nn, (__int128)dd); }
+    static __int128 gcd(__int128 a, __int128 b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { __int128 t = a % b; a = b; b = t; } return a; }
+    static __int128 mulck(__int128 a, __int128 b) { __int128 r; if (__builtin_mul_overflow(a, b, &r)) throw std::overflow_error("rational overflow (128-bit)"); return r; }
+    static __int128 addck(__int128 a, __int128 b) { __int128 r; if (__builtin_add_overflow(a, b, &r)) throw std::overflow_error("rational overflow (128-bit)"); return r; }
     void set(__int128 nn, __int128 dd) {
         if (dd == 0) throw std::domain_error("rational with zero denominator");
         if (dd < 0) { nn = -nn; dd = -dd; }
-        __int128 a = nn < 0 ? -nn : nn, b = dd;
-        while (b) { __int128 t = a % b; a = b; b = t; }
-        if (a > 1) { nn /= a; dd /= a; }
-        if (nn > INT64_MAX || nn < -INT64_MAX || dd > INT64_MAX) throw std::overflow_error("rational overflow (64-bit)");
-        n = (int64_t)nn; d = (int64_t)dd;
+        const __int128 g = gcd(nn, dd);
+        if (g > 1) { nn /= g; dd /= g; }
+        n = nn; d = dd;
     }
     static Rat make(__int128 nn, __int128 dd) { Rat r; r.set(nn, dd); return r; }
+    // a.n/a.d * b.n/b.d and a.n/a.d + b.n/b.d with the common factors taken out before the products
+    static Rat mul(const Rat &a, const Rat &b) { const __int128 g1 = gcd(a.n, b.d), g2 = gcd(b.n, a.d); return make(mulck(a.n / (g1 ? g1 : 1), b.n / (g2 ? g2 : 1)), mulck(a.d / (g2 ? g2 : 1), b.d / (g1 ? g1 : 1))); }
+    static Rat add(const Rat &a, const Rat &b) { const __int128 g = gcd(a.d, b.d), bd = b.d / g, ad = a.d / g; return make(addck(mulck(a.n, bd), mulck(b.n, ad)), mulck(a.d, bd)); }
     bool operator==(const Rat &o) const { return n == o.n && d == o.d; }
     bool operator!=(const Rat &o) const { return !(*this == o); }
-    bool operator<(const Rat &o) const { return (__int128)n * o.d < (__int128)o.n * d; }
+    bool operator<(const Rat &o) const { Rat m; m.n = -o.n; m.d = o.d; return add(*this, m).n < 0; }
 };
+inline std::ostream &operator<<(std::ostream &os, __int128 v) {
+    char t[48]; int k = 47; t[k] = 0; const bool neg = v < 0; unsigned __int128 u = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    do { t[--k] = (char)('0' + (int)(u % 10)); u /= 10; } while (u);
+    if (neg) t[--k] = '-';
+    return os << (t + k);
+}
 inline std::ostream &operator<<(std::ostream &os, const Rat &r) { os << r.n; if (r.d != 1) os << '/' << r.d; return os; }
 
 inline Rat parse_rat(const std::string &s) {
@@ -153,11 +166,11 @@ struct QField {
     Elt zero() const { return Rat(0); }
     Elt one() const { return Rat(1); }
     Elt mone() const { return Rat(-1); }
-    Elt mul(const Elt &a, const Elt &b) const { return Rat::make((__int128)a.n * b.n, (__int128)a.d * b.d); }
-    Elt add(const Elt &a, const Elt &b) const { return Rat::make((__int128)a.n * b.d + (__int128)b.n * a.d, (__int128)a.d * b.d); }
+    Elt mul(const Elt &a, const Elt &b) const { return Rat::mul(a, b); }
+    Elt add(const Elt &a, const Elt &b) const { return Rat::add(a, b); }
     Elt neg(const Elt &a) const { return Rat::make(-(__int128)a.n, a.d); }
     Elt inv(const Elt &a) const { return Rat::make(a.d, a.n); }
-    Elt div(const Elt &a, const Elt &b) const { return Rat::make((__int128)a.n * b.d, (__int128)a.d * b.n); }
+    Elt div(const Elt &a, const Elt &b) const { return Rat::mul(a, Rat::make(b.d, b.n)); }
     bool isZero(const Elt &a) const { return a.n == 0; }
     bool isOne(const Elt &a) const { return a.n == 1 && a.d == 1; }
     bool isMOne(const Elt &a) const { return a.n == -1 && a.d == 1; }

@@ -24,7 +24,7 @@ namespace {
 struct HipTril {
     void *h = nullptr;
     decltype(&plo_init) init = nullptr; decltype(&plo_last_error) last_error = nullptr;
-    decltype(&plo_tril_plan_create_x) create = nullptr; decltype(&plo_tril_plan_destroy) destroy = nullptr; decltype(&plo_tril_search) search = nullptr;
+    decltype(&plo_tril_plan_create_q) create = nullptr; decltype(&plo_tril_plan_destroy) destroy = nullptr; decltype(&plo_tril_search) search = nullptr;
     bool load() {
         std::vector<std::string> cand;
         for (const char *v : {"PLO_HIP_LIB", "PLINOPT_HIP_LIB"}) if (const char *e = getenv(v)) cand.emplace_back(e);   // (one name for the tools and plinopt_amd/capi.py; the older one still works)
@@ -34,7 +34,7 @@ struct HipTril {
         for (auto &c : cand) { h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
         if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
         init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
-        create = (decltype(create))dlsym(h, "plo_tril_plan_create_x"); destroy = (decltype(destroy))dlsym(h, "plo_tril_plan_destroy");
+        create = (decltype(create))dlsym(h, "plo_tril_plan_create_q"); destroy = (decltype(destroy))dlsym(h, "plo_tril_plan_destroy");
         search = (decltype(search))dlsym(h, "plo_tril_search");
         return init && last_error && create && destroy && search;
     }
@@ -42,12 +42,13 @@ struct HipTril {
 
 bool better(const Tricount &l, const Tricount &r) { return l[0] < r[0] || (l[0] == r[0] && l[1] < r[1]); }   // :893-897
 
-struct ICsr { std::vector<uint32_t> rp{0}, col; std::vector<int32_t> val; bool unit = true, full = true; };
+// rational CSR for plo_tril_plan_create_q (round 3: the device programs carry the coefficients modulo a 31-bit prime)
+struct ICsr { std::vector<uint32_t> rp{0}, col; std::vector<int64_t> num, den; bool unit = true, full = true; };
 ICsr icsr(const QMat &M) {
     ICsr c;
     for (const auto &row : M.rows) {
         if (row.empty() || row.size() > 64) c.full = false;
-        for (const auto &e : row) { c.col.push_back((uint32_t)e.first); if (!(e.second.d == 1 && (e.second.n == 1 || e.second.n == -1))) c.unit = false; c.val.push_back((int32_t)e.second.n); }
+        for (const auto &e : row) { c.col.push_back((uint32_t)e.first); if (!(e.second.d == 1 && (e.second.n == 1 || e.second.n == -1))) c.unit = false; c.num.push_back((int64_t)e.second.n); c.den.push_back((int64_t)e.second.d); }
         c.rp.push_back((uint32_t)c.col.size());
     }
     return c;
@@ -82,16 +83,17 @@ int main(int argc, char **argv) {
         bool on_gpu = false; double kms = 0;
         if (loops > 0) {
             ICsr ca = icsr(A), cb = icsr(B), ct = icsr(T);
-            const bool device_ok = ca.unit && cb.unit && ct.unit && ca.full && cb.full && ct.full;
+            // device path: no empty row, rows of at most 64 entries; with -e only +-1 coefficients (TransposedDoubleAlgorithm on the device is the unit form)
+            const bool device_ok = ca.full && cb.full && ct.full && (!expanded || (ca.unit && cb.unit && ct.unit));
             using Key = std::tuple<size_t, size_t, uint64_t, int>;      // (ADD, SCA, seed, variant): the order of :893-897 made total
             // restarts s0 .. s0+cnt-1 on one device (plo_tril_search); throws on failure
             auto gpu_search = [&](int device, uint64_t s0, uint64_t cnt, plo_tril_best_t &r, plo_stats_t &st) {
                 HipTril L;
                 if (!L.load()) throw std::runtime_error("cannot load libplinopt_hip.so");        // no silent fallback: --gpu 0 selects the host loop
                 if (L.init(device) != PLO_OK) throw std::runtime_error(L.last_error());
-                plo_icsr_t a{(uint32_t)A.rowdim(), (uint32_t)A.coldim(), ca.rp.data(), ca.col.data(), ca.val.data()};
-                plo_icsr_t b{(uint32_t)B.rowdim(), (uint32_t)B.coldim(), cb.rp.data(), cb.col.data(), cb.val.data()};
-                plo_icsr_t t{(uint32_t)T.rowdim(), (uint32_t)T.coldim(), ct.rp.data(), ct.col.data(), ct.val.data()};
+                plo_qcsr_t a{(uint32_t)A.rowdim(), (uint32_t)A.coldim(), ca.rp.data(), ca.col.data(), ca.num.data(), ca.den.data()};
+                plo_qcsr_t b{(uint32_t)B.rowdim(), (uint32_t)B.coldim(), cb.rp.data(), cb.col.data(), cb.num.data(), cb.den.data()};
+                plo_qcsr_t t{(uint32_t)T.rowdim(), (uint32_t)T.coldim(), ct.rp.data(), ct.col.data(), ct.num.data(), ct.den.data()};
                 plo_tril_plan_t *plan = nullptr;
                 if (L.create(&a, &b, &t, expanded ? 1 : 0, &plan) != PLO_OK) throw std::runtime_error(L.last_error());
                 const int rc = L.search(plan, s0, cnt, &r, &st);
@@ -150,7 +152,7 @@ int main(int argc, char **argv) {
                     const Tricount g{r.add, r.sca, r.mul};
                     if (better(g, best)) { best = g; bseed = r.seed; bvar = (int)r.variant; }
                 } else {
-                    if (gpu) std::clog << "# matrices are not +-1 without empty rows: host search" << std::endl;
+                    if (gpu) std::clog << "# an empty row, a row of more than 64 entries, or -e with coefficients other than +-1: host search" << std::endl;
                     // best of the loop under (ADD, SCA, seed, variant), then strictly better than the unpermuted program
                     const Key lb = host_loop(seed0, loops);
                     const Tricount g{std::get<0>(lb), std::get<1>(lb), A.rowdim()};

@@ -1435,6 +1435,7 @@ struct plo_tril_plan {
     void *d_img = nullptr; uint32_t *d_err = nullptr; unsigned long long *d_best = nullptr;
     uint32_t waves_per_wg = 4, lds_bytes = 0, blocks_per_cu = 1;
     uint64_t algo_bytes = 0;
+    bool rational = false;           // coefficients other than +-1: residues modulo a 31-bit prime, tril_kernel<true>
 };
 
 namespace {
@@ -1446,7 +1447,8 @@ int tril_launch(plo_tril_plan *pl, plo::TrilJob J, plo_stats_t *st) {
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, g_stream));
-    hipLaunchKernelGGL(plo::tril_kernel, dim3((uint32_t)grid), dim3(64 * pl->waves_per_wg), pl->lds_bytes, g_stream, pl->P, J);
+    if (pl->rational) hipLaunchKernelGGL((plo::tril_kernel<true>), dim3((uint32_t)grid), dim3(64 * pl->waves_per_wg), pl->lds_bytes, g_stream, pl->P, J);
+    else hipLaunchKernelGGL((plo::tril_kernel<false>), dim3((uint32_t)grid), dim3(64 * pl->waves_per_wg), pl->lds_bytes, g_stream, pl->P, J);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, g_stream)); HIPCHK(hipEventSynchronize(e1));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -1466,16 +1468,19 @@ extern "C" {
 
 int plo_tril_plan_create(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, plo_tril_plan_t **plan) { return plo_tril_plan_create_x(A, B, T, 0, plan); }
 
-int plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, int expanded, plo_tril_plan_t **plan)
+// Common builder: entries as rationals num/den.  All entries +-1: the unit kernel (small signed values); otherwise the residues
+// modulo PLO_TRIL_PRIME and the rational instantiation of the kernel (plo_tril.hip).
+#define PLO_TRIL_PRIME 2147483629u
+int plo_tril_plan_create_q(const plo_qcsr_t *A, const plo_qcsr_t *B, const plo_qcsr_t *T, int expanded, plo_tril_plan_t **plan)
 {
     if (g_device < 0) return fail(PLO_E_HIP, "plo_init was not called (or found no HIP device)");
     if (!A || !B || !T || !plan) return fail(PLO_E_ARG, "null argument");
-    const plo_icsr_t *Ms[3] = {A, B, T};
+    const plo_qcsr_t *Ms[3] = {A, B, T};
     if (A->m == 0 || A->m != B->m || A->m != T->m) return fail(PLO_E_ARG, "A, B and T (transposed product matrix) need the same number of rows");
-    if (A->m > 65535u) return fail(PLO_E_CAPACITY, "more than 65535 rows");
-    uint32_t cap = 0; size_t bytes = 0; uint64_t algo = 8;
-    for (const plo_icsr_t *M : Ms) {
-        if (!M->rowptr || !M->col || !M->val || M->n == 0 || M->n > 65535u) return fail(PLO_E_ARG, "bad matrix");
+    if (A->m > 16382u) return fail(PLO_E_CAPACITY, "more than 16382 rows");
+    uint32_t cap = 0; size_t bytes = 0; uint64_t algo = 8; bool unit = true;
+    for (const plo_qcsr_t *M : Ms) {
+        if (!M->rowptr || !M->col || !M->num || M->n == 0 || M->n > 16382u) return fail(PLO_E_ARG, "bad matrix (at most 16382 variables)");
         const uint32_t nnz = M->rowptr[M->m];
         if (nnz > 65535u) return fail(PLO_E_CAPACITY, "more than 65535 non-zeros");
         for (uint32_t i = 0; i < M->m; ++i) {
@@ -1483,32 +1488,44 @@ int plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_i
             if (len == 0) return fail(PLO_E_UNSUPPORTED, "empty row: host path only");
             if (len > 64) return fail(PLO_E_UNSUPPORTED, "row with more than 64 entries: host path only");
             for (uint32_t e = M->rowptr[i]; e < M->rowptr[i + 1]; ++e) {
-                if (M->val[e] != 1 && M->val[e] != -1) return fail(PLO_E_UNSUPPORTED, "entry other than +-1: host path only");
+                const int64_t nu = M->num[e], de = M->den ? M->den[e] : 1;
+                if (nu == 0 || de == 0) return fail(PLO_E_ARG, "zero entry or zero denominator");
+                if (!(de == 1 && (nu == 1 || nu == -1))) unit = false;
+                if (de % (int64_t)PLO_TRIL_PRIME == 0 || nu % (int64_t)PLO_TRIL_PRIME == 0) return fail(PLO_E_UNSUPPORTED, "entry not a unit modulo the device's prime: host path only");
                 if (M->col[e] >= M->n || (e > M->rowptr[i] && M->col[e] <= M->col[e - 1])) return fail(PLO_E_ARG, "columns must be sorted and in range");
             }
         }
         cap = std::max(cap, 2u * nnz + 3u * M->m);
         if (expanded && M == T) cap = std::max(cap, 4u * nnz + 2u * M->m);        // TransposedDoubleAlgorithm: 4(len-1)+2 atoms per row
-        if (expanded && M == T && M->n >= 65535u) return fail(PLO_E_CAPACITY, "one more variable of c than 16 bits hold");
-        bytes += round_up((M->m + 1) * 2, 16) + round_up(nnz * 2, 16) + round_up(nnz, 16);
+        if (expanded && M == T && M->n >= 16382u) return fail(PLO_E_CAPACITY, "one more variable of c than the atom holds");
+        bytes += round_up((M->m + 1) * 2, 16) + round_up(nnz * 2, 16) + round_up(nnz, 16) + round_up(nnz * 4, 16);
         algo += 2ull * (M->m + 1) + 3ull * nnz;                 // the CSR image of the three matrices, once per candidate
     }
+    if (expanded && !unit) return fail(PLO_E_UNSUPPORTED, "trilplacer -e with coefficients other than +-1: host path only");
     cap = round_up(cap + 2, 64);
     plo_tril_plan *pl = new plo_tril_plan();
+    pl->rational = !unit;
     std::vector<uint8_t> img(bytes, 0);
     if (hipMalloc(&pl->d_img, bytes) != hipSuccess) { delete pl; return fail(PLO_E_HIP, "hipMalloc"); }
     size_t off = 0;
     for (int w = 0; w < 3; ++w) {
-        const plo_icsr_t *M = Ms[w]; const uint32_t nnz = M->rowptr[M->m];
+        const plo_qcsr_t *M = Ms[w]; const uint32_t nnz = M->rowptr[M->m];
         plo::TrilMat &D = pl->P.M[w];
         D.m = M->m; D.n = M->n; D.nnz = nnz;
         uint16_t *rp = (uint16_t *)(img.data() + off); D.rp = (const uint16_t *)((uint8_t *)pl->d_img + off); off += round_up((M->m + 1) * 2, 16);
         uint16_t *cl = (uint16_t *)(img.data() + off); D.col = (const uint16_t *)((uint8_t *)pl->d_img + off); off += round_up(nnz * 2, 16);
         int8_t *vl = (int8_t *)(img.data() + off); D.val = (const int8_t *)((uint8_t *)pl->d_img + off); off += round_up(nnz, 16);
+        uint32_t *vp = (uint32_t *)(img.data() + off); D.valp = (const uint32_t *)((uint8_t *)pl->d_img + off); off += round_up(nnz * 4, 16);
         for (uint32_t i = 0; i <= M->m; ++i) rp[i] = (uint16_t)M->rowptr[i];
-        for (uint32_t e = 0; e < nnz; ++e) { cl[e] = (uint16_t)M->col[e]; vl[e] = (int8_t)M->val[e]; }
+        for (uint32_t e = 0; e < nnz; ++e) {
+            cl[e] = (uint16_t)M->col[e];
+            const int64_t nu = M->num[e], de = M->den ? M->den[e] : 1;
+            vl[e] = unit ? (int8_t)nu : 0;
+            int64_t a = nu % (int64_t)PLO_TRIL_PRIME, d = de % (int64_t)PLO_TRIL_PRIME; if (a < 0) a += PLO_TRIL_PRIME; if (d < 0) d += PLO_TRIL_PRIME;
+            vp[e] = (uint32_t)((uint64_t)a * inv_mod((uint32_t)d, PLO_TRIL_PRIME) % PLO_TRIL_PRIME);
+        }
     }
-    pl->P.cap = cap; pl->P.expanded = expanded ? 1u : 0u;
+    pl->P.cap = cap; pl->P.expanded = expanded ? 1u : 0u; pl->P.p = unit ? 0u : PLO_TRIL_PRIME;
     pl->P.lds_per_wave = round_up(8u * cap + 2u * ((A->m + 1u) & ~1u) + A->m, 16) + 16u * ((cap + 63u) / 64u);   // atoms, permutation, signs; masks of a pushvariables pass
     pl->algo_bytes = algo;
     pl->waves_per_wg = 4;
@@ -1516,12 +1533,28 @@ int plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_i
     if (pl->lds_bytes > 64u * 1024u) { pl->waves_per_wg = 1; pl->lds_bytes = pl->P.lds_per_wave; }
     if (pl->lds_bytes > g_lds_max) { (void)hipFree(pl->d_img); delete pl; return fail(PLO_E_CAPACITY, "program does not fit LDS"); }
     pl->blocks_per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32u / pl->waves_per_wg, (uint32_t)(g_lds_max / pl->lds_bytes)));
+    const void *fn = pl->rational ? (const void *)plo::tril_kernel<true> : (const void *)plo::tril_kernel<false>;
     if (hipMemcpy(pl->d_img, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMalloc((void **)&pl->d_err, 4) != hipSuccess ||
-        hipMalloc((void **)&pl->d_best, 8) != hipSuccess || hipFuncSetAttribute((const void *)plo::tril_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes) != hipSuccess) {
+        hipMalloc((void **)&pl->d_best, 8) != hipSuccess || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes) != hipSuccess) {
         plo_tril_plan_destroy(pl); return fail(PLO_E_HIP, "device setup of the trilplacer plan failed");
     }
     *plan = pl;
     return PLO_OK;
+}
+
+// integer entries (the interface of rounds 1-2): the same builder with denominators 1
+int plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_icsr_t *T, int expanded, plo_tril_plan_t **plan)
+{
+    if (!A || !B || !T || !plan) return fail(PLO_E_ARG, "null argument");
+    const plo_icsr_t *Ms[3] = {A, B, T};
+    std::vector<int64_t> nums[3]; plo_qcsr_t Q[3];
+    for (int w = 0; w < 3; ++w) {
+        if (!Ms[w]->rowptr || !Ms[w]->col || !Ms[w]->val) return fail(PLO_E_ARG, "bad matrix");
+        const uint32_t nnz = Ms[w]->rowptr[Ms[w]->m];
+        nums[w].assign(Ms[w]->val, Ms[w]->val + nnz);
+        Q[w] = plo_qcsr_t{Ms[w]->m, Ms[w]->n, Ms[w]->rowptr, Ms[w]->col, nums[w].data(), nullptr};
+    }
+    return plo_tril_plan_create_q(&Q[0], &Q[1], &Q[2], expanded, plan);
 }
 
 void plo_tril_plan_destroy(plo_tril_plan_t *pl)

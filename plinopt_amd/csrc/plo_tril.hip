@@ -28,8 +28,8 @@
 
 namespace plo {
 
-struct TrilMat { uint32_t m, n, nnz; const uint16_t *rp; const uint16_t *col; const int8_t *val; };
-struct TrilPlan { TrilMat M[3]; uint32_t cap; uint32_t lds_per_wave; uint32_t expanded; };   // expanded: `trilplacer -e`
+struct TrilMat { uint32_t m, n, nnz; const uint16_t *rp; const uint16_t *col; const int8_t *val; const uint32_t *valp; };   // valp: residues modulo TrilPlan::p (rational inputs)
+struct TrilPlan { TrilMat M[3]; uint32_t cap; uint32_t lds_per_wave; uint32_t expanded; uint32_t p; };   // expanded: `trilplacer -e`; p != 0: rational coefficients as residues modulo the prime p
 struct TrilJob {
     uint64_t seed0; const uint64_t *seeds; uint64_t ncand;
     uint32_t *ops;               // 6 per candidate: ADD,SCA,MUL oriented then unoriented (may be null)
@@ -51,14 +51,28 @@ __device__ unsigned long long g_tprof[8];   // lane 0 of wave 0 of every workgro
 #define TP_ADD(k_, t0_) do { } while (0)
 #endif
 // one atom = one 8-byte word: src | des<<16 | val<<32 | ope<<48 (des, val signed 16 bits)
+// Rational inputs (round 3; Atom::_val is a Givaro::Rational, plinopt_inplace.inl:19): the value of an atom is its image modulo a
+// 31-bit prime, and the word is src (14 bits) | des (14 bits, all ones = none) | ope (3 bits) in the low half, the residue in the
+// high half.  What the program's counts depend on survives the image: an additive atom carries the SIGNED coefficient of its
+// operation (cumulate :96-107 adds or subtracts and then only normalises the sign: ope and |val| are a representation), it is a
+// no-op iff the coefficient is 0 and scalar iff it is not +-1 (complexity :133-144); a multiplicative atom carries its factor,
+// a no-op iff 1 (:108-118 normalises |val| >= 1 the same way).  A collision modulo the prime would need a non-zero rational
+// of the inputs' size to vanish modulo 2147483629; the tool replays and verifies the winner over Q in any case.
 struct TrilProg { uint64_t *at; uint32_t n; };
-__device__ __forceinline__ uint64_t ta_make(uint32_t src, int des, int val, uint32_t ope) {
-    return (uint64_t)(src & 0xFFFFu) | ((uint64_t)((uint32_t)des & 0xFFFFu) << 16) | ((uint64_t)((uint32_t)val & 0xFFFFu) << 32) | ((uint64_t)ope << 48);
+template <bool RAT> __device__ __forceinline__ uint64_t ta_make(uint32_t src, int des, uint32_t val, uint32_t ope) {
+    if constexpr (RAT) return (uint64_t)((src & 0x3FFFu) | (((uint32_t)des & 0x3FFFu) << 14) | (ope << 28)) | ((uint64_t)val << 32);
+    else return (uint64_t)(src & 0xFFFFu) | ((uint64_t)((uint32_t)des & 0xFFFFu) << 16) | ((uint64_t)(val & 0xFFFFu) << 32) | ((uint64_t)ope << 48);
 }
-__device__ __forceinline__ int ta_src(uint64_t a) { return (int)(a & 0xFFFFull); }
-__device__ __forceinline__ int ta_des(uint64_t a) { return (int)(int16_t)(uint16_t)(a >> 16); }
-__device__ __forceinline__ int ta_val(uint64_t a) { return (int)(int16_t)(uint16_t)(a >> 32); }
-__device__ __forceinline__ uint32_t ta_ope(uint64_t a) { return (uint32_t)(a >> 48) & 0xFFu; }
+template <bool RAT> __device__ __forceinline__ int ta_src(uint64_t a) { if constexpr (RAT) return (int)((uint32_t)a & 0x3FFFu); else return (int)(a & 0xFFFFull); }
+template <bool RAT> __device__ __forceinline__ int ta_des(uint64_t a) {
+    if constexpr (RAT) { const uint32_t d = ((uint32_t)a >> 14) & 0x3FFFu; return d == 0x3FFFu ? -1 : (int)d; }
+    else return (int)(int16_t)(uint16_t)(a >> 16);
+}
+// unit inputs: a small signed integer; rational inputs: the residue (as int bits)
+template <bool RAT> __device__ __forceinline__ int ta_val(uint64_t a) { if constexpr (RAT) return (int)(uint32_t)(a >> 32); else return (int)(int16_t)(uint16_t)(a >> 32); }
+template <bool RAT> __device__ __forceinline__ uint32_t ta_ope(uint64_t a) { if constexpr (RAT) return ((uint32_t)a >> 28) & 7u; else return (uint32_t)(a >> 48) & 0xFFu; }
+__device__ __forceinline__ uint32_t t_mulmod(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)(((uint64_t)a * b) % p); }
+__device__ __forceinline__ uint32_t t_invmod(uint32_t a, uint32_t p) { uint32_t r = 1u, bs = a; for (uint32_t e = p - 2u; e; e >>= 1) { if (e & 1u) r = t_mulmod(r, bs, p); bs = t_mulmod(bs, bs, p); } return r; }
 
 __device__ __forceinline__ uint32_t t_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t t_rng(uint32_t &s) { s = (uint32_t)((950706376ull * (uint64_t)s) % 2147483647ull); return s; }
@@ -101,12 +115,13 @@ template <class F> __device__ __forceinline__ uint32_t t_find(const TrilProg &P,
 }
 
 // what stops the walk of atom `it` at atom `nx`: a merge (sameops + cumulate, :266-282) or a dependency (:284-307)
-__device__ __forceinline__ bool t_merges(uint64_t it, uint64_t nx) {
-    const uint32_t io = ta_ope(it), no = ta_ope(nx);
-    return (uint32_t)it == (uint32_t)nx && ((t_as(io) && t_as(no)) || (t_md(io) && t_md(no)));       // same src and des, compatible operations
+template <bool RAT> __device__ __forceinline__ bool t_merges(uint64_t it, uint64_t nx) {
+    const uint32_t io = ta_ope<RAT>(it), no = ta_ope<RAT>(nx);
+    const bool same = RAT ? (((uint32_t)it ^ (uint32_t)nx) & 0x0FFFFFFFu) == 0u : (uint32_t)it == (uint32_t)nx;
+    return same && ((t_as(io) && t_as(no)) || (t_md(io) && t_md(no)));       // same src and des, compatible operations
 }
-__device__ __forceinline__ bool t_breaks(uint64_t it, uint64_t nx, bool transposed) {
-    const int is = ta_src(it), id = ta_des(it), ns = ta_src(nx), nd = ta_des(nx); const uint32_t io = ta_ope(it), no = ta_ope(nx);
+template <bool RAT> __device__ __forceinline__ bool t_breaks(uint64_t it, uint64_t nx, bool transposed) {
+    const int is = ta_src<RAT>(it), id = ta_des<RAT>(it), ns = ta_src<RAT>(nx), nd = ta_des<RAT>(nx); const uint32_t io = ta_ope<RAT>(it), no = ta_ope<RAT>(nx);
     bool brk = (is == ns) && (no == T_BAR || (t_as(io) && t_md(no)) || (t_md(io) && t_as(no)));
     brk |= transposed ? (id == ns) : (id == ns && no != T_BAR);
     brk |= (is == nd);
@@ -114,12 +129,12 @@ __device__ __forceinline__ bool t_breaks(uint64_t it, uint64_t nx, bool transpos
 }
 
 // :243-311.  true = one merge applied.
-__device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
+template <bool RAT> __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane, uint32_t prime) {
     for (uint32_t base = 0; base < P.n; base += 64u) {
         const uint32_t p = base + lane, n = P.n;
         uint64_t it = 0;
         bool act = p < n;
-        if (act) { it = P.at[p]; act = ta_ope(it) != T_BAR; }
+        if (act) { it = P.at[p]; act = ta_ope<RAT>(it) != T_BAR; }
         uint32_t k = p + 1u, q = 0; int res = act ? 0 : 2;       // 0 walking, 1 merge found, 2 stopped
         // most walks end within a few atoms: a few lock-step steps, one atom per lane ...
         for (uint32_t step = 0; step < PLO_TRIL_LOCKSTEPS && __builtin_amdgcn_ballot_w64(res == 0); ++step) {
@@ -127,8 +142,8 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
                 if (k >= n) res = 2;
                 else {
                     const uint64_t nx = P.at[k];
-                    if (t_merges(it, nx)) { res = 1; q = k; }
-                    else if (t_breaks(it, nx, transposed)) res = 2;
+                    if (t_merges<RAT>(it, nx)) { res = 1; q = k; }
+                    else if (t_breaks<RAT>(it, nx, transposed)) res = 2;
                     else ++k;
                 }
             }
@@ -142,8 +157,8 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
                 const int L = __builtin_ctzll(und); und &= und - 1ull;
                 const uint64_t bit = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(it >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)it, L);
                 const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
-                const uint32_t e = t_find(P, bk, n, lane, [&](uint64_t nx) { return t_merges(bit, nx) || t_breaks(bit, nx, transposed); });
-                const bool mg = e < n && t_merges(bit, P.at[e < n ? e : 0u]);
+                const uint32_t e = t_find(P, bk, n, lane, [&](uint64_t nx) { return t_merges<RAT>(bit, nx) || t_breaks<RAT>(bit, nx, transposed); });
+                const bool mg = e < n && t_merges<RAT>(bit, P.at[e < n ? e : 0u]);
                 if ((int)lane == L) { if (mg) { res = 1; q = e; } else res = 2; }
                 if (mg) break;
             }
@@ -153,9 +168,14 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
             const int L = __builtin_ctzll(ok);
             const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)p, L), qq = (uint32_t)__builtin_amdgcn_readlane((int)q, L);
             const uint64_t a1 = P.at[pp], a2 = P.at[qq];
-            const uint32_t o1 = ta_ope(a1), o2 = ta_ope(a2); const int v1 = ta_val(a1), v2 = ta_val(a2);
+            const uint32_t o1 = ta_ope<RAT>(a1), o2 = ta_ope<RAT>(a2); const int v1 = ta_val<RAT>(a1), v2 = ta_val<RAT>(a2);
             uint32_t o = o1; int v; bool noop;
-            if (t_as(o1)) {                                   // :96-107
+            if constexpr (RAT) {
+                const uint32_t u1 = (uint32_t)v1, u2 = (uint32_t)v2; uint32_t u;
+                if (t_as(o1)) { u = (o1 == o2) ? (uint32_t)(((uint64_t)u1 + u2) % prime) : (uint32_t)(((uint64_t)u1 + prime - u2) % prime); noop = u == 0u; }   // :96-107: the signed coefficient of o1 (the sign swap of :103-106 is a representation)
+                else { u = (o1 == o2) ? t_mulmod(u1, u2, prime) : t_mulmod(u1, t_invmod(u2, prime), prime); noop = u == 1u; }                                  // :108-118
+                v = (int)u;
+            } else if (t_as(o1)) {                            // :96-107
                 v = (o1 == o2) ? v1 + v2 : v1 - v2;
                 if (v < 0) { o = (o1 == T_ADD) ? T_SUB : T_ADD; v = -v; }
                 noop = v == 0;
@@ -165,7 +185,7 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
             TW_SYNC();
             t_erase(P, qq, lane);
             if (noop) t_erase(P, pp, lane);
-            else if (lane == 0) P.at[pp] = ta_make((uint32_t)ta_src(a1), ta_des(a1), v, o);
+            else if (lane == 0) P.at[pp] = ta_make<RAT>((uint32_t)ta_src<RAT>(a1), ta_des<RAT>(a1), (uint32_t)v, o);
             TW_SYNC();
             return true;
         }
@@ -188,7 +208,7 @@ __device__ bool t_simplify(TrilProg &P, bool transposed, uint32_t lane) {
 // wave instructions whichever way it is organised (gather 270, lock-step walks 500, chain 340, permutation 225) and the kernel
 // is bound by instruction issue at 8 waves per SIMD: the couples were never the cost, the 71 fixpoint trips x 16 passes are.
 // Built with -DPLO_TRIL_PASSPUSH; the default is the literal form.
-__device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane, uint32_t *bm) {
+template <bool RAT> __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane, uint32_t *bm) {
     const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t i = 0; i < numout; ++i) {
         uint32_t pos = 0;
@@ -199,7 +219,7 @@ __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane, uin
             for (uint32_t b = pos & ~63u; b < n && cnt < 64u; b += 64u) {
                 const uint32_t k = b + lane;
                 uint64_t a = 0; bool is = false;
-                if (k < n && k >= pos) { a = P.at[k]; is = ta_ope(a) != T_BAR && ta_src(a) == (int)i; }
+                if (k < n && k >= pos) { a = P.at[k]; is = ta_ope<RAT>(a) != T_BAR && ta_src<RAT>(a) == (int)i; }
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(is);
                 if (!m) continue;
                 // lane (cnt + rank) takes the atom of the lane with that rank in m
@@ -216,10 +236,10 @@ __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane, uin
             const uint32_t ncand = cnt < 64u ? cnt : 64u;
             const bool have = lane < ncand;
             // 2. stoppers
-            const uint32_t fo = ta_ope(fa); const int fd = ta_des(fa); const bool fas = t_as(fo);
+            const uint32_t fo = ta_ope<RAT>(fa); const int fd = ta_des<RAT>(fa); const bool fas = t_as(fo);
             auto stops = [&](uint64_t a) -> bool {
-                const int sa = ta_src(a);
-                return fas ? (fd == sa || (sa == (int)i && (fd == ta_des(a) || t_md(ta_ope(a))))) : (ta_des(a) == (int)i || sa == (int)i);
+                const int sa = ta_src<RAT>(a);
+                return fas ? (fd == sa || (sa == (int)i && (fd == ta_des<RAT>(a) || t_md(ta_ope<RAT>(a))))) : (ta_des<RAT>(a) == (int)i || sa == (int)i);
             };
             uint32_t k = c + 1u, e = n; int res = have ? 0 : 2;               // 0 walking, 2 done (e = stopper or n)
             for (uint32_t step = 0; step < PLO_TRIL_LOCKSTEPS && __builtin_amdgcn_ballot_w64(res == 0); ++step) {
@@ -235,13 +255,13 @@ __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane, uin
                     const int L = __builtin_ctzll(und); und &= und - 1ull;
                     const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
                     const int bfd = __builtin_amdgcn_readlane(fd, L); const bool bfas = __builtin_amdgcn_readlane((int)fas, L) != 0;
-                    const uint32_t ee = t_find(P, bk, n, lane, [&](uint64_t a) { const int sa = ta_src(a);
-                        return bfas ? (bfd == sa || (sa == (int)i && (bfd == ta_des(a) || t_md(ta_ope(a))))) : (ta_des(a) == (int)i || sa == (int)i); });
+                    const uint32_t ee = t_find(P, bk, n, lane, [&](uint64_t a) { const int sa = ta_src<RAT>(a);
+                        return bfas ? (bfd == sa || (sa == (int)i && (bfd == ta_des<RAT>(a) || t_md(ta_ope<RAT>(a))))) : (ta_des<RAT>(a) == (int)i || sa == (int)i); });
                     if ((int)lane == L) { e = ee; res = 2; }
                 }
             }
             bool rot = false;
-            if (have && e < n) { const uint64_t ea = P.at[e]; rot = fas ? (!(fd == ta_src(ea)) && fd == ta_des(ea)) : (!(ta_des(ea) == (int)i) && t_md(ta_ope(ea))); }
+            if (have && e < n) { const uint64_t ea = P.at[e]; rot = fas ? (!(fd == ta_src<RAT>(ea)) && fd == ta_des<RAT>(ea)) : (!(ta_des<RAT>(ea) == (int)i) && t_md(ta_ope<RAT>(ea))); }
             // 3. the chain of couples
             unsigned long long sel = 0; uint32_t cur = 0, nextpos = n; bool passdone = false;
             for (;;) {
@@ -287,47 +307,53 @@ __device__ void t_pushvariables(TrilProg &P, uint32_t numout, uint32_t lane, uin
 }
 
 // the literal form: one (find, find, rotate) trip per couple
-__device__ void t_pushvariables_ref(TrilProg &P, uint32_t numout, uint32_t lane) {
+template <bool RAT> __device__ void t_pushvariables_ref(TrilProg &P, uint32_t numout, uint32_t lane) {
     for (uint32_t i = 0; i < numout; ++i) {
         uint32_t pos = 0;
         for (;;) {
             const uint32_t n = P.n;
-            const uint32_t f = t_find(P, pos, n, lane, [&](uint64_t a) { return ta_ope(a) != T_BAR && ta_src(a) == (int)i; });
+            const uint32_t f = t_find(P, pos, n, lane, [&](uint64_t a) { return ta_ope<RAT>(a) != T_BAR && ta_src<RAT>(a) == (int)i; });
             if (f >= n) break;
             const uint64_t fa = P.at[f];
-            const uint32_t fo = ta_ope(fa); const int fd = ta_des(fa);
+            const uint32_t fo = ta_ope<RAT>(fa); const int fd = ta_des<RAT>(fa);
             uint32_t e;
-            if (t_as(fo)) e = t_find(P, f + 1u, n, lane, [&](uint64_t a) { const int s = ta_src(a); return fd == s || (s == (int)i && (fd == ta_des(a) || t_md(ta_ope(a)))); });
-            else e = t_find(P, f + 1u, n, lane, [&](uint64_t a) { return ta_des(a) == (int)i || ta_src(a) == (int)i; });
+            if (t_as(fo)) e = t_find(P, f + 1u, n, lane, [&](uint64_t a) { const int s = ta_src<RAT>(a); return fd == s || (s == (int)i && (fd == ta_des<RAT>(a) || t_md(ta_ope<RAT>(a)))); });
+            else e = t_find(P, f + 1u, n, lane, [&](uint64_t a) { return ta_des<RAT>(a) == (int)i || ta_src<RAT>(a) == (int)i; });
             if (e >= n) { if (f + 1u != n) t_rotate(P, f, n, lane); break; }      // can be moved to the end (:381-391)
             const uint64_t ea = P.at[e];
             bool rot;
-            if (t_as(fo)) rot = !(fd == ta_src(ea)) && fd == ta_des(ea);
-            else rot = !(ta_des(ea) == (int)i) && t_md(ta_ope(ea));
+            if (t_as(fo)) rot = !(fd == ta_src<RAT>(ea)) && fd == ta_des<RAT>(ea);
+            else rot = !(ta_des<RAT>(ea) == (int)i) && t_md(ta_ope<RAT>(ea));
             if (rot && f + 1u != e) t_rotate(P, f, e, lane);
             pos = e + 1u;
         }
     }
 }
 
-// :400-502 for +-1 matrices without empty rows; perm/sign describe the candidate's rows
-__device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, bool transposed,
-                         bool oriented, uint32_t &rng, uint32_t lane, uint32_t ops[3], uint32_t cap, uint32_t *errw, uint32_t *bm) {
+// :400-502 for matrices without empty rows; perm/sign describe the candidate's rows.  RAT = false: entries +-1 (small signed values,
+// no scaling atom in the transposed program); RAT = true: entries are residues of rationals modulo `prime`.
+template <bool RAT> __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, bool transposed,
+                         bool oriented, uint32_t &rng, uint32_t lane, uint32_t ops[3], uint32_t cap, uint32_t *errw, uint32_t *bm, uint32_t prime) {
     P.n = 0;
     const unsigned long long tb0 = clock64(); (void)tb0;
     uint32_t preci = M.n;
+    const int ONE = 1, MONE = RAT ? (int)(prime - 1u) : -1;
     for (uint32_t l = 0; l < M.m; ++l) {
         const uint32_t r = perm[l], b = M.rp[r], len = (uint32_t)M.rp[r + 1u] - b;
         if (len == 0 || len > 64u) { if (lane == 0) atomicMax(errw, (uint32_t)TERR_ROW); return; }
         if (P.n + 2u * len + 2u > cap) { if (lane == 0) atomicMax(errw, (uint32_t)TERR_CAP); return; }
         const bool neg = (sgn[l] >> sbit) & 1u;
         int c = -1, v = 0;
-        if (lane < len) { c = M.col[b + lane]; v = M.val[b + lane]; if (neg) v = -v; }
+        if (lane < len) {
+            c = M.col[b + lane];
+            if constexpr (RAT) { const uint32_t x = M.valp[b + lane]; v = (int)(neg ? (x ? prime - x : 0u) : x); }
+            else { v = M.val[b + lane]; if (neg) v = -v; }
+        }
         uint32_t ai;
         if (!oriented) ai = t_rng(rng) % len;                                                          // :226-232
         else {                                                                                         // :179-216
             const unsigned long long mp = __builtin_amdgcn_ballot_w64(lane < len && (uint32_t)c == preci);
-            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lane < len && v == 1);
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lane < len && v == ONE);
             ai = mp ? (uint32_t)__builtin_ctzll(mp) : len;
             if (ai == len || !((m1 >> ai) & 1ull)) {
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(m1);
@@ -340,40 +366,41 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
             if (ai == len) ai = 0;
         }
         const int i = __builtin_amdgcn_readlane(c, (int)ai), av = __builtin_amdgcn_readlane(v, (int)ai);
-        const uint32_t scale = (!transposed && av != 1) ? 1u : 0u;                                      // transposed: only if not +-1
+        // scaling of the chosen variable (:416-424, :467-475): direct program: whenever the pivot is not 1; transposed: unless it is +-1
+        const uint32_t scale = transposed ? ((av != ONE && av != MONE) ? 1u : 0u) : (av != ONE ? 1u : 0u);
         const uint32_t base = P.n, bar = base + scale + (len - 1u);
         if (lane < len && lane != ai) {
             const uint32_t rk = lane - (lane > ai ? 1u : 0u);
             const uint32_t p1 = base + scale + rk, p2 = bar + 1u + rk;
-            if (transposed) {                                                                          // :424-427, :444-447
-                P.at[p1] = ta_make((uint32_t)c, i, v, av == -1 ? T_ADD : T_SUB);
-                P.at[p2] = ta_make((uint32_t)c, i, v, av == -1 ? T_SUB : T_ADD);
-            } else {                                                                                   // :428-431, :448-451
-                P.at[p1] = ta_make((uint32_t)i, c, v, T_ADD);
-                P.at[p2] = ta_make((uint32_t)i, c, v, T_SUB);
+            if (transposed) {                                                                          // :428-431, :448-451 (MONEOP: swapped when the pivot is -1)
+                P.at[p1] = ta_make<RAT>((uint32_t)c, i, (uint32_t)v, av == MONE ? T_ADD : T_SUB);
+                P.at[p2] = ta_make<RAT>((uint32_t)c, i, (uint32_t)v, av == MONE ? T_SUB : T_ADD);
+            } else {                                                                                   // :432-435, :452-455
+                P.at[p1] = ta_make<RAT>((uint32_t)i, c, (uint32_t)v, T_ADD);
+                P.at[p2] = ta_make<RAT>((uint32_t)i, c, (uint32_t)v, T_SUB);
             }
         }
         if (lane == ai) {
-            if (scale) P.at[base] = ta_make((uint32_t)i, -1, av, T_MUL);
-            P.at[bar] = ta_make((uint32_t)i, -1, av, T_BAR);
-            if (scale) P.at[bar + len] = ta_make((uint32_t)i, -1, av, T_DIV);
+            if (scale) P.at[base] = ta_make<RAT>((uint32_t)i, -1, (uint32_t)av, transposed ? T_DIV : T_MUL);
+            P.at[bar] = ta_make<RAT>((uint32_t)i, -1, (uint32_t)av, T_BAR);
+            if (scale) P.at[bar + len] = ta_make<RAT>((uint32_t)i, -1, (uint32_t)av, transposed ? T_MUL : T_DIV);
         }
         P.n = base + 2u * scale + 2u * (len - 1u) + 1u;
         if (len > 1u) preci = (uint32_t)i;
         TW_SYNC();
     }
-    // no '*1' atoms exist for +-1 inputs (:481-482); fixpoint :488-494
+    // no '*1' atoms exist (a scaling atom is only made for a pivot other than 1, :481-482); fixpoint :488-494
     TP_ADD(1, tb0);
     bool simp;
     do {
         unsigned long long t1 = clock64();
 #ifdef PLO_TRIL_PASSPUSH
-        if (transposed) t_pushvariables(P, M.n, lane, bm);
+        if (transposed) t_pushvariables<RAT>(P, M.n, lane, bm);
 #else
-        if (transposed) t_pushvariables_ref(P, M.n, lane);
+        if (transposed) t_pushvariables_ref<RAT>(P, M.n, lane);
 #endif
         TP_ADD(2, t1); t1 = clock64();
-        simp = t_simplify(P, transposed, lane);
+        simp = t_simplify<RAT>(P, transposed, lane, prime);
         TP_ADD(3, t1);
 #ifdef PLO_TRIL_PROFILE
         if (threadIdx.x == 0) g_tprof[4] += 1;
@@ -381,8 +408,8 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
     } while (simp);
     uint32_t a = 0, s = 0, mu = 0;                                                                    // :133-144
     for (uint32_t k = lane; k < P.n; k += 64u) {
-        const uint64_t at = P.at[k]; const uint32_t o = ta_ope(at); const int v = ta_val(at);
-        if (t_as(o)) { ++a; if (v != 1 && v != -1) ++s; }
+        const uint64_t at = P.at[k]; const uint32_t o = ta_ope<RAT>(at); const int v = ta_val<RAT>(at);
+        if (t_as(o)) { ++a; if (v != ONE && v != MONE) ++s; }
         if (t_md(o)) ++s;
         if (o == T_BAR) ++mu;
     }
@@ -395,7 +422,7 @@ __device__ void t_linear(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
 // i+1 -- and gives 2(len-1) atoms, the two barriers of one double-size AXPY, and 2(len-1) atoms again (one trip per pair
 // of expanded rows: see oracle/plo_tril_oracle.c).  a = +-1, so y = 1/a = a, z = -c and no scaling atom exists.  No random
 // draw: the first entry is the pivot.
-__device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, uint32_t lane,
+template <bool RAT> __device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, uint32_t lane,
                          uint32_t ops[3], uint32_t cap, uint32_t *errw, uint32_t *bm) {
     P.n = 0;
     for (uint32_t l = 0; l < M.m; ++l) {
@@ -413,36 +440,36 @@ __device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
         const uint32_t o2 = a == -1 ? T_SUB : T_ADD;           // MONEOP('+', a) (and MONEOP('+', y))
         if (lane >= 1u && lane < len) {
             if (has_c && lane == 1u) {
-                P.at[base + 1u] = ta_make((uint32_t)(c + 1), ci, v, o1);                               // :541-542 (the entry at i+1 only moves to i+2)
-                P.at[base2] = ta_make((uint32_t)(c + 1), ci, v, o2);                                   // :556-557
+                P.at[base + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o1);                               // :541-542 (the entry at i+1 only moves to i+2)
+                P.at[base2] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o2);                                   // :556-557
             } else {
                 const uint32_t off = 2u * lane - 2u, off2 = has_c ? 2u * lane - 3u : 2u * lane - 2u;
-                P.at[base + off] = ta_make((uint32_t)c, i, v, o1);                                     // :537-540
-                P.at[base + off + 1u] = ta_make((uint32_t)(c + 1), ci, v, o1);                         // :541-542
-                P.at[base2 + off2] = ta_make((uint32_t)c, i, v, o2);                                   // :552-555
-                P.at[base2 + off2 + 1u] = ta_make((uint32_t)(c + 1), ci, v, o2);                       // :556-557
+                P.at[base + off] = ta_make<RAT>((uint32_t)c, i, v, o1);                                     // :537-540
+                P.at[base + off + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o1);                         // :541-542
+                P.at[base2 + off2] = ta_make<RAT>((uint32_t)c, i, v, o2);                                   // :552-555
+                P.at[base2 + off2 + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o2);                       // :556-557
             }
         }
         if (lane == 0) {
             if (has_c) {
-                P.at[base] = ta_make((uint32_t)ci, i, -v1, o2);                                        // :532-533: z = -c
-                P.at[base2 + 2u * (len - 1u) - 1u] = ta_make((uint32_t)ci, i, v1, o2);                 // :563-564
+                P.at[base] = ta_make<RAT>((uint32_t)ci, i, -v1, o2);                                        // :532-533: z = -c
+                P.at[base2 + 2u * (len - 1u) - 1u] = ta_make<RAT>((uint32_t)ci, i, v1, o2);                 // :563-564
             }
-            P.at[bar] = ta_make((uint32_t)i, -1, a, T_BAR);                                            // :546-548
-            P.at[bar + 1u] = ta_make((uint32_t)ci, -1, a, T_BAR);
+            P.at[bar] = ta_make<RAT>((uint32_t)i, -1, a, T_BAR);                                            // :546-548
+            P.at[bar + 1u] = ta_make<RAT>((uint32_t)ci, -1, a, T_BAR);
         }
         P.n = base + 4u * (len - 1u) + 2u;
         TW_SYNC();
     }
     bool simp;
 #ifdef PLO_TRIL_PASSPUSH
-    do { t_pushvariables(P, M.n + 1u, lane, bm); simp = t_simplify(P, true, lane); } while (simp);
+    do { t_pushvariables<RAT>(P, M.n + 1u, lane, bm); simp = t_simplify<RAT>(P, true, lane, 0u); } while (simp);
 #else
-    do { t_pushvariables_ref(P, M.n + 1u, lane); simp = t_simplify(P, true, lane); } while (simp);
+    do { t_pushvariables_ref<RAT>(P, M.n + 1u, lane); simp = t_simplify<RAT>(P, true, lane, 0u); } while (simp);
 #endif
     uint32_t ad = 0, sc = 0, mu = 0;                                                                   // :133-144
     for (uint32_t k = lane; k < P.n; k += 64u) {
-        const uint64_t at = P.at[k]; const uint32_t o = ta_ope(at); const int v = ta_val(at);
+        const uint64_t at = P.at[k]; const uint32_t o = ta_ope<RAT>(at); const int v = ta_val<RAT>(at);
         if (t_as(o)) { ++ad; if (v != 1 && v != -1) ++sc; }
         if (t_md(o)) ++sc;
         if (o == T_BAR) ++mu;
@@ -451,7 +478,7 @@ __device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, co
     ops[0] = ad; ops[1] = sc; ops[2] = mu >> 1;                                                        // :799: a double-size AXPY holds two barriers
 }
 
-__global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
+template <bool RAT> __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tdyn[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -489,8 +516,9 @@ __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
             if (basec && variant == 1u) { tot[3] = tot[0]; tot[4] = tot[1]; tot[5] = tot[2]; break; }
             for (uint32_t w = 0; w < 3u; ++w) {
                 uint32_t o[3] = {0, 0, 0};
-                if (w == 2u && P.expanded) t_double(G, P.M[2], perm, sgn, 2u, lane, o, cap, J.err, bm);
-                else t_linear(G, P.M[w], perm, sgn, w, w == 2u, variant == 0u, rng, lane, o, cap, J.err, bm);
+                bool done_ = false;
+                if constexpr (!RAT) { if (w == 2u && P.expanded) { t_double<false>(G, P.M[2], perm, sgn, 2u, lane, o, cap, J.err, bm); done_ = true; } }
+                if (!done_) t_linear<RAT>(G, P.M[w], perm, sgn, w, w == 2u, variant == 0u, rng, lane, o, cap, J.err, bm, P.p);
                 tot[3u * variant] += o[0]; tot[3u * variant + 1u] += o[1]; tot[3u * variant + 2u] += o[2];
             }
             tot[3u * variant + 2u] /= 3u;                                                            // :801-803

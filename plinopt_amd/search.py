@@ -221,12 +221,21 @@ class TrilPlan:
             capi.check(L.plo_init(device))
         self._keep = []
         cs = []
-        for (n, rowptr, col, val) in mats:
-            a = ((ctypes.c_uint32 * len(rowptr))(*rowptr), (ctypes.c_uint32 * max(len(col), 1))(*col), (ctypes.c_int32 * max(len(val), 1))(*val))
+        rational = any(len(t) == 5 for t in mats)            # (n, rowptr, col, num, den): rational coefficients (plo_tril_plan_create_q)
+        for t in mats:
+            n, rowptr, col, val = t[:4]
+            if rational:
+                den = t[4] if len(t) == 5 else [1] * len(val)
+                a = ((ctypes.c_uint32 * len(rowptr))(*rowptr), (ctypes.c_uint32 * max(len(col), 1))(*col), (ctypes.c_int64 * max(len(val), 1))(*[int(x) for x in val]),
+                     (ctypes.c_int64 * max(len(den), 1))(*[int(x) for x in den]))
+                cs.append(capi.QCSR(m, n, a[0], a[1], a[2], a[3]))
+            else:
+                a = ((ctypes.c_uint32 * len(rowptr))(*rowptr), (ctypes.c_uint32 * max(len(col), 1))(*col), (ctypes.c_int32 * max(len(val), 1))(*val))
+                cs.append(capi.ICSR(m, n, a[0], a[1], a[2]))
             self._keep.append(a)
-            cs.append(capi.ICSR(m, n, a[0], a[1], a[2]))
         self._h = ctypes.c_void_p()
-        capi.check(L.plo_tril_plan_create_x(ctypes.byref(cs[0]), ctypes.byref(cs[1]), ctypes.byref(cs[2]), int(bool(expanded)), ctypes.byref(self._h)))
+        create = L.plo_tril_plan_create_q if rational else L.plo_tril_plan_create_x
+        capi.check(create(ctypes.byref(cs[0]), ctypes.byref(cs[1]), ctypes.byref(cs[2]), int(bool(expanded)), ctypes.byref(self._h)))
         self.last_stats = None
 
     def __del__(self):

@@ -56,10 +56,66 @@ def test_search_same_argmin(hip):
     assert G.search(0, 2000) == O.search(0, 2000)
 
 
-def test_non_unit_inputs_are_refused(hip):
+def all_triples():
+    out = []
+    for l in sorted(glob.glob(os.path.join(DATA, "*_L.sms"))):
+        r, p = l[:-6] + "_R.sms", l[:-6] + "_P.sms"
+        if not (os.path.exists(r) and os.path.exists(p)):
+            continue
+        try:
+            [read_sms(f) for f in (l, r, p)]
+        except ValueError:
+            continue
+        out.append(os.path.basename(l)[:-6])
+    return out
+
+
+ALL = all_triples()
+RATIONAL = [t for t in ALL if t not in UNIT]
+
+
+def test_every_fixture_triple_is_listed():
+    assert len(ALL) == 47 and len(RATIONAL) == 25
+
+
+@pytest.mark.parametrize("name", RATIONAL)
+def test_rational_fixtures_cost_many_bit_exact(hip, name):
+    """Round 3: the reference's matrices are rationals (Atom::_val is a Givaro::Rational, plinopt_inplace.inl:19); the device programs
+    carry the coefficients modulo a 31-bit prime (plo_tril_plan_create_q).  All six counts of every seed equal the oracle's, which
+    works over Q -- on each of the 25 {L,R,P} triples with coefficients other than +-1 (with the 22 unit ones: all 47)."""
+    from plinopt_amd import TrilPlan
+    O = OracleTril.from_sms(*(os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")))
+    G = TrilPlan(O.m, [(n, rp, col, [int(x) for x in num], [int(x) for x in den]) for n, (rp, col, num, den) in zip(O.dims, O.csr)])
+    n = 32 if O.m > 30 else 64
+    seeds = [TRIL_BASE_SEED, 0, 1, 2**40 + 7] + list(range(3000, 3000 + n))
+    assert G.cost_many(seeds=seeds) == O.cost_many(seeds=seeds)
+
+
+def test_rational_search_same_argmin(hip):
+    from plinopt_amd import TrilPlan
+    for name, n in (("4x4x4_48_rational", 300), ("2x2x2_7_DPS-accurate", 1500)):
+        O = OracleTril.from_sms(*(os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")))
+        G = TrilPlan(O.m, [(nn, rp, col, [int(x) for x in num], [int(x) for x in den]) for nn, (rp, col, num, den) in zip(O.dims, O.csr)])
+        assert G.search(100, n) == O.search(100, n)
+
+
+def test_integer_entries_through_the_integer_interface(hip):
+    """plo_tril_plan_create_x with entries 2 and 3: refused in rounds 1-2, now the rational instantiation (denominators 1)"""
+    from fractions import Fraction
+    from plinopt_amd import TrilPlan
+    A = [[1, 2], [1, 1]]; B = [[1, 1], [-1, 1]]; T = [[1, 1], [3, 1]]
+    dic = lambda M: {(i, j): Fraction(v) for i, r in enumerate(M) for j, v in enumerate(r) if v}
+    O = OracleTril((2, 2, dic(A)), (2, 2, dic(B)), (2, 2, {(j, i): v for (i, j), v in dic(T).items()}))
+    csr = lambda M: (2, [0, 2, 4], [0, 1, 0, 1], [v for r in M for v in r])
+    G = TrilPlan(2, [csr(A), csr(B), csr(T)])
+    seeds = [TRIL_BASE_SEED, 0, 1, 2, 3, 4, 5]
+    assert G.cost_many(seeds=seeds) == O.cost_many(seeds=seeds)
+
+
+def test_expanded_rational_inputs_are_refused(hip):
     from plinopt_amd import TrilPlan, capi
     with pytest.raises(capi.PloError) as e:
-        TrilPlan(2, [(2, [0, 1, 2], [0, 1], [1, 2]), (2, [0, 1, 2], [0, 1], [1, 1]), (2, [0, 1, 2], [0, 1], [1, 1])])
+        TrilPlan(2, [(2, [0, 1, 2], [0, 1], [1, 2]), (2, [0, 1, 2], [0, 1], [1, 1]), (2, [0, 1, 2], [0, 1], [1, 1])], expanded=True)
     assert e.value.code == capi.PLO_E_UNSUPPORTED
 
 
@@ -101,3 +157,20 @@ def test_expanded_search_same_argmin_and_cli(hip):
     assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
     assert "restarts on GPU" in g.stderr and g.stdout == h.stdout
     assert re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", g.stderr) == re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", h.stderr)
+
+
+@pytest.mark.parametrize("name,loops", [("4x4x4_48_rational", 600), ("2x2x2_7_DPS-accurate", 3000), ("2x2x2_7_DPS-intermediate-12.0695", 2000), ("3x3x6_40_DPS-accurate", 400)])
+def test_trilplacer_cli_runs_rational_inputs_on_the_gpu(hip, name, loops):
+    """bin/trilplacer on matrices with rational coefficients: the restart loop on the GPU (rounds 1-2: host loop), the winner replayed
+    over Q (128-bit rationals) and checked against the device's counts; same program and counts as the host loop."""
+    import re
+    import subprocess
+    from plo_testlib import ROOT
+    files = [os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")]
+    g = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-O", str(loops), "--seed", "41"] + files, capture_output=True, text=True, timeout=600)
+    h = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-O", str(loops), "--seed", "41", "--gpu", "0"] + files, capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
+    assert "restarts on GPU" in g.stderr and "restarts on host" in h.stderr
+    assert g.stdout == h.stdout
+    assert re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", g.stderr) == re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", h.stderr)
+
