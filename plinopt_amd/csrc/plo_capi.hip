@@ -373,8 +373,8 @@ int build_big_plan(plo_plan *pl)
         std::vector<uint32_t> rat(nv * nv);
         for (uint32_t i = 0; i < nv; ++i) for (uint32_t j = 0; j < nv; ++j) rat[i * nv + j] = (uint32_t)((uint64_t)vt[i].x * vt[j].y % p);
         std::vector<uint32_t> rv(rat); std::sort(rv.begin(), rv.end()); rv.erase(std::unique(rv.begin(), rv.end()), rv.end());
-        std::vector<uint16_t> rt(nv * nv), iv(rv.size());
-        for (uint32_t k = 0; k < nv * nv; ++k) rt[k] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), rat[k]) - rv.begin());
+        std::vector<uint16_t> rt(PLO_RSTRIDE * PLO_RSTRIDE, 0), iv(rv.size());     // identifiers at [i * 32 + j]
+        for (uint32_t i = 0; i < nv; ++i) for (uint32_t j = 0; j < nv; ++j) rt[i * PLO_RSTRIDE + j] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), rat[i * nv + j]) - rv.begin());
         for (size_t k = 0; k < rv.size(); ++k) iv[k] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), inv_mod(rv[k], p)) - rv.begin());   // the inverse of v_i/v_j is v_j/v_i: in the set
         if ((rc = upload(pl, rv, &B.rval)) || (rc = upload(pl, rt, &B.rtid)) || (rc = upload(pl, iv, &B.invid))) return rc;
         B.nr = (uint32_t)rv.size(); B.mode = 2u;
@@ -396,7 +396,7 @@ int build_big_plan(plo_plan *pl)
         B.o_pcount = take(4ull << B.pbits); B.o_ptail = take(4ull << B.pbits);
         B.o_log = take((uint64_t)B.logcap * 8); B.o_hot = take(8ull << B.hotbits_max);
     } else B.o_tab = take(cap * 8);
-    B.o_ent = take(((uint64_t)nnz + 64) * 4); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
+    B.o_ent = take(((uint64_t)nnz + 128) * 4); B.o_col = take((uint64_t)nnz * 4); B.o_val = take((uint64_t)nnz * 4); B.o_inv = take((uint64_t)nnz * 4);
     B.o_len = take((uint64_t)m * 4); B.o_ucount = take(NC * 4); B.o_cntM = take(NC * 4);
     B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 16); B.o_aff = take((uint64_t)m * 32);
     B.o_ncrptr = take((NC + 2) * 4); B.o_ncr = take(((uint64_t)nnz + 64) * 4);
@@ -414,7 +414,7 @@ int build_big_plan(plo_plan *pl)
     // dynamic LDS, in words: histogram, tables of the mode, then max(ProgramGen scratch, aggregation table: 2^aggbits entries of 8 bytes, 6 in mode 2)
     const uint32_t agg_words = B.mode == 2u ? (1u << B.aggbits) + (1u << B.aggbits) / 2u : 2u << B.aggbits;
     uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, agg_words);
-    uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + (B.nv * B.nv + 3u) / 4u * 2u + (B.nr + 3u) / 4u * 2u + (B.defer ? 0u : (1u << B.aggbits) / 2u) : 0u;   // mode 2: ratio values, ratio ids, inverse ids, slot list of the aggregation table (eager flush only)
+    uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + PLO_RSTRIDE * PLO_RSTRIDE / 2u + (B.nr + 3u) / 4u * 2u + (B.defer ? 0u : (1u << B.aggbits) / 2u) : 0u;   // mode 2: ratio values, ratio ids, inverse ids, slot list of the aggregation table (eager flush only)
     if (B.defer) { tab_words += PLO_DBLOOM_WORDS; scr_words = std::max<uint32_t>(scr_words, PLO_DMREG_WORDS - PLO_DBLOOM_WORDS); }   // Bloom filter, and 64 KB in all for the merge
     pl->big_lds = (((B.maxf0 + 2u) & ~1u) + tab_words + scr_words) * 4u;
     if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
@@ -489,7 +489,7 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
                 static const char *cls[4] = {">=256", "64..255", "16..63", "<16"};
                 for (int c_ = 0; c_ < 4; ++c_) { fprintf(stderr, "#   rows/step %-8s ms per candidate: level %.1f select %.1f rows %.1f sweep %.1f flush1 %.1f flush2 %.1f tail %.1f\n", cls[c_],
                     g2[c_ * 8 + 0] / 1e5 / g2[32], g2[c_ * 8 + 1] / 1e5 / g2[32], g2[c_ * 8 + 2] / 1e5 / g2[32], g2[c_ * 8 + 3] / 1e5 / g2[32], g2[c_ * 8 + 4] / 1e5 / g2[32], (g2[c_ * 8 + 6] + g2[c_ * 8 + 5]) / 1e5 / g2[32], g2[c_ * 8 + 7] / 1e5 / g2[32]); } } }
-            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[3]) fprintf(stderr, "#   sweep of the steps with >= 256 rows, all candidates: %llu trips by %llu wave-sweeps; cycles per trip: chunk wait + stores %.0f, aggregation of both chunks %.0f, rest of the loop %.0f; per wave-sweep %.0f cycles, %.1f trips\n", gp[3], gp[5], (double)gp[0] / gp[3], (double)gp[1] / gp[3], (double)gp[2] / gp[3], (double)gp[4] / gp[5], (double)gp[3] / gp[5]); }
+            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[3]) fprintf(stderr, "#   sweep of the steps with >= 256 rows, all candidates: %llu trips by %llu wave-sweeps; cycles per trip: chunk wait + stores %.0f, aggregation of both chunks %.0f, rest of the loop %.0f; per wave-sweep %.0f cycles, %.1f trips; probe rounds per trip %.2f, active lanes per trip %.1f\n", gp[3], gp[5], (double)gp[0] / gp[3], (double)gp[1] / gp[3], (double)gp[2] / gp[3], (double)gp[4] / gp[5], (double)gp[3] / gp[5], (double)gp[6] / gp[3], (double)gp[7] / gp[3]); }
             { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && (gp[14] || gp[15])) fprintf(stderr, "#   flush 1, all candidates: entries whose pair with a has a as SECOND column %llu, with b %llu\n", gp[14], gp[15]); }
             { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[11]) fprintf(stderr, "#   flush 1 of the steps with >= 256 rows: %llu wave-trips by %llu wave-flushes; cycles per trip: fetch + decode %.0f, probe loads %.0f, stores + bookkeeping %.0f; per wave-flush %.0f cycles, %.1f trips\n", gp[11], gp[13], (double)gp[8] / gp[11], (double)gp[9] / gp[11], (double)gp[10] / gp[11], (double)gp[12] / gp[13], (double)gp[11] / gp[13]); }
             fprintf(stderr, "#   steps by rows/step [>=256, 64.., 16.., <16]: %u %u %u %u; sweep1 us %u %u %u %u; sweep2 us %u %u %u %u; fallbacks %u %u; flushed keys %u %u\n",

@@ -69,7 +69,7 @@ struct BigPlan {
     uint64_t mu;
     uint32_t nv, vt_lds;                  // distinct values; their {value, inverse} table is staged in LDS when it has <= 512 entries
     uint32_t mode, nr;                    // kernel instance: 0 value table in global memory, 1 in LDS, 2 ratio identifiers (nv <= 32); nr = distinct ratios v_i/v_j
-    const uint16_t *rtid, *invid;         // mode 2: identifier of v_i/v_j at [i*nv+j]; identifier of the inverse ratio
+    const uint16_t *rtid, *invid;         // mode 2: identifier of v_i/v_j at [i*32+j] (PLO_RSTRIDE); identifier of the inverse ratio
     const uint32_t *rval;                 // mode 2: the ratio of an identifier
     const uint32_t *rs, *ent0, *tptr, *trows, *ucount0, *hist0;
     const uint2 *vt;                      // {value, inverse} per value index
@@ -353,6 +353,7 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_
 // (column << 10 | ratio identifier) in a u32 key array and a u16 count array -- 6 bytes per entry instead of 8, 32-bit
 // LDS operations, and no modular product in the sweep (the identifier comes from a 2-byte table lookup).
 #define PLO_RIDB 10u
+#define PLO_RSTRIDE 32u                    // row stride of the ratio-identifier table (at most 32 values): an index is a shift and an or
 struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint16_t *list; uint32_t *bloom; };   // bloom: DEFER, followed by the scratch region   // list: mode 2, one u16 per aggregation slot
 __device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *aggn, uint16_t *agglist, uint32_t listcap) {
     const uint32_t mask = (1u << aggbits) - 1u;
@@ -388,20 +389,20 @@ __device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, ui
 
 // The same probe loop for the staged sweep (mode 2 with deferred updates): a claimed slot sets its bit in a bitmap with a
 // fire-and-forget atomic -- no counter with a returned value, no slot list (two LDS round trips less on the claim path).
-__device__ __forceinline__ bool agg_add_rid_bm(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *bm) {
+__device__ __forceinline__ bool agg_add_rid_bm(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *bm, uint32_t *iters = nullptr) {
+    // aligned pairs of slots (one ds_read_b64, the two counts share a word); the hash is a 24-bit product (full rate)
     const uint32_t mask = (1u << aggbits) - 1u;
-    uint32_t s = (key * 0x9E3779B1u) >> (32u - aggbits);
+    uint32_t s = ((uint32_t)__umul24(key, 0x9E3779u) >> (32u - aggbits)) & ~1u;      // (__umul24 returns int: an arithmetic shift without the cast)
     for (uint32_t pr = 0; pr < PLO_AGG_PROBES;) {
-        const uint32_t s1 = (s + 1u) & mask;
-        const uint32_t k0 = __hip_atomic_load(&aggk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k1 = __hip_atomic_load(&aggk[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool hit0 = k0 == key, emp0 = k0 == 0xFFFFFFFFu, first = hit0 || emp0;
-        const bool hit = hit0 || (!emp0 && k1 == key), emp = emp0 || (!hit && k1 == 0xFFFFFFFFu);
-        const uint32_t t = first ? s : s1;
-        if (hit) { wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); return true; }
-        if (emp) {
+        if (iters) ++*iters;
+        const unsigned long long kk = __hip_atomic_load((unsigned long long *)(aggk + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t k0 = (uint32_t)kk, k1 = (uint32_t)(kk >> 32);
+        if (k0 == key || k1 == key) { wg_add(&aggc32[s >> 1], k0 == key ? 1u : 0x10000u); return true; }      // (an empty first slot rules the second one out)
+        if (k0 == 0xFFFFFFFFu || k1 == 0xFFFFFFFFu) {
+            const uint32_t sec = k0 == 0xFFFFFFFFu ? 0u : 1u, t = s + sec;
             const uint32_t old = wg_cas(&aggk[t], 0xFFFFFFFFu, key);
-            if (old == 0xFFFFFFFFu || old == key) { if (old != key) wg_or(&bm[t >> 5], 1u << (t & 31u)); wg_add(&aggc32[t >> 1], 1u << ((t & 1u) << 4)); return true; }
-            continue;
+            if (old == 0xFFFFFFFFu || old == key) { if (old != key) wg_or(&bm[t >> 5], 1u << (t & 31u)); wg_add(&aggc32[s >> 1], sec ? 0x10000u : 1u); return true; }
+            continue;                      // somebody took the slot for another key: look at both again
         }
         s = (s + 2u) & mask; pr += 2u;
     }
@@ -1034,8 +1035,8 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
             auto emit = [&](uint32_t i, uint32_t base, uint32_t L, uint32_t pa, uint32_t pb, uint32_t ea, uint32_t eb) {
                 uint32_t inv_r;
                 if constexpr (MODE == 2) {
-                    if (rval[rtid[PLO_EVI(eb) * nv + PLO_EVI(ea)]] != r) return;
-                    inv_r = rval[rtid[PLO_EVI(ea) * nv + PLO_EVI(eb)]];
+                    if (rval[rtid[PLO_EVI(eb) * PLO_RSTRIDE + PLO_EVI(ea)]] != r) return;
+                    inv_r = rval[rtid[PLO_EVI(ea) * PLO_RSTRIDE + PLO_EVI(eb)]];
                 } else {
                     const uint2 A = VT(PLO_EVI(ea)), B = VT(PLO_EVI(eb));
                     if (B.x != bmul(r, A.x, p, mu, mers)) return;
@@ -1048,7 +1049,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                 if constexpr (MODE == 2) {
                     // 16-byte record (value indices have 5 bits): positions, row start, length (<= 8192: 14 bits) | value index and +-1 flag of
                     // the a and b entries, row -- 32 bytes in round 2: 48 MB less written and read per candidate on config 5
-                    *(uint4 *)(aff + 4u * idx) = make_uint4(pa | (pb << 16), base, L | (PLO_EVI(ea) << 14) | (PLO_EUNIT(ea) << 19) | (PLO_EVI(eb) << 20) | (PLO_EUNIT(eb) << 25), i);
+                    *(uint4 *)(aff + 4u * idx) = make_uint4(pa | (pb << 16), base, L | (PLO_EUNIT(ea) << 14) | (PLO_EVI(ea) << 15) | (PLO_EUNIT(eb) << 20) | (PLO_EVI(eb) << 21), i);
                 } else {
                 uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each), row start and length; the two packed entries
                 *(uint4 *)rec = make_uint4(i, pa | (pb << 16), base, L);
@@ -1096,20 +1097,27 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
         // pair with a has ratio x, the pair with b has ratio r x (c < a), r/x (a < c < b) or x/r (b < c).  One LDS entry
         // per (c, x) therefore carries both retirements; the flush derives the two table keys.
         {
-            // ea_, eb_: the row's two removed entries (their value indices name v_a and v_b)
-            auto retire_entry = [&](uint32_t e, uint32_t ea_, uint32_t eb_, uint2 VA, uint2 VB) {
+            // via, vib: value indices of the row's two removed entries (they name v_a and v_b)
+#ifdef PLO_BIG_PROFILE
+            uint32_t probe_iters = 0;
+#endif
+            auto retire_entry = [&](uint32_t e, uint32_t via, uint32_t vib, uint2 VA, uint2 VB) {
                 const uint32_t c = PLO_ECOL(e);
                 // x = v_a/v_c (c < a) or v_c/v_a (c > a) names both retired pairs; y = v_a/v_c names the pair with the new column
                 // (x itself, or 1/x: kept beside x in the entry when the bits allow, so that the flush needs no inversion)
                 uint32_t x, y, q2, ins;                                        // q2: ratio of the pair with b; ins: ratio of the pair with the new column (both only on the fallback path)
                 if constexpr (MODE == 2) {
-                    const uint32_t vi = PLO_EVI(e), via = PLO_EVI(ea_);
-                    const uint32_t yid = rtid[via * nv + vi], xid = c < a ? yid : (uint32_t)rtid[vi * nv + via];
+                    const uint32_t vi = PLO_EVI(e);
+                    const uint32_t xid = rtid[c < a ? (via * PLO_RSTRIDE) | vi : (vi * PLO_RSTRIDE) | via];      // one lookup, no branch
+#ifdef PLO_BIG_PROFILE
+                    if constexpr (FAST) { if (agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm, &probe_iters)) return; }
+#else
                     if constexpr (FAST) { if (agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm)) return; }
+#endif
                     else if (agg_add_rid(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, &sh.aggn, agglist, listcap)) return;
-                    const uint32_t vib = PLO_EVI(eb_), bc = rval[rtid[vib * nv + vi]];                       // v_b / v_c
-                    x = rval[xid]; y = rval[yid];
-                    q2 = c < b ? bc : rval[rtid[vi * nv + vib]];
+                    const uint32_t bc = rval[rtid[vib * PLO_RSTRIDE + vi]];                                  // v_b / v_c
+                    x = rval[xid]; y = rval[rtid[via * PLO_RSTRIDE + vi]];
+                    q2 = c < b ? bc : rval[rtid[vi * PLO_RSTRIDE + vib]];
                     ins = l0 == a ? y : bc;
                 } else {
                     const uint2 V = VT(PLO_EVI(e));
@@ -1169,7 +1177,83 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
             // is loaded before the chunks before it are stored -- so no load sees a store.
             const uint32_t nrw = naff > wave ? (naff - wave + nwaves - 1u) / nwaves : 0u;      // rows of this wave: wave, wave + nwaves, ...
 #ifdef PLO_BIG_PROFILE
-            unsigned long long pw0 = 0, pw1 = 0, pw2 = 0, ptr = 0, tl_ = clock64(); const unsigned long long ts_ = tl_;
+            unsigned long long pw0 = 0, pw1 = 0, pw2 = 0, ptr = 0, pit = 0, pact = 0, tl_ = clock64(); const unsigned long long ts_ = tl_;
+#endif
+#ifndef PLO_BIG_ROWSWEEP
+            if constexpr (FAST) {
+            // Flat sweep (round 3): the entries of the wave's next 64 rows form ONE sequence and every trip takes its next 64
+            // entries, whatever rows they belong to -- lanes are full (two rows per trip, a 64-lane chunk each: 53 % on config 5),
+            // and what was wave-uniform per row (positions, length, value indices: scalar registers, spilled) is per lane.
+            // Row of a lane: the row ends inside a window of 2048 entries are marked in 32 LDS words of the wave, one per
+            // trip; a lane's row = rows that ended before the trip + marks at or below its lane (v_mbcnt); the row's record
+            // comes from the lane that loaded it (ds_bpermute).
+            // Stores of a trip reach back at most two positions and never into the next trip's entries (requested a trip
+            // earlier), so no load sees a store.
+            uint64_t *fm = sh.sel + 256u + 32u * wave;                  // (the bitmap of claimed slots takes at most the first 2 KB)
+            const uint32_t dump = P.nnz + 64u + lane;                   // (the entry array has 128 spare words)
+            const uint32_t selsh = l0 == a ? 14u : 20u;                 // the new column's entry carries the +-1 flag and the value index of the l0 entry
+            for (uint32_t k0 = 0; k0 < nrw; k0 += 64u) {
+                const bool have = k0 + lane < nrw;
+                const uint32_t qq = have ? wave + (k0 + lane) * nwaves : wave;
+                const uint4 R0 = *(const uint4 *)(aff + 4u * qq);
+                const uint32_t Lr = have ? (R0.z & 0x3FFFu) : 0u;
+                const uint32_t E = wave_incl_scan(Lr), S = E - Lr, T = RL(E, 63);
+                const uint32_t safe = RL(R0.y, 0);
+                uint32_t qlo = 0;
+                for (uint32_t w0 = 0; w0 < T; w0 += 2048u) {
+                    if (lane < 32u) __hip_atomic_store(&fm[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier();
+                    if (have && E >= w0 && E - w0 < 2048u) wg_or((unsigned long long *)&fm[(E - w0) >> 6], 1ull << (E & 63u));
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier();
+                    const uint64_t mreg = __hip_atomic_load(&fm[lane & 31u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t mrl = (uint32_t)mreg, mrh = (uint32_t)(mreg >> 32);
+                    const uint32_t ntw = ((T - w0 < 2048u ? T - w0 : 2048u) + 63u) >> 6;
+                    // Trip t_: the row of each lane (advances qlo), the row's record fetched from the lane that holds it -- four
+                    // ds_bpermute in flight together, one wait -- and the request for the entry.  A mark at bit i says "a row ended
+                    // before position i": rows ended at or below a lane = bit 0 + v_mbcnt of the mask shifted right by one.
+                    auto prep = [&](uint32_t t_, uint32_t &ad_, uint32_t &z_, uint32_t &pp_, uint32_t &rz_, uint32_t &e_) {
+                        const bool ok = t_ < ntw;                          // (the trip after the window's last one is requested nowhere and marks nothing)
+                        const uint32_t ml = ok ? RL(mrl, t_ & 31u) : 0u, mh = ok ? RL(mrh, t_ & 31u) : 0u;
+                        const uint32_t m1l = (ml >> 1) | (mh << 31), m1h = mh >> 1;
+                        const int qa = (int)((qlo + (ml & 1u) + __builtin_amdgcn_mbcnt_hi(m1h, __builtin_amdgcn_mbcnt_lo(m1l, 0u))) << 2);
+                        qlo += (uint32_t)__builtin_popcount(ml) + (uint32_t)__builtin_popcount(mh);
+                        const uint32_t rb_ = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)R0.y), S_ = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)S);
+                        pp_ = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)R0.x); rz_ = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)R0.z);
+                        const uint32_t f_ = w0 + (t_ << 6) + lane;
+                        z_ = f_ - S_; ad_ = rb_ + z_;
+                        e_ = ent[ok && f_ < T ? ad_ : safe];
+                    };
+                    uint32_t adc, zc, ppc, rzc, ec; prep(0u, adc, zc, ppc, rzc, ec);
+                    // (the wait counters of the loop header merge both incoming edges: with the first entry still in flight here every
+                    // trip would wait for all but one memory operation, i.e. for the stores of the trip before)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+                    for (uint32_t t = 0; t < ntw; ++t) {
+                        uint32_t adn, zn, ppn, rzn, en; prep(t + 1u, adn, zn, ppn, rzn, en);
+#ifdef PLO_BIG_PROFILE
+                        const unsigned long long t0_ = clock64();
+#endif
+                        const uint32_t pa = ppc & 0xFFFFu, pb = ppc >> 16;
+                        const bool in = w0 + (t << 6) + lane < T, act = in && zc != pa && zc != pb;
+                        // the row is rewritten in the same pass (:96-110): entries right of the first removed position shift left;
+                        // the new column's entry goes last (len and the +-1 counters were updated by the search).  Both stores are
+                        // UNCONDITIONAL (idle lanes write to a dump word behind the entries): behind a branch the compiler cannot
+                        // count them and waits for every store of the trip (vmcnt(0)) before it uses the entry requested a trip ahead.
+                        ent[act && zc > pa ? adc - 1u - (zc > pb ? 1u : 0u) : dump] = ec;
+                        ent[in && zc + 1u == (rzc & 0x3FFFu) ? adc - 1u : dump] = (((rzc >> selsh) & 63u) << 15) | lm;
+#ifdef PLO_BIG_PROFILE
+                        __builtin_amdgcn_wave_barrier(); const unsigned long long t1_ = clock64(); probe_iters = 0;
+#endif
+                        if (act) retire_entry(ec, (rzc >> 15) & 31u, (rzc >> 21) & 31u, make_uint2(0, 0), make_uint2(0, 0));
+#ifdef PLO_BIG_PROFILE
+                        {   __builtin_amdgcn_wave_barrier(); const unsigned long long t2_ = clock64(); pw0 += t1_ - t0_; pw1 += t2_ - t1_; pw2 += t0_ - tl_; tl_ = t2_; ++ptr;
+                            uint32_t mx = probe_iters; for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)mx, o); mx = u > mx ? u : mx; }
+                            pit += mx; pact += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act)); tl_ = clock64(); }
+#endif
+                        adc = adn; zc = zn; ppc = ppn; rzc = rzn; ec = en;
+                    }
+                }
+            }
+            } else
 #endif
             for (uint32_t k0 = 0; k0 < nrw; k0 += 64u) {
                 // two rows per trip; the first chunks of the next pair are requested before the current pair is worked on
@@ -1179,7 +1263,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                 if constexpr (MODE == 2) {
                     const uint4 R0 = *(const uint4 *)(aff + 4u * qq);
                     Rpp = R0.x; Rbase = R0.y; RL_ = have ? (R0.z & 0x3FFFu) : 0u;
-                    Rea = (((R0.z >> 14) & 31u) << 16) | (((R0.z >> 19) & 1u) << 15); Reb = (((R0.z >> 20) & 31u) << 16) | (((R0.z >> 25) & 1u) << 15);   // value index and +-1 flag: all the sweep needs of the two entries
+                    Rea = ((R0.z >> 14) & 63u) << 15; Reb = ((R0.z >> 20) & 63u) << 15;   // value index and +-1 flag: all the sweep needs of the two entries
                 } else {
                     const uint4 R0 = *(const uint4 *)(aff + 8u * qq); const uint2 R1 = *(const uint2 *)(aff + 8u * qq + 4u);
                     Rpp = R0.y; Rbase = R0.z; RL_ = have ? R0.w : 0u; Rea = R1.x; Reb = R1.y;
@@ -1216,8 +1300,8 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
 #ifdef PLO_BIG_PROFILE
                         const unsigned long long t1_ = clock64();
 #endif
-                        if (actA) retire_entry(eA, eaA, ebA, VaA, VbA);
-                        if (actB) retire_entry(eB, eaB, ebB, VaB, VbB);
+                        if (actA) retire_entry(eA, PLO_EVI(eaA), PLO_EVI(ebA), VaA, VbA);
+                        if (actB) retire_entry(eB, PLO_EVI(eaB), PLO_EVI(ebB), VaB, VbB);
                         __builtin_amdgcn_wave_barrier();
 #ifdef PLO_BIG_PROFILE
                         { const unsigned long long t2_ = clock64(); pw0 += t1_ - t0_; pw1 += t2_ - t1_; pw2 += t0_ - tl_; tl_ = t2_; ++ptr; }
@@ -1232,7 +1316,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                 }
             }
 #ifdef PLO_BIG_PROFILE
-            if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[0], pw0); atomicAdd(&sh.pw[1], pw1); atomicAdd(&sh.pw[2], pw2); atomicAdd(&sh.pw[3], ptr); atomicAdd(&sh.pw[4], clock64() - ts_); atomicAdd(&sh.pw[5], 1ull); }
+            if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[0], pw0); atomicAdd(&sh.pw[1], pw1); atomicAdd(&sh.pw[2], pw2); atomicAdd(&sh.pw[3], ptr); atomicAdd(&sh.pw[4], clock64() - ts_); atomicAdd(&sh.pw[5], 1ull); atomicAdd(&sh.pw[6], pit); atomicAdd(&sh.pw[7], pact); }
 #endif
         }
 #undef RL
@@ -1803,10 +1887,10 @@ template <int MODE, bool DEFER> __global__ __launch_bounds__(PLO_BIG_THREADS, 4)
     }
     if constexpr (MODE == 2) {                                     // ratio identifiers, ratios, inverse identifiers
         uint32_t *rv = nextw; nextw += (P.nr + 1u) & ~1u;
-        uint16_t *rt = (uint16_t *)nextw; nextw += (P.nv * P.nv + 3u) / 4u * 2u;
+        uint16_t *rt = (uint16_t *)nextw; nextw += PLO_RSTRIDE * PLO_RSTRIDE / 2u;
         uint16_t *iv = (uint16_t *)nextw; nextw += (P.nr + 3u) / 4u * 2u;
         for (uint32_t k = threadIdx.x; k < P.nr; k += blockDim.x) { rv[k] = P.rval[k]; iv[k] = P.invid[k]; }
-        for (uint32_t k = threadIdx.x; k < P.nv * P.nv; k += blockDim.x) rt[k] = P.rtid[k];
+        for (uint32_t k = threadIdx.x; k < PLO_RSTRIDE * PLO_RSTRIDE; k += blockDim.x) rt[k] = P.rtid[k];
         TB.rval = rv; TB.rtid = rt; TB.invid = iv;
         if constexpr (!DEFER) { TB.list = (uint16_t *)nextw; nextw += (1u << P.aggbits) / 2u; }
     }
