@@ -316,8 +316,8 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
         if (verbose > 0) std::clog << "# " << g_kshard.shards << " shards (one GPU each): -K" << std::endl;
     }
     // All of it on the device (plo_kernel_search: the wave of a restart eliminates, builds both images and runs both
-    // Optimizer calls): matrices of at most 64 x 64.  --host-decomp keeps the decompositions on the host (round-1 path).
-    if constexpr (std::is_same<F, ZpField>::value) if (!have && use_gpu && L.kernel_search && !g_host_decomp && lM.rowdim() <= 64 && lM.coldim() <= 64) {
+    // Optimizer calls): matrices of at most 128 rows and 64 columns with at most 64 dependent rows.  --host-decomp keeps the decompositions on the host (round-1 path).
+    if constexpr (std::is_same<F, ZpField>::value) if (!have && use_gpu && L.kernel_search && !g_host_decomp && lM.rowdim() <= 128 && lM.coldim() <= 64) {
         KernelDecomp<F> kd0;
         if (!kernel_decomp(f, lM, seed0, kd0)) { std::clog << "# \033[1;36mZero dimensional kernel.\033[0m" << std::endl; return false; }   // :1343-1346 (the rank does not depend on the order)
         std::vector<uint32_t> rp, cc, vv; to_csr(lM, rp, cc, vv);
@@ -600,7 +600,7 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         if (verbose > 0) std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one GPU each)") << ": " << total << " candidates, slowest kernel " << kmax << " ms" << std::endl;
     }
     // the same for -K (decompositions on the device, one per restart): N shards of the restart range
-    if constexpr (std::is_same<F, ZpField>::value) if (tryKernel && !kfi && q != 0 && gpu >= 2 && loops > 0 && !g_host_decomp && g_kernel_block == 1 && lM.rowdim() <= 64 && lM.coldim() <= 64) {
+    if constexpr (std::is_same<F, ZpField>::value) if (tryKernel && !kfi && q != 0 && gpu >= 2 && loops > 0 && !g_host_decomp && g_kernel_block == 1 && lM.rowdim() <= 128 && lM.coldim() <= 64) {
         KernelDecomp<F> kd0;
         if (kernel_decomp(f, lM, seed0, kd0)) {                                       // (a zero dimensional kernel is reported by kernel_method)
             std::vector<uint32_t> rp, cc, vv; to_csr(lM, rp, cc, vv);

@@ -1138,13 +1138,14 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
     if (g_device < 0) return fail(PLO_E_HIP, "plo_init not called");
     if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
     if (const char *bad = csr_defect(M, p)) return fail(PLO_E_ARG, bad);
-    if (M->m == 0 || M->m > 64 || M->n == 0 || M->n > 64) return fail(PLO_E_UNSUPPORTED, "device decomposition needs at most 64 rows and 64 columns");
+    if (M->m == 0 || M->m > 128 || M->n == 0 || M->n > 64) return fail(PLO_E_UNSUPPORTED, "device decomposition needs at most 128 rows and 64 columns");
     if (nrestarts > 0xFFFFFFFFull) return fail(PLO_E_ARG, "at most 2^32-1 restarts per call");
     plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
     const auto t0 = std::chrono::steady_clock::now();
     if (best) { best->adds = best->muls = 0xFFFFFFFFu; best->seed = ~0ull; }
     const uint32_t m = M->m, n = M->n, R = rank_mod_p(M, p), ndeps = m - R;
     if (ndeps == 0) return fail(PLO_E_UNSUPPORTED, "zero dimensional kernel");
+    if (ndeps > 64) return fail(PLO_E_UNSUPPORTED, "more than 64 dependent rows: Dep's ProgramGen keeps one row per lane");
     if (R == 0) return fail(PLO_E_UNSUPPORTED, "zero matrix");
 
     uint8_t *d_img = nullptr; uint64_t *d_rsD = nullptr; uint32_t *d_adds = nullptr, *d_muls = nullptr, *d_info = nullptr, *d_err = nullptr, *d_sz = nullptr; unsigned long long *d_best = nullptr;
@@ -1171,8 +1172,8 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         uint32_t off = 0;
         K.off_depc = off;  off += ndeps * R * 4u;
         K.off_vrow = off;  off += 64u * 4u;
-        K.off_ord = off;   off += 64u * 2u;
-        K.off_piv = off;   off += 64u * 2u;
+        K.off_ord = off;   off += 128u * 2u;
+        K.off_piv = off;   off += 128u * 2u;
         K.off_basis = off; off += 64u * 2u;
         K.off_deps = off;  off += 64u * 2u;
         K.scratch_bytes = round_up(off, 16);

@@ -19,7 +19,10 @@
 //      the same region (rows = kept dependent rows, columns = rows of M, the
 //      combination over the basis rows; inverses by Fermat, pair table by
 //      tab_inc), Optimizer on Dep with the stream where the first call left it.
-// Needs m, n <= 64 (a row and a combination fit one register per lane); the
+// Needs n <= 64 (a row and a combination fit one register per lane), m <= 128
+// (a lane eliminates rows lane and lane + 64: `-F` on 4x4x4, [M;I] = 65 rows,
+// and the 84-row P matrices of the 3x4x7 family stay here) and at most 64
+// dependent rows (Dep keeps one row per lane in ProgramGen); the
 // sizes of Dep's image are bounded from rank(M) by the host, its pair table by a
 // sizing launch (kmethod_size_kernel); a full table is reported (ERR_TABLE) and
 // the launch repeated with a larger one, as for the other wave-kernel plans.
@@ -85,20 +88,24 @@ __device__ uint32_t kmethod_decompose(const KPlan &K, uint8_t *reg, const KScrat
     const uint32_t sv = n + 1u, sc = R + 1u;
     uint32_t *V = (uint32_t *)(reg + K.off_vc), *C = V + m * sv;
     uint32_t rng = 1u + (uint32_t)(splitmix64(dseed) % 2147483646ull);
-    if (lane < m) S.ord[lane] = (uint16_t)lane;
+    for (uint32_t row = lane; row < m; row += 64u) S.ord[row] = (uint16_t)row;
     PLO_WAVE_SYNC();
     if (lane == 0) for (uint32_t i = m; i > 1u; --i) { const uint32_t j = rng_next(rng) % i; const uint16_t t = S.ord[i - 1u]; S.ord[i - 1u] = S.ord[j]; S.ord[j] = t; }
     rng = uni32(rng);
     PLO_WAVE_SYNC();
-    uint32_t mypos = 0xFFFFFFFFu;                                            // place of this lane's row in the order
-    if (lane < m) S.piv[S.ord[lane]] = (uint16_t)lane;                       // (piv doubles as the inverse permutation)
+    uint32_t mypos[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};                          // place of this lane's rows (lane, lane + 64) in the order
+    for (uint32_t q = lane; q < m; q += 64u) S.piv[S.ord[q]] = (uint16_t)q;  // (piv doubles as the inverse permutation)
     PLO_WAVE_SYNC();
-    if (lane < m) {
-        mypos = S.piv[lane];
-        for (uint32_t j = 0; j < n; ++j) V[lane * sv + j] = 0u;
-        for (uint32_t j = 0; j < R; ++j) C[lane * sc + j] = 0u;
-        const uint32_t base = rsM[lane], ln = lenM[lane];
-        for (uint32_t z = 0; z < ln; ++z) V[lane * sv + colM[base + z]] = valM[base + z];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t row = lane + 64u * (uint32_t)h;
+        if (row < m) {
+            mypos[h] = S.piv[row];
+            for (uint32_t j = 0; j < n; ++j) V[row * sv + j] = 0u;
+            for (uint32_t j = 0; j < R; ++j) C[row * sc + j] = 0u;
+            const uint32_t base = rsM[row], ln = lenM[row];
+            for (uint32_t z = 0; z < ln; ++z) V[row * sv + colM[base + z]] = valM[base + z];
+        }
     }
     PLO_WAVE_SYNC();
     uint32_t nb = 0, nd = 0;
@@ -120,16 +127,20 @@ __device__ uint32_t kmethod_decompose(const KPlan &K, uint8_t *reg, const KScrat
         else if (lane == nb) C[L * sc + lane] = iv;
         if (lane == 0) S.basis[nb] = (uint16_t)L;
         PLO_WAVE_SYNC();
-        if (lane < m && mypos > t) {                                         // rows still to come
-            const uint32_t x = V[lane * sv + pc];
-            if (x) {
-                for (uint32_t j = 0; j < n; ++j) {
-                    const uint32_t e = V[L * sv + j];
-                    if (e) { const uint32_t xe = kmul(x, e, p, mu, mers), w = V[lane * sv + j]; V[lane * sv + j] = w >= xe ? w - xe : w + p - xe; }
-                }
-                for (uint32_t j = 0; j <= nb; ++j) {
-                    const uint32_t cb = C[L * sc + j];
-                    if (cb) { uint32_t w = C[lane * sc + j] + kmul(x, cb, p, mu, mers); w -= w >= p ? p : 0u; C[lane * sc + j] = w; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t row = lane + 64u * (uint32_t)h;
+            if (row < m && mypos[h] > t) {                                   // rows still to come
+                const uint32_t x = V[row * sv + pc];
+                if (x) {
+                    for (uint32_t j = 0; j < n; ++j) {
+                        const uint32_t e = V[L * sv + j];
+                        if (e) { const uint32_t xe = kmul(x, e, p, mu, mers), w = V[row * sv + j]; V[row * sv + j] = w >= xe ? w - xe : w + p - xe; }
+                    }
+                    for (uint32_t j = 0; j <= nb; ++j) {
+                        const uint32_t cb = C[L * sc + j];
+                        if (cb) { uint32_t w = C[row * sc + j] + kmul(x, cb, p, mu, mers); w -= w >= p ? p : 0u; C[row * sc + j] = w; }
+                    }
                 }
             }
         }
@@ -146,18 +157,10 @@ __device__ uint32_t kmethod_decompose(const KPlan &K, uint8_t *reg, const KScrat
     return nd - ni;
 }
 
-// row j of Dep as (column = row of M, value), columns increasing: returns the length; lane c < m gets has/pos/value
-__device__ __forceinline__ uint32_t kmethod_dep_row(const KPlan &K, const KScratch &S, uint32_t j, uint32_t lane, bool &has, uint32_t &pos, uint32_t &x) {
+// length of row j of Dep (its non-zero coefficients over the basis rows)
+__device__ __forceinline__ uint32_t kmethod_dep_row(const KPlan &K, const KScratch &S, uint32_t j, uint32_t lane) {
     const uint32_t R = K.rank;
-    S.vrow[lane] = 0u;
-    PLO_WAVE_SYNC();
-    if (lane < R) { const uint32_t c = S.depc[j * R + lane]; if (c) S.vrow[S.basis[lane]] = c; }
-    PLO_WAVE_SYNC();
-    x = S.vrow[lane]; has = x != 0u;
-    const uint64_t mk = __ballot(has);
-    pos = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
-    PLO_WAVE_SYNC();
-    return (uint32_t)__popcll(mk);
+    return (uint32_t)__popcll(__ballot(lane < R && S.depc[j * R + lane] != 0u));
 }
 
 // One restart.  Returns adds<<32 | muls of the two programs together.
@@ -183,7 +186,7 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
         uint64_t *tab = (uint64_t *)(reg + PM.off_tab), *cmask = (uint64_t *)(reg + PM.off_cmask), *umask = (uint64_t *)(reg + PM.off_umask);
         uint32_t *val = (uint32_t *)(reg + PM.off_val), *inv = (uint32_t *)(reg + PM.off_inv);
         uint16_t *col = (uint16_t *)(reg + PM.off_col), *len = (uint16_t *)(reg + PM.off_len);
-        const uint32_t abs_ = PM.rb + PM.bb, rb = PM.rb;
+        const uint32_t abs_ = PM.rb + PM.bb, rb = PM.rb, msM = 2u * PM.mw;      // masks: {cmask[mw], umask[mw]} per column
         // G rows per trip (lane groups of LPR lanes, as in the sweeps of the wave kernel): lane t of a group retires the pairs its
         // entry forms with every earlier entry of the row, and clears its column's mask bits
         const uint32_t LPR = 1u << PM.lpr_log2, G = 64u >> PM.lpr_log2, g = lane >> PM.lpr_log2, t = lane & (LPR - 1u);
@@ -198,7 +201,7 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
                     bad |= !tab_dec(tab, ((uint64_t)col[base + x] << abs_) | ((uint64_t)cy << rb) | r, PM.cap, PM.hbits);
                 }
             }
-            if (have) { atomicAnd((unsigned long long *)&cmask[cy * 2u], ~(1ull << i)); atomicAnd((unsigned long long *)&umask[cy * 2u], ~(1ull << i)); }
+            if (have) { atomicAnd((unsigned long long *)&cmask[cy * msM + (i >> 6)], ~(1ull << (i & 63u))); atomicAnd((unsigned long long *)&umask[cy * msM + (i >> 6)], ~(1ull << (i & 63u))); }
             PLO_WAVE_SYNC();
             if (act && t == 0u) len[i] = 0;
         }
@@ -216,7 +219,7 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
         uint16_t *col = (uint16_t *)(reg + PD.off_col), *len = (uint16_t *)(reg + PD.off_len);
         const uint32_t abs_ = PD.rb + PD.bb, rb = PD.rb;
         for (uint32_t s = lane; s < PD.cap; s += 64u) tab[s] = PLO_EMPTY;
-        if (lane < m) { cmask[lane * 2u] = 0ull; umask[lane * 2u] = 0ull; }
+        for (uint32_t c = lane; c < m; c += 64u) { cmask[c * 2u] = 0ull; umask[c * 2u] = 0ull; }      // (Dep has at most 64 rows: one mask word)
         if (lane < PD.m) len[lane] = 0;
         PLO_WAVE_SYNC();
         // Rows of Dep, G at a time (groups of LPR >= rank lanes).  The columns of Dep are the basis rows of M: lane s of a group
@@ -345,8 +348,7 @@ __global__ __launch_bounds__(256) void kmethod_size_kernel(KPlan K, WaveJob J, u
         if (kept == 0u) { if (lane == 0) atomicMax(&sz[2], 1u); continue; }
         uint32_t pairs = 0, ent = 0;
         for (uint32_t j = 0; j < kept; ++j) {
-            bool has; uint32_t pos, x;
-            const uint32_t ln = kmethod_dep_row(K, S, j, lane, has, pos, x);
+            const uint32_t ln = kmethod_dep_row(K, S, j, lane);
             pairs += ln * (ln - (ln ? 1u : 0u)) / 2u; ent += ln;
         }
         if (lane == 0) { atomicMax(&sz[0], pairs); atomicMax(&sz[1], ent); }

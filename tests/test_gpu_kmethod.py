@@ -15,7 +15,15 @@ NAMES = ["4x4x4_49_156_L.sms", "4x4x4_49_156_R.sms", "4x4x4_49_156_P.sms", "3x3x
 
 
 def usable(M):
-    return M.m <= 64 and M.n <= 64 and M.kernel_restart(1) is not None
+    return M.m <= 128 and M.n <= 64 and M.m - M.n <= 64 and M.kernel_restart(1) is not None
+
+
+def with_identity(M):
+    """[M ; I]: what `-F` hands to the kernel method (reference include/plinopt_optimize.inl:640-648, the identity added to the goals)"""
+    rp, c, v = list(M.rowptr), list(M.col), list(M.val)
+    for j in range(M.n):
+        c.append(j); v.append(1); rp.append(len(c))
+    return OracleMatrix(M.m + M.n, M.n, rp, c, v, M.p)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -23,7 +31,7 @@ def test_every_restart_equals_the_oracle(hip, name):
     from plinopt_amd import kernel_search
     M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
     if not usable(M):
-        pytest.skip("more than 64 rows/columns or zero dimensional kernel")
+        pytest.skip("more than 128 rows / 64 columns / 64 dependent rows, or zero dimensional kernel")
     n, seed0 = 200, 5
     adds, muls, info, best, st = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n)
     exp = [M.kernel_restart(seed0 + k) for k in range(n)]
@@ -31,6 +39,26 @@ def test_every_restart_equals_the_oracle(hip, name):
     k = min(range(n), key=lambda k: (exp[k][0] + exp[k][1], exp[k][0], k))
     assert best == (exp[k][0], exp[k][1], seed0 + k)
     assert st["launches"] >= 2 and st["candidates"] == n          # the sizing launch + the search
+
+
+@pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "4x4x4_49_156_R.sms", "4x4x4_49_156_P.sms", "3x3x6_40_L.sms", "3x3x3_23_58_P.sms", "4x4x4_48_rational_L.sms"])
+def test_more_than_64_rows(hip, name):
+    """`-F` on 4x4x4: [M ; I] has 65 rows (49 dependent ones on the L side, 16 on the P side) -- a lane of the wave eliminates rows
+    lane and lane + 64, the column masks of Free have two words.  Every restart equals the oracle's."""
+    from plinopt_amd import capi, kernel_search
+    M = with_identity(OracleMatrix.from_sms(os.path.join(DATA, name), P))
+    n, seed0 = 120, 9
+    exp = [M.kernel_restart(seed0 + k) for k in range(n)]
+    unit = all(x in (1, P - 1) for x in M.val)
+    if M.m > 64 and not unit:                                 # non +-1 coefficients with more than 64 rows: ProgramGen of the wave kernel keeps one row per lane
+        with pytest.raises(capi.PloError) as e:
+            kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n)
+        assert e.value.code in (capi.PLO_E_CAPACITY, capi.PLO_E_UNSUPPORTED)
+        return
+    adds, muls, info, best, st = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n)
+    assert [(a, mu) + i for a, mu, i in zip(adds, muls, info)] == exp
+    k = min(range(n), key=lambda k: (exp[k][0] + exp[k][1], exp[k][0], k))
+    assert best == (exp[k][0], exp[k][1], seed0 + k)
 
 
 def test_blocks_of_restarts_share_a_decomposition(hip):
@@ -72,7 +100,7 @@ def test_other_moduli(hip, name, prime):
     mu = floor(2^64 / p); matrices with rational coefficients (entries vanish or collide modulo small primes)"""
     from plinopt_amd import kernel_search
     M = OracleMatrix.from_sms(os.path.join(DATA, name), prime)
-    if M.m > 64 or M.n > 64 or M.kernel_restart(1) is None:
+    if not usable(M):
         pytest.skip("shape or zero dimensional kernel modulo %d" % prime)
     n, seed0 = 60, 77
     from plinopt_amd import capi
