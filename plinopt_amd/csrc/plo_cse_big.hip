@@ -423,7 +423,6 @@ __device__ __forceinline__ int row_find(const uint32_t *ent, uint32_t base, uint
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r, aggn, nspill; uint64_t kprime; uint64_t selkey;
-    uint32_t sb, sl0;              // the step's second column and the column whose entry the new column takes (for the out-of-line paths)
     uint32_t nbisect, spilltot, listover;   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
     uint32_t logn, hotn, hotbits, nforced, hotops, logtot_lo, logtot_hi;   // DEFER: log fill, claimed hot slots, hot table size; diagnostics: merges forced by log/hot pressure, updates served by the hot table, log entries written
     uint32_t derr; unsigned long long tmg[4], tmb[4]; uint32_t ngrp; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
@@ -1019,7 +1018,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
         // ---- RemOneCSE :60-194
         const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
-        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; sh.sb = b; sh.sl0 = l0; }
+        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; }      // (nothing here uses `swap`: the two counts stay in flight while the row lists are walked)
         if constexpr (FAST) { for (uint32_t w = tid; w < ((1u << aggbits) + 31u) / 32u; w += nth) aggbm[w] = 0u; }      // (the tie pick used the buffer)
         BSYNC();
 #define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
