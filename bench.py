@@ -283,14 +283,14 @@ def bench_cob(args):
                 aw[tag + "_wall_s"] = best
                 g = _re.search(r"with (\d+) non-zeroes", r.stderr)
                 aw[tag + "_nnz_residue"] = int(g.group(1)) if g else None
-                g = _re.search(r"# GPU \(Q[^)]*\): (\d+) enumerations, kernels ([0-9.e+-]+) ms", r.stderr)
+                g = _re.search(r"# GPU \(Q[^)]*\): (\d+) enumerations in (\d+) launches[^,]*, kernels ([0-9.e+-]+) ms", r.stderr)
                 if g:
-                    aw["gpu_enumerations"] = int(g.group(1)); aw["gpu_kernel_ms"] = float(g.group(2))
+                    aw["gpu_enumerations"] = int(g.group(1)); aw["gpu_launches"] = int(g.group(2)); aw["gpu_kernel_ms"] = float(g.group(3))
                 g = _re.search(r"# CoB enumeration: (\d+) candidate rows", r.stderr)
                 if g:
                     aw["candidate_rows"] = int(g.group(1))
             aw["note"] = ("256 candidate rows per enumeration: the command is bound by process start, HIP initialisation and one launch + copy per "
-                          "enumeration and prime, not by the enumeration; the GPU pays from about 12 coefficients (2e4 rows per enumeration) on -- the "
+                          "enumeration (both primes in one launch, plo_cob_search_batch), not by the enumeration; the GPU pays from about 12 coefficients (2e4 rows per enumeration) on -- the "
                           "headline figure above is `-c 56` (9.8e6 rows per enumeration)")
         except Exception as e:       # the tools are built by __graft_entry__.build(); a missing binary only drops this block
             aw["error"] = str(e)

@@ -172,6 +172,17 @@ int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint3
                          const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
                          uint64_t first_group, uint64_t ngroups, plo_cob_best_t *out, plo_stats_t *stats);
 
+/* Up to 4 enumerations of the same shape (n, m, row, offsetblock) in ONE launch -- one upload, one kernel, one download: the two
+ * primes of an enumeration over the rationals (bin/sparsifier without -q calls localSparsifier :282-314 once over Q; this build
+ * enumerates modulo two primes and checks the winners over Q), or the shards of one enumeration.  out[k] as plo_cob_search. */
+typedef struct {
+    const uint32_t *TM, *Cand, *coeffs;   /* residues modulo p, as for plo_cob_search */
+    uint32_t ncoeffs, p;
+    int32_t  w0, w1;
+} plo_cob_problem_t;
+int plo_cob_search_batch(uint32_t nprob, uint32_t n, uint32_t m, uint32_t row, uint32_t offsetblock,
+                         const plo_cob_problem_t *prob, plo_cob_best_t *out, plo_stats_t *stats);
+
 /* ---- -E, the exhaustive CSE tree: RecSub / RecOptimizer (include/plinopt_optimize.inl:889-1013, called by AllCSEOpt
  * :1252-1281) explore every schedule of pairs of frequency > 1 (not only the maximal ones).  Here a schedule is a
  * candidate addressed by an index in the mixed radix of its own path: at every step the children (distinct triples of

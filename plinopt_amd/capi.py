@@ -22,7 +22,7 @@ EXPORTS = [
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch", "plo_kernel_search",
     "plo_cse_enum_cost_many_plan", "plo_cse_enum_search_plan",
-    "plo_cob_search", "plo_cob_search_range",
+    "plo_cob_search", "plo_cob_search_range", "plo_cob_search_batch",
     "plo_tril_plan_create", "plo_tril_plan_create_x", "plo_tril_plan_create_q", "plo_tril_plan_destroy", "plo_tril_cost_many", "plo_tril_search",
     "plo_pack_cost",
 ]
@@ -52,6 +52,12 @@ class Stats(ctypes.Structure):
 
 class CobBest(ctypes.Structure):
     _fields_ = [("zeros_v", ctypes.c_int32), ("zeros_w", ctypes.c_int32), ("index", ctypes.c_uint64), ("found", ctypes.c_uint32)]
+
+
+class CobProblem(ctypes.Structure):
+    """plo_cob_problem_t of include/plinopt_hip.h"""
+    _fields_ = [("TM", ctypes.POINTER(ctypes.c_uint32)), ("Cand", ctypes.POINTER(ctypes.c_uint32)), ("coeffs", ctypes.POINTER(ctypes.c_uint32)),
+                ("ncoeffs", ctypes.c_uint32), ("p", ctypes.c_uint32), ("w0", ctypes.c_int32), ("w1", ctypes.c_int32)]
 
 
 class ICSR(ctypes.Structure):
@@ -124,6 +130,8 @@ def lib():
         L.plo_cob_search_range.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p,
                                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                            ctypes.POINTER(CobBest), ctypes.POINTER(Stats)]
+        L.plo_cob_search_batch.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                           ctypes.POINTER(CobProblem), ctypes.POINTER(CobBest), ctypes.POINTER(Stats)]
         L.plo_cse_enum_cost_many_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u64p, ctypes.POINTER(Stats)]
         L.plo_cse_enum_search_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(Best), u64p, ctypes.POINTER(Stats)]
         L.plo_tril_plan_create.argtypes = [ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ICSR), ctypes.POINTER(ctypes.c_void_p)]

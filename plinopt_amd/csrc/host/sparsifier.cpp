@@ -27,6 +27,7 @@ struct HipCob {
     decltype(&plo_init) init = nullptr;
     decltype(&plo_last_error) last_error = nullptr;
     decltype(&plo_cob_search) cob_search = nullptr;
+    decltype(&plo_cob_search_batch) cob_search_batch = nullptr;
     bool load() {
         std::vector<std::string> cand;
         for (const char *v : {"PLO_HIP_LIB", "PLINOPT_HIP_LIB"}) if (const char *e = getenv(v)) cand.emplace_back(e);   // (one name for the tools and plinopt_amd/capi.py; the older one still works)
@@ -37,13 +38,14 @@ struct HipCob {
         if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
         init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
         cob_search = (decltype(cob_search))dlsym(h, "plo_cob_search");
+        cob_search_batch = (decltype(cob_search_batch))dlsym(h, "plo_cob_search_batch");
         return init && last_error && cob_search;
     }
 };
 
 // GPU backend of the enumeration (Z_p only)
 struct CobGpuBackend : CobBackend<ZpField> {
-    HipCob &L; double kernel_ms = 0;
+    HipCob &L; double kernel_ms = 0; uint64_t launches = 0;
     explicit CobGpuBackend(HipCob &l) : L(l) {}
     CobBest best(const ZpField &f, const DMat<uint32_t> &TM, const DMat<uint32_t> &Cand, size_t row, size_t off,
                  const std::vector<uint32_t> &coeffs, int w0, int w1) override {
@@ -53,7 +55,7 @@ struct CobGpuBackend : CobBackend<ZpField> {
         plo_cob_best_t b{}; plo_stats_t st{};
         int rc = L.cob_search((uint32_t)n, (uint32_t)m, tm.data(), cd.data(), (uint32_t)row, (uint32_t)off, coeffs.data(), (uint32_t)coeffs.size(), f.p, w0, w1, &b, &st);
         if (rc != PLO_OK) throw std::runtime_error(std::string("GPU CoB search failed: ") + L.last_error());
-        this->candidates += st.candidates; kernel_ms += st.kernel_ms;
+        this->candidates += st.candidates; kernel_ms += st.kernel_ms; launches += st.launches;
         CobBest r; r.zv = b.zeros_v; r.zw = b.zeros_w; r.index = b.index; r.found = b.found != 0;
         return r;
     }
@@ -67,7 +69,7 @@ struct CobGpuBackend : CobBackend<ZpField> {
 // independence test).  The two runs must name the same candidate and that candidate is re-evaluated over Q on the host
 // (independence by rank, both zero counts); anything else sends this (block, row) to the host enumeration over Q.
 struct CobGpuQBackend : CobBackend<QField> {
-    HipCob &L; double kernel_ms = 0; uint64_t fallbacks = 0, gpu_calls = 0;
+    HipCob &L; double kernel_ms = 0; uint64_t fallbacks = 0, gpu_calls = 0, launches = 0;
     CobHostBackend<QField> host;
     explicit CobGpuQBackend(HipCob &l) : L(l) {}
     static int64_t lcm64(int64_t a, int64_t b) { int64_t x = a, y = b; while (y) { int64_t t = x % y; x = y; y = t; } __int128 r = (__int128)a / x * b; if (r > ((__int128)1 << 40)) throw std::overflow_error("denominators too large"); return (int64_t)r; }
@@ -85,18 +87,25 @@ struct CobGpuQBackend : CobBackend<QField> {
             for (size_t k = 0; k < C; ++k) { __int128 v = (__int128)coeffs[k].n * (dC / coeffs[k].d); cfi[k] = v; cmax = std::max(cmax, v < 0 ? -v : v); }
             for (size_t i = 0; i < row; ++i) { int64_t dr = 1; for (auto &e : Cand[i]) dr = lcm64(dr, e.d); for (size_t j = 0; j < n; ++j) cdi[i * n + j] = (__int128)Cand[i][j].n * (dr / Cand[i][j].d); }
             if (4 * tmax * cmax >= (__int128)primes[1]) throw std::overflow_error("entries too large for an exact zero test modulo a 31-bit prime");
+            // both moduli in ONE launch (plo_cob_search_batch: one upload, one kernel, one download)
             plo_cob_best_t b[2]{}; plo_stats_t st[2]{};
+            std::vector<uint32_t> tm[2], cd[2], cf[2]; plo_cob_problem_t pr[2];
             for (int q = 0; q < 2; ++q) {
                 const __int128 P = primes[q];
                 auto red = [&](__int128 v) { __int128 r = v % P; if (r < 0) r += P; return (uint32_t)r; };
-                std::vector<uint32_t> tm(n * m), cd(n * n), cf(C);
-                for (size_t k = 0; k < n * m; ++k) tm[k] = red(tmi[k]);
-                for (size_t k = 0; k < n * n; ++k) cd[k] = red(cdi[k]);
-                for (size_t k = 0; k < C; ++k) cf[k] = red(cfi[k]);
-                const int rc = L.cob_search((uint32_t)n, (uint32_t)m, tm.data(), cd.data(), (uint32_t)row, (uint32_t)off, cf.data(), (uint32_t)C, primes[q], w0, w1, &b[q], &st[q]);
+                tm[q].resize(n * m); cd[q].resize(n * n); cf[q].resize(C);
+                for (size_t k = 0; k < n * m; ++k) tm[q][k] = red(tmi[k]);
+                for (size_t k = 0; k < n * n; ++k) cd[q][k] = red(cdi[k]);
+                for (size_t k = 0; k < C; ++k) cf[q][k] = red(cfi[k]);
+                pr[q] = plo_cob_problem_t{tm[q].data(), cd[q].data(), cf[q].data(), (uint32_t)C, primes[q], w0, w1};
+            }
+            {
+                int rc;
+                if (L.cob_search_batch) { rc = L.cob_search_batch(2, (uint32_t)n, (uint32_t)m, (uint32_t)row, (uint32_t)off, pr, b, &st[0]); st[0].candidates /= 2; }
+                else { rc = PLO_OK; for (int q = 0; q < 2 && rc == PLO_OK; ++q) { rc = L.cob_search((uint32_t)n, (uint32_t)m, tm[q].data(), cd[q].data(), (uint32_t)row, (uint32_t)off, cf[q].data(), (uint32_t)C, primes[q], w0, w1, &b[q], &st[q]); if (q) { st[0].kernel_ms += st[1].kernel_ms; st[0].launches += st[1].launches; } } }
                 if (rc == PLO_E_CAPACITY || rc == PLO_E_UNSUPPORTED) throw std::range_error(std::string("the device refused this enumeration (") + L.last_error() + ")");   // e.g. more than 255 coefficients: the host enumerates, as it does for entries too large for the primes
                 if (rc != PLO_OK) throw std::runtime_error(std::string("GPU CoB search failed: ") + L.last_error());
-                kernel_ms += st[q].kernel_ms;
+                kernel_ms += st[0].kernel_ms; launches += st[0].launches;
             }
             this->candidates += st[0].candidates; ++gpu_calls;
             if (b[0].found != b[1].found || (b[0].found && (b[0].index != b[1].index || b[0].zeros_v != b[1].zeros_v || b[0].zeros_w != b[1].zeros_w)))
@@ -219,7 +228,7 @@ int main(int argc, char **argv)
                 if (!L.load() || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return 2; }
                 CobGpuBackend B(L);
                 int rc = tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
-                std::clog << "# GPU: enumeration kernels " << B.kernel_ms << " ms, " << (B.kernel_ms > 0 ? B.candidates / (B.kernel_ms * 1e-3) : 0.0) << " candidate rows/s" << std::endl;
+                std::clog << "# GPU: " << B.launches << " launches, enumeration kernels " << B.kernel_ms << " ms, " << (B.kernel_ms > 0 ? B.candidates / (B.kernel_ms * 1e-3) : 0.0) << " candidate rows/s" << std::endl;
                 return rc;
             }
             CobHostBackend<ZpField> B;
@@ -232,7 +241,7 @@ int main(int argc, char **argv)
             if (!L.load() || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return 2; }
             CobGpuQBackend B(L);
             int rc = tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
-            std::clog << "# GPU (Q, two 31-bit primes + check over Q): " << B.gpu_calls << " enumerations, kernels " << B.kernel_ms << " ms, " << B.fallbacks << " on the host" << std::endl;
+            std::clog << "# GPU (Q, two 31-bit primes + check over Q): " << B.gpu_calls << " enumerations in " << B.launches << " launches (both moduli of an enumeration in one), kernels " << B.kernel_ms << " ms, " << B.fallbacks << " on the host" << std::endl;
             return rc;
         }
         CobHostBackend<QField> B;

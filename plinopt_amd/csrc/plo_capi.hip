@@ -1331,19 +1331,21 @@ int plo_cob_search(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *C
     return plo_cob_search_range(n, m, TM, Cand, row, offsetblock, coeffs, ncoeffs, p, w0, w1, 0, (uint64_t)ncoeffs * ncoeffs * ncoeffs, out, st);
 }
 
-int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
-                         const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
-                         uint64_t first_group, uint64_t ngroups, plo_cob_best_t *out, plo_stats_t *st)
+namespace {
+// Host side of one enumeration: the right nullspace of the rows already chosen restricted to the block, the block of TM, the
+// initial best word.  dependent: the chosen rows are dependent (rank(Cand with row := w) can never exceed `row`, :174).
+struct CobPrep { bool dependent = false; uint32_t qn = 0, fb = 0; std::vector<uint32_t> nb, tmb; unsigned long long init = 0; };
+int cob_check(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock, const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p)
 {
-    if (!TM || !Cand || !coeffs || !out) return fail(PLO_E_ARG, "null argument");
-    if (ncoeffs && (first_group > (uint64_t)ncoeffs * ncoeffs * ncoeffs || ngroups > (uint64_t)ncoeffs * ncoeffs * ncoeffs - first_group)) return fail(PLO_E_ARG, "group range outside the (i,j,k) prefixes");
+    if (!TM || !Cand || !coeffs) return fail(PLO_E_ARG, "null argument");
     if (p < 3 || p >= 0x80000000u || !(p & 1u)) return fail(PLO_E_ARG, "modulus must be an odd prime below 2^31");
     if (n == 0 || row >= n || offsetblock >= n || ncoeffs == 0) return fail(PLO_E_ARG, "bad dimensions");
     if (ncoeffs > 255) return fail(PLO_E_CAPACITY, "more than 255 coefficients: the candidate index does not fit 32 bits");
     if ((uint64_t)(m + 1) * (n + 1) >= 0xFFFFFFFFull) return fail(PLO_E_CAPACITY, "score does not fit 32 bits");
-    if (g_device < 0) { int rc = plo_init(0); if (rc != PLO_OK) return rc; }
-    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
-    auto t0 = std::chrono::steady_clock::now();
+    return PLO_OK;
+}
+void cob_prepare(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock, uint32_t p, int32_t w0, int32_t w1, CobPrep &R)
+{
     // right nullspace of the rows already chosen (rows 0..row-1 of Cand), by reduced row echelon form mod p
     std::vector<std::vector<uint32_t>> A(row, std::vector<uint32_t>(n));
     for (uint32_t i = 0; i < row; ++i) for (uint32_t j = 0; j < n; ++j) A[i][j] = Cand[(size_t)i * n + j] % p;
@@ -1357,15 +1359,11 @@ int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint3
         for (uint32_t i = 0; i < row; ++i) if (i != r0 && A[i][c]) { const uint32_t l = A[i][c]; for (uint32_t j = c; j < n; ++j) A[i][j] = (uint32_t)(((uint64_t)A[i][j] + (uint64_t)(p - l) * A[r0][j]) % p); }
         piv.push_back(c); ++r0;
     }
-    if (piv.size() != row) {      // chosen rows are dependent: rank(Cand with row := w) can never exceed `row` (:174)
-        out->found = 0; out->zeros_v = w0; out->zeros_w = w1; out->index = 0;
-        st->candidates = ngroups * ncoeffs;
-        return PLO_OK;
-    }
+    R.dependent = piv.size() != row;
+    if (R.dependent) return;
     std::vector<char> isp(n, 0); for (uint32_t c : piv) isp[c] = 1;
     const uint32_t fb = std::min<uint32_t>(4, n - offsetblock);
-    std::vector<uint32_t> nb; uint32_t qn = 0;           // 4 x qn, only the block positions of each basis vector
-    std::vector<std::vector<uint32_t>> cols;
+    std::vector<std::vector<uint32_t>> cols;                  // only the block positions of each basis vector
     for (uint32_t fc = 0; fc < n; ++fc) {
         if (isp[fc]) continue;
         std::vector<uint32_t> x(n, 0); x[fc] = 1;
@@ -1373,13 +1371,104 @@ int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint3
         bool any = false; for (uint32_t t = 0; t < fb; ++t) any |= x[offsetblock + t] != 0;
         if (any) cols.push_back({x[offsetblock], fb > 1 ? x[offsetblock + 1] : 0, fb > 2 ? x[offsetblock + 2] : 0, fb > 3 ? x[offsetblock + 3] : 0});
     }
-    qn = (uint32_t)cols.size(); nb.assign(4 * (size_t)std::max<uint32_t>(qn, 1), 0);
-    for (uint32_t c = 0; c < qn; ++c) for (uint32_t t = 0; t < 4; ++t) nb[(size_t)t * qn + c] = cols[c][t];
-    std::vector<uint32_t> tmb(4 * (size_t)m, 0);
-    for (uint32_t t = 0; t < fb; ++t) for (uint32_t j = 0; j < m; ++j) tmb[(size_t)t * m + j] = TM[(size_t)(offsetblock + t) * m + j] % p;
-    const uint64_t first = first_group * ncoeffs, total = (first_group + ngroups) * ncoeffs;      // flattened (i,j,k,l) range of this call
+    R.fb = fb; R.qn = (uint32_t)cols.size(); R.nb.assign(4 * (size_t)std::max<uint32_t>(R.qn, 1), 0);
+    for (uint32_t c = 0; c < R.qn; ++c) for (uint32_t t = 0; t < 4; ++t) R.nb[(size_t)t * R.qn + c] = cols[c][t];
+    R.tmb.assign(4 * (size_t)m, 0);
+    for (uint32_t t = 0; t < fb; ++t) for (uint32_t j = 0; j < m; ++j) R.tmb[(size_t)t * m + j] = TM[(size_t)(offsetblock + t) * m + j] % p;
     const int64_t thr = w0 < 0 ? -1 : (int64_t)w0 * (n + 1) + std::max(w1, 0);
-    const unsigned long long init = ((unsigned long long)(thr + 1) << 32) | 0xFFFFFFFFull;
+    R.init = ((unsigned long long)(thr + 1) << 32) | 0xFFFFFFFFull;
+}
+void cob_decode(unsigned long long w, unsigned long long init, uint32_t n, int32_t w0, int32_t w1, plo_cob_best_t *out)
+{
+    out->found = w != init ? 1u : 0u;
+    if (out->found) { const uint32_t sc = (uint32_t)(w >> 32) - 1u; out->zeros_v = (int32_t)(sc / (n + 1)); out->zeros_w = (int32_t)(sc % (n + 1)); out->index = (uint32_t)~(uint32_t)w; }
+    else { out->zeros_v = w0; out->zeros_w = w1; out->index = 0; }
+}
+} // namespace
+
+// Up to PLO_COB_BATCH enumerations of the same shape (n, m, row, block) in ONE launch: one upload, one kernel (blockIdx.y = the
+// enumeration), one download.  bin/sparsifier over the rationals enumerates modulo two primes: one launch instead of two.
+int plo_cob_search_batch(uint32_t nprob, uint32_t n, uint32_t m, uint32_t row, uint32_t offsetblock, const plo_cob_problem_t *prob, plo_cob_best_t *out, plo_stats_t *st)
+{
+    if (!prob || !out || nprob == 0 || nprob > PLO_COB_BATCH) return fail(PLO_E_ARG, "1 to 4 enumerations per launch");
+    for (uint32_t k = 0; k < nprob; ++k) { const int rc = cob_check(n, m, prob[k].TM, prob[k].Cand, row, offsetblock, prob[k].coeffs, prob[k].ncoeffs, prob[k].p); if (rc != PLO_OK) return rc; }
+    if (g_device < 0) { int rc = plo_init(0); if (rc != PLO_OK) return rc; }
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    auto t0 = std::chrono::steady_clock::now();
+    CobPrep R[PLO_COB_BATCH]; uint32_t live[PLO_COB_BATCH], nlive = 0;
+    for (uint32_t k = 0; k < nprob; ++k) {
+        cob_prepare(n, m, prob[k].TM, prob[k].Cand, row, offsetblock, prob[k].p, prob[k].w0, prob[k].w1, R[k]);
+        const uint64_t C = prob[k].ncoeffs;
+        st->candidates += C * C * C * C;
+        if (R[k].dependent) { out[k].found = 0; out[k].zeros_v = prob[k].w0; out[k].zeros_w = prob[k].w1; out[k].index = 0; }
+        else live[nlive++] = k;
+    }
+    if (nlive == 0) { st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); return PLO_OK; }
+    // one device buffer kept by the context, one upload: [best words (2 each) | per enumeration: TM block | nullspace block | coefficients]
+    DevCtx &cx = cur_ctx();
+    size_t off[PLO_COB_BATCH][3], words = 2 * (size_t)nlive; bool tab = !getenv("PLO_COB_GENERIC"); size_t lds = 0;
+    plo::CobBatch B{}; uint64_t maxgroups = 0, maxtotal = 0;
+    for (uint32_t q = 0; q < nlive; ++q) {
+        const uint32_t k = live[q], C = prob[k].ncoeffs;
+        off[q][0] = words; words += R[k].tmb.size(); off[q][1] = words; words += R[k].nb.size(); off[q][2] = words; words += C;
+        B.ms[q] = m | 1u; B.qs[q] = std::max<uint32_t>(R[k].qn, 1u) | 1u;
+        tab = tab && 4ull * C * ((size_t)B.ms[q] + B.qs[q]) * 4 <= 72u * 1024u;
+        maxgroups = std::max<uint64_t>(maxgroups, (uint64_t)C * C * C); maxtotal = std::max<uint64_t>(maxtotal, (uint64_t)C * C * C * C);
+    }
+    for (uint32_t q = 0; q < nlive; ++q) { const uint32_t k = live[q], C = prob[k].ncoeffs; lds = std::max<size_t>(lds, tab ? (size_t)(4ull * C * ((size_t)B.ms[q] + B.qs[q]) * 4) : (4 * (size_t)m + 4 * (size_t)R[k].qn + C) * 4); }
+    if (lds > g_lds_max) return fail(PLO_E_CAPACITY, "block of TM does not fit LDS");
+    if (cx.cob_words < words) {
+        if (cx.cob_buf) (void)hipFree(cx.cob_buf);
+        cx.cob_buf = nullptr; cx.cob_words = 0;
+        HIPCHK(hipMalloc((void **)&cx.cob_buf, (words + 1024) * 4)); cx.cob_words = words + 1024;
+    }
+    if (!cx.cob_e0) { HIPCHK(hipEventCreate(&cx.cob_e0)); HIPCHK(hipEventCreate(&cx.cob_e1)); }
+    std::vector<uint32_t> up(words);
+    for (uint32_t q = 0; q < nlive; ++q) {
+        const uint32_t k = live[q], C = prob[k].ncoeffs, p = prob[k].p;
+        memcpy(up.data() + 2 * q, &R[k].init, 8);
+        memcpy(up.data() + off[q][0], R[k].tmb.data(), R[k].tmb.size() * 4); memcpy(up.data() + off[q][1], R[k].nb.data(), R[k].nb.size() * 4); memcpy(up.data() + off[q][2], prob[k].coeffs, (size_t)C * 4);
+        plo::CobJob &J = B.J[q];
+        J.n = n; J.m = m; J.qn = R[k].qn; J.fb = R[k].fb; J.C = C; J.p = p; J.mu = (~0ull) / p; J.first = 0; J.total = (uint64_t)C * C * C * C;
+        J.tm = cx.cob_buf + off[q][0]; J.nb = cx.cob_buf + off[q][1]; J.coeffs = cx.cob_buf + off[q][2]; J.best = (unsigned long long *)cx.cob_buf + q;
+    }
+    for (uint32_t q = nlive; q < PLO_COB_BATCH; ++q) B.J[q] = B.J[0];      // (never launched: blockIdx.y < nlive)
+    B.tab = tab ? 1u : 0u;
+    HIPCHK(hipMemcpyAsync(cx.cob_buf, up.data(), words * 4, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipFuncSetAttribute((const void *)plo::cob_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t grid = tab ? std::max<uint64_t>(1, std::min<uint64_t>((maxgroups + 3) / 4, (uint64_t)g_cus * 2)) : std::max<uint64_t>(1, std::min<uint64_t>((maxtotal + 255) / 256, (uint64_t)g_cus * 8));
+    HIPCHK(hipEventRecord(cx.cob_e0, g_stream));
+    hipLaunchKernelGGL(plo::cob_batch_kernel, dim3((uint32_t)grid, nlive), dim3(256), lds, g_stream, B);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(cx.cob_e1, g_stream)); HIPCHK(hipEventSynchronize(cx.cob_e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, cx.cob_e0, cx.cob_e1));
+    unsigned long long w[PLO_COB_BATCH] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(w, cx.cob_buf, 8 * (size_t)nlive, hipMemcpyDeviceToHost));
+    for (uint32_t q = 0; q < nlive; ++q) { const uint32_t k = live[q]; cob_decode(w[q], R[k].init, n, prob[k].w0, prob[k].w1, &out[k]); }
+    st->kernel_ms = ms; st->launches = 1; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)lds; st->waves_per_wg = 4;
+    st->algo_bytes = (16ull * m + 8) * nlive;
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PLO_OK;
+}
+
+int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint32_t *Cand, uint32_t row, uint32_t offsetblock,
+                         const uint32_t *coeffs, uint32_t ncoeffs, uint32_t p, int32_t w0, int32_t w1,
+                         uint64_t first_group, uint64_t ngroups, plo_cob_best_t *out, plo_stats_t *st)
+{
+    if (!out) return fail(PLO_E_ARG, "null argument");
+    { const int rc = cob_check(n, m, TM, Cand, row, offsetblock, coeffs, ncoeffs, p); if (rc != PLO_OK) return rc; }
+    if (first_group > (uint64_t)ncoeffs * ncoeffs * ncoeffs || ngroups > (uint64_t)ncoeffs * ncoeffs * ncoeffs - first_group) return fail(PLO_E_ARG, "group range outside the (i,j,k) prefixes");
+    if (g_device < 0) { int rc = plo_init(0); if (rc != PLO_OK) return rc; }
+    plo_stats_t local{}; if (!st) st = &local; else *st = plo_stats_t{};
+    auto t0 = std::chrono::steady_clock::now();
+    CobPrep R; cob_prepare(n, m, TM, Cand, row, offsetblock, p, w0, w1, R);
+    if (R.dependent) {      // chosen rows are dependent: rank(Cand with row := w) can never exceed `row` (:174)
+        out->found = 0; out->zeros_v = w0; out->zeros_w = w1; out->index = 0;
+        st->candidates = ngroups * ncoeffs;
+        return PLO_OK;
+    }
+    const uint32_t qn = R.qn, fb = R.fb; const std::vector<uint32_t> &nb = R.nb, &tmb = R.tmb; const unsigned long long init = R.init;
+    const uint64_t first = first_group * ncoeffs, total = (first_group + ngroups) * ncoeffs;      // flattened (i,j,k,l) range of this call
     const size_t lds = (4 * (size_t)m + 4 * (size_t)qn + ncoeffs) * 4;
     if (lds > g_lds_max) return fail(PLO_E_CAPACITY, "block of TM does not fit LDS");
     // one device buffer kept by the context, one upload: [best word (2) | TM block | nullspace block | coefficients]
@@ -1419,9 +1508,7 @@ int plo_cob_search_range(uint32_t n, uint32_t m, const uint32_t *TM, const uint3
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long w = 0;
     HIPCHK(hipMemcpy(&w, d_best, 8, hipMemcpyDeviceToHost));
-    out->found = w != init ? 1u : 0u;
-    if (out->found) { const uint32_t sc = (uint32_t)(w >> 32) - 1u; out->zeros_v = (int32_t)(sc / (n + 1)); out->zeros_w = (int32_t)(sc % (n + 1)); out->index = (uint32_t)~(uint32_t)w; }
-    else { out->zeros_v = w0; out->zeros_w = w1; out->index = 0; }
+    cob_decode(w, init, n, w0, w1, out);
     st->kernel_ms = ms; st->launches = 1; st->candidates = total - first; st->grid = (uint32_t)grid; st->lds_bytes = (uint32_t)(use_tab ? lds_tab : lds); st->waves_per_wg = 4;
     st->algo_bytes = 16ull * m + 8;                       // the 4 x m block of TM, once, plus the result word
     st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

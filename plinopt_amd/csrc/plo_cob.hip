@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t cob_mul(uint32_t a, uint32_t b, uint32_t p, 
 }
 __device__ __forceinline__ bool cob_zero4(uint64_t s, uint32_t p) { return s == 0 || s == p || s == 2ull * p || s == 3ull * p; }
 
-__global__ __launch_bounds__(256) void cob_kernel(CobJob J)
+__device__ __forceinline__ void cob_body(const CobJob &J)
 {
     extern __shared__ uint32_t cl[];                    // tm block (4*m) then nullspace block (4*qn) then coeffs (C)
     uint32_t *tm = cl, *nb = cl + 4u * J.m, *cf = nb + 4u * J.qn;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void cob_kernel(CobJob J)
 // takes one (i,j,k); its lanes take l; per column the wave does three broadcast LDS reads and a reduction for
 // neg_c, each lane one LDS read and one compare.  The independence test w.N != 0 has the same shape on the
 // tabulated products with the nullspace block.  ~0.2 wave instructions per candidate and column instead of ~90.
-__global__ __launch_bounds__(256) void cob_tab_kernel(CobJob J, uint32_t ms /* odd row stride >= m */, uint32_t qs /* odd stride >= qn */)
+__device__ __forceinline__ void cob_tab_body(const CobJob &J, uint32_t ms /* odd row stride >= m */, uint32_t qs /* odd stride >= qn */)
 {
     extern __shared__ uint32_t cl[];
     const uint32_t p = J.p, C = J.C, m = J.m, qn = J.qn, fb = J.fb;
@@ -140,6 +140,21 @@ __global__ __launch_bounds__(256) void cob_tab_kernel(CobJob J, uint32_t ms /* o
         const uint64_t v = ((uint64_t)hi << 32) | lo; mybest = v > mybest ? v : mybest;
     }
     if (lane == 0 && mybest) atomicMax(J.best, (unsigned long long)mybest);
+}
+
+__global__ __launch_bounds__(256) void cob_kernel(CobJob J) { cob_body(J); }
+__global__ __launch_bounds__(256) void cob_tab_kernel(CobJob J, uint32_t ms, uint32_t qs) { cob_tab_body(J, ms, qs); }
+
+// Several enumerations of the same shape in ONE launch (blockIdx.y = the enumeration): the two primes of an enumeration over the
+// rationals (CobGpuQBackend of bin/sparsifier), or the shards of one.  Table form when `tab`.
+#define PLO_COB_BATCH 4
+struct CobBatch { CobJob J[PLO_COB_BATCH]; uint32_t ms[PLO_COB_BATCH], qs[PLO_COB_BATCH]; uint32_t tab; };
+__global__ __launch_bounds__(256) void cob_batch_kernel(CobBatch B)
+{
+    const uint32_t y = blockIdx.y;
+    // (a switch on the uniform index: the jobs stay in the kernel-argument segment instead of being copied to scratch)
+    if (B.tab) { if (y == 0u) cob_tab_body(B.J[0], B.ms[0], B.qs[0]); else if (y == 1u) cob_tab_body(B.J[1], B.ms[1], B.qs[1]); else if (y == 2u) cob_tab_body(B.J[2], B.ms[2], B.qs[2]); else cob_tab_body(B.J[3], B.ms[3], B.qs[3]); }
+    else { if (y == 0u) cob_body(B.J[0]); else if (y == 1u) cob_body(B.J[1]); else if (y == 2u) cob_body(B.J[2]); else cob_body(B.J[3]); }
 }
 
 } // namespace plo

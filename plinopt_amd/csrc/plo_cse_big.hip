@@ -771,7 +771,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
     // (MODE is a template parameter: the compiler turns a run-time choice between the two address spaces into a flat load)
     const uint2 *vtg = P.vt; const uint2 *vts = TB.vts;
     auto VT = [&](uint32_t vi) -> uint2 { if constexpr (MODE == 1) return vts[vi]; else return vtg[vi]; };
-    const uint16_t *rtid = TB.rtid, *invid = TB.invid; const uint32_t *rval = TB.rval; const uint32_t nv = P.nv;   // mode 2
+    const uint16_t *rtid = TB.rtid, *invid = TB.invid; const uint32_t *rval = TB.rval;   // mode 2
     uint32_t *aggk = (uint32_t *)agg, *aggc32 = aggk + (1u << aggbits); uint16_t *aggc16 = (uint16_t *)aggc32;      // mode 2: key array, count array
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
     // slots claimed in the aggregation table by the running sweep (the flush walks this list, not the table): mode 2 has room

@@ -205,6 +205,21 @@ def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1, groups
     return (b.zeros_v, b.zeros_w, b.index, b.found), st.as_dict()
 
 
+def cob_search_batch(n, m, row, offsetblock, problems):
+    """Up to 4 enumerations of the same shape in ONE launch (`plo_cob_search_batch`): problems = [(TM, Cand, coeffs, p, w0, w1), ...]
+    (the two primes of an enumeration over the rationals).  Returns ([(zeros_v, zeros_w, index, found), ...], stats)."""
+    L = capi.lib()
+    arr = lambda xs: (ctypes.c_uint32 * max(len(xs), 1))(*xs)
+    keep, pr = [], (capi.CobProblem * len(problems))()
+    for k, (TM, Cand, coeffs, p, w0, w1) in enumerate(problems):
+        a, b, c = arr(TM), arr(Cand), arr(coeffs); keep += [a, b, c]
+        pr[k] = capi.CobProblem(ctypes.cast(a, ctypes.POINTER(ctypes.c_uint32)), ctypes.cast(b, ctypes.POINTER(ctypes.c_uint32)),
+                                ctypes.cast(c, ctypes.POINTER(ctypes.c_uint32)), len(coeffs), p, w0, w1)
+    out, st = (capi.CobBest * len(problems))(), capi.Stats()
+    capi.check(L.plo_cob_search_batch(len(problems), n, m, row, offsetblock, pr, out, ctypes.byref(st)))
+    return [(b.zeros_v, b.zeros_w, b.index, b.found) for b in out], st.as_dict()
+
+
 TRIL_BASE_SEED = (1 << 64) - 1
 
 

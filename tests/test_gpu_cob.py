@@ -75,6 +75,33 @@ def test_cob_random_blocks(hip):
         assert got == exp, (trial, p, n, m, row, C, w0)
 
 
+def test_cob_batch_of_enumerations_in_one_launch(hip):
+    """plo_cob_search_batch: up to four enumerations of one shape (different moduli, matrices, thresholds; dependent chosen rows in
+    some) in ONE launch -- each result equals the oracle's for that enumeration, and the launch counter says 1."""
+    from plinopt_amd import cob_search_batch
+    rng = random.Random(11)
+    for trial in range(30):
+        n, m = rng.randint(1, 7), rng.randint(1, 40)
+        row = rng.randint(0, n - 1)
+        off = (row // 4) * 4
+        probs = []
+        for _ in range(rng.randint(1, 4)):
+            p = rng.choice([7, 101, 131071, 2147483629, 2147483647])
+            TM = [rng.choice([0, 0, 1, p - 1, 2, 3]) % p for _ in range(n * m)]
+            Cand = [0] * (n * n)
+            for i in range(row):
+                for j in range(n):
+                    Cand[i * n + j] = rng.choice([0, 1, p - 1, 2]) % p
+            C = rng.randint(1, 6)
+            coeffs = [0, 1, p - 1, 2 % p, (p - 2) % p, 3 % p][:C]
+            w0 = rng.choice([-1, 0, m // 2])
+            probs.append((TM, Cand, coeffs, p, w0, 0 if w0 >= 0 else -1))
+        got, st = cob_search_batch(n, m, row, off, probs)
+        exp = [oracle_cob_search(n, m, TM, Cand, row, off, coeffs, p, w0, w1) for (TM, Cand, coeffs, p, w0, w1) in probs]
+        assert got == exp, (trial, n, m, row)
+        assert st["launches"] <= 1 and st["candidates"] == sum(len(q[2]) ** 4 for q in probs)
+
+
 @pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "2x2x2_7_Winograd_L.sms", "2x2x2_7_DPS-accurate_L.sms", "3x3x3_23_58_P.sms"])
 def test_sparsifier_cli_gpu_equals_host(hip, name):
     """bin/sparsifier -q p -c C on the GPU prints the same change of basis as the host enumeration and the
@@ -100,7 +127,7 @@ def test_sparsifier_cli_on_gpu_prints_the_oracles_basis(hip, name, b, c):
     path = os.path.join(DATA, name)
     CoB, Res, cand = oracle_sparsify(dense_mod(path, P), P, b, c, True)
     g = subprocess.run([SPS, "-q", str(P), "-b", str(b), "-c", str(c), "-S", path], capture_output=True, text=True, timeout=600)
-    assert g.returncode == 0 and "SUCCESS: consistent factorization" in g.stderr and "# GPU: enumeration kernels" in g.stderr, g.stderr
+    assert g.returncode == 0 and "SUCCESS: consistent factorization" in g.stderr and re.search(r"# GPU: \d+ launches, enumeration kernels", g.stderr), g.stderr
     assert parse_sms_text(g.stdout) == CoB
     tail = g.stderr.split("residuum profile:")[1]
     assert parse_sms_text(tail[tail.index("\n") + 1:]) == Res
@@ -119,8 +146,9 @@ def test_sparsifier_over_the_rationals_on_gpu_equals_host(hip, name, c):
     h = subprocess.run([SPS, "-c", c, "-S", "--gpu", "0", path], capture_output=True, text=True, timeout=900)
     assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
     assert "SUCCESS: consistent factorization" in g.stderr
-    m = re.search(r"# GPU \(Q, two 31-bit primes \+ check over Q\): (\d+) enumerations, kernels [0-9.e+-]+ ms, (\d+) on the host", g.stderr)
-    assert m and int(m.group(1)) > 0 and int(m.group(2)) == 0, g.stderr
+    m = re.search(r"# GPU \(Q, two 31-bit primes \+ check over Q\): (\d+) enumerations in (\d+) launches \(both moduli of an enumeration in one\), kernels [0-9.e+-]+ ms, (\d+) on the host", g.stderr)
+    assert m and int(m.group(1)) > 0 and int(m.group(3)) == 0, g.stderr
+    assert int(m.group(2)) <= int(m.group(1))               # plo_cob_search_batch: ONE launch per enumeration (an enumeration after dependent rows needs none)
     assert g.stdout == h.stdout
     assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)
 
