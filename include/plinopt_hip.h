@@ -55,6 +55,8 @@ typedef struct {
     uint32_t waves_per_wg;   /* candidates in flight per workgroup */
     uint32_t grid;           /* workgroups per launch */
     uint64_t algo_bytes;     /* algorithmic bytes per candidate, B_cand = 8*nnz + 12*P0 + 8 */
+    uint32_t reduce;         /* plo_cse_search_multi: 1 = the minimum over the devices went through one RCCL MIN all-reduce (and equals the host's) */
+    uint32_t reserved;
 } plo_stats_t;
 
 /* cost order of the restart loop, include/plinopt_optimize.h:53-64 */

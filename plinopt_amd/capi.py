@@ -44,7 +44,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("seconds", ctypes.c_double), ("kernel_ms", ctypes.c_double),
                 ("candidates", ctypes.c_uint64), ("launches", ctypes.c_uint32),
                 ("lds_bytes", ctypes.c_uint32), ("waves_per_wg", ctypes.c_uint32),
-                ("grid", ctypes.c_uint32), ("algo_bytes", ctypes.c_uint64)]
+                ("grid", ctypes.c_uint32), ("algo_bytes", ctypes.c_uint64),
+                ("reduce", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

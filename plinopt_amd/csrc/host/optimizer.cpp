@@ -557,7 +557,7 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         const int rc = L.cse_search_multi(&A, q, seed0, loops, PLO_COST_SUM_THEN_ADD, gpu, devs.data(), &b, &st);
         if (rc != PLO_OK) { ++g_failures; std::cerr << "# \033[1;31mERROR: shard failed: " << L.last_error() << "\033[0m" << std::endl; return 2; }
         sharded.ops = {b.adds, b.muls}; sharded.seed = b.seed; sharded.done = b.seed != ~0ull;
-        if (verbose > 0) std::clog << "# " << gpu << " shards (one GPU and one host thread each, one process): " << st.candidates << " candidates, slowest kernel " << st.kernel_ms << " ms" << std::endl;
+        if (verbose > 0) std::clog << "# " << gpu << " shards (one GPU and one host thread each, one process): " << st.candidates << " candidates, slowest kernel " << st.kernel_ms << " ms" << (st.reduce ? ", minimum by one RCCL MIN all-reduce" : ", minimum on the host") << std::endl;
     }
     if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0 && !sharded.done) {
         const bool host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob: every shard on the host engine

@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -915,6 +916,57 @@ int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nsee
 }
 
 // The restart range in `ndev` contiguous shards, one host thread and one device per shard; the minimum under (cost, seed).
+namespace {
+// RCCL, loaded at run time (librccl.so.1 of the ROCm installation; no link-time dependency): the MIN all-reduce of plo_cse_search_multi.
+struct Rccl {
+    typedef void *comm_t;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+    bool ok = false;
+    Rccl() {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll"); AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy"); GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        ok = CommInitAll && AllReduce && CommDestroy && GroupStart && GroupEnd;
+    }
+};
+Rccl &rccl() { static Rccl r; return r; }
+enum { RCCL_UINT64 = 5, RCCL_MIN = 3 };      // ncclUint64, ncclMin of rccl/rccl.h
+
+// MIN over the devices of one 64-bit word each (one ncclAllReduce per device inside a group, issued by this thread); false when
+// RCCL is not there or a call fails (the caller then reduces on the host -- the result is the same word either way).
+bool rccl_min_u64(const std::vector<int> &devs, std::vector<unsigned long long> &words, std::string &why)
+{
+    Rccl &R = rccl();
+    if (!R.ok) { why = "librccl not loadable"; return false; }
+    const int n = (int)devs.size();
+    std::vector<Rccl::comm_t> comms((size_t)n, nullptr);
+    std::vector<unsigned long long *> dbuf((size_t)n, nullptr); std::vector<hipStream_t> strm((size_t)n, nullptr);
+    bool good = R.CommInitAll(comms.data(), n, devs.data()) == 0;
+    if (!good) why = "ncclCommInitAll failed";
+    for (int i = 0; good && i < n; ++i) {
+        good = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipStreamCreateWithFlags(&strm[(size_t)i], hipStreamNonBlocking) == hipSuccess &&
+               hipMalloc((void **)&dbuf[(size_t)i], 8) == hipSuccess && hipMemcpy(dbuf[(size_t)i], &words[(size_t)i], 8, hipMemcpyHostToDevice) == hipSuccess;
+        if (!good) why = "device buffer for the all-reduce";
+    }
+    if (good) {
+        R.GroupStart();
+        for (int i = 0; i < n; ++i) good = good && R.AllReduce(dbuf[(size_t)i], dbuf[(size_t)i], 1, RCCL_UINT64, RCCL_MIN, comms[(size_t)i], strm[(size_t)i]) == 0;
+        good = (R.GroupEnd() == 0) && good;
+        if (!good) why = "ncclAllReduce failed";
+    }
+    for (int i = 0; good && i < n; ++i) {
+        good = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipStreamSynchronize(strm[(size_t)i]) == hipSuccess && hipMemcpy(&words[(size_t)i], dbuf[(size_t)i], 8, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!good) why = "reading the reduced word";
+    }
+    for (int i = 0; i < n; ++i) { if (dbuf[(size_t)i] || strm[(size_t)i]) { (void)hipSetDevice(devs[(size_t)i]); if (dbuf[(size_t)i]) (void)hipFree(dbuf[(size_t)i]); if (strm[(size_t)i]) (void)hipStreamDestroy(strm[(size_t)i]); } if (comms[(size_t)i]) R.CommDestroy(comms[(size_t)i]); }
+    return good;
+}
+} // namespace
+
 int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode, int ndev, const int *devices,
                          plo_best_t *out, plo_stats_t *stats)
 {
@@ -950,6 +1002,29 @@ int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_
         agg.grid = S.st.grid; agg.lds_bytes = S.st.lds_bytes; agg.waves_per_wg = S.st.waves_per_wg; agg.algo_bytes = S.st.algo_bytes;
         if (S.b.seed == ~0ull) continue;
         if (!have || key(S.b) < key(*out) || (key(S.b) == key(*out) && S.b.seed < out->seed)) { *out = S.b; have = true; }
+    }
+    // The same minimum as ONE RCCL MIN all-reduce over the devices (xGMI): every device contributes its shard's packed word
+    // key << 32 | (seed - seed0) -- the order above when both key fields fit 16 bits and the range 32 -- and every device receives the
+    // winner's.  Default with two or more devices (PLO_MULTI_REDUCE=host keeps the host loop only, =rccl also reduces a single
+    // device's word); the host minimum above is kept as the check: a different word is an error.
+    {
+        const char *mode = getenv("PLO_MULTI_REDUCE");
+        const bool want = mode ? !strcmp(mode, "rccl") : ndev >= 2;
+        bool fits = have && nseeds <= 0xFFFFFFFFull;
+        for (auto &S : sh) if (S.cnt && S.b.seed != ~0ull) fits = fits && key(S.b).first < 65536 && key(S.b).second < 65536;
+        if (want && fits) {
+            std::vector<int> devs; std::vector<unsigned long long> words;
+            for (int r = 0; r < ndev; ++r) { const Shard &S = sh[(size_t)r]; devs.push_back(devices ? devices[r] : r);
+                words.push_back(S.cnt && S.b.seed != ~0ull ? ((unsigned long long)key(S.b).first << 48) | ((unsigned long long)key(S.b).second << 32) | (unsigned long long)(S.b.seed - seed0) : ~0ull); }
+            bool distinct = true; for (size_t i = 0; i < devs.size(); ++i) for (size_t j = 0; j < i; ++j) distinct = distinct && devs[i] != devs[j];
+            std::string why;
+            if (!distinct) agg.reduce = 0;                                           // (a communicator needs distinct devices: PLO_GPU_DEVICES=0,0 in the tests)
+            else if (rccl_min_u64(devs, words, why)) {
+                const unsigned long long mine = ((unsigned long long)key(*out).first << 48) | ((unsigned long long)key(*out).second << 32) | (unsigned long long)(out->seed - seed0);
+                for (unsigned long long w : words) if (w != mine) return fail(PLO_E_HIP, "RCCL MIN all-reduce and host minimum disagree");
+                agg.reduce = 1;
+            } else if (mode) return fail(PLO_E_HIP, "PLO_MULTI_REDUCE=rccl: " + why);
+        }
     }
     agg.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats) *stats = agg;

@@ -96,7 +96,7 @@ def cse_search_multi(m, n, rowptr, col, val, p, seed0, nseeds, devices, cost_mod
     b, st = capi.Best(), capi.Stats()
     capi.check(L.plo_cse_search_multi(ctypes.byref(csr), p, seed0, nseeds, cost_mode, len(devices), devs, ctypes.byref(b), ctypes.byref(st)))
     del keep
-    return (b.adds, b.muls, b.seed), {"seconds": st.seconds, "kernel_ms": st.kernel_ms, "candidates": st.candidates, "launches": st.launches}
+    return (b.adds, b.muls, b.seed), {"seconds": st.seconds, "kernel_ms": st.kernel_ms, "candidates": st.candidates, "launches": st.launches, "reduce": st.reduce}
 
 
 def cmp_op_count_key(adds, muls, cost_mode=capi.COST_SUM_THEN_ADD):

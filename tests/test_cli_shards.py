@@ -87,6 +87,25 @@ def test_in_library_multi_device_search_equals_one_device(hip, ndev):
 
 
 @pytest.mark.gpu
+def test_multi_device_minimum_through_rccl(hip, monkeypatch):
+    """north_star: "a single RCCL MIN all-reduce over xGMI".  plo_cse_search_multi reduces the shards' packed words
+    key << 32 | (seed - seed0) with ONE ncclAllReduce(ncclUint64, ncclMin) over a communicator of its devices (librccl loaded at
+    run time) and checks the result against the host minimum; the test box has one GPU, so the communicator has one rank here
+    (PLO_MULTI_REDUCE=rccl asks for the all-reduce even then) -- same winner as the single-device search, stats say `reduce`."""
+    from plinopt_amd import CSEPlan, cse_search_multi
+    from plo_testlib import OracleMatrix
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), P)
+    monkeypatch.setenv("PLO_MULTI_REDUCE", "rccl")
+    got, st = cse_search_multi(M.m, M.n, M.rowptr, M.col, M.val, P, 7, 3001, [0])
+    assert st["reduce"] == 1
+    plan = CSEPlan(M.m, M.n, M.rowptr, M.col, M.val, P)
+    assert plan.search(7, 3001) == got
+    monkeypatch.setenv("PLO_MULTI_REDUCE", "host")
+    got2, st2 = cse_search_multi(M.m, M.n, M.rowptr, M.col, M.val, P, 7, 3001, [0])
+    assert got2 == got and st2["reduce"] == 0
+
+
+@pytest.mark.gpu
 def test_trilplacer_two_shards_on_the_gpu(hip):
     files = [os.path.join(DATA, "4x4x4_49_156" + x) for x in ("_L.sms", "_R.sms", "_P.sms")]
     rc1, out1, err1 = _run([TRIL] + files + ["-O", "3001", "--seed", "9"])
