@@ -1231,7 +1231,7 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); e0 = e1 = nullptr;
     };
 #define KCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(PLO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
-    uint32_t pairs_max = 0;
+    uint32_t pairs_max = 0, ent_max = 0;
     // Dep's table starts at 0.75 x the sampled PAIR count (an upper bound of its distinct triples, usually far above it): a
     // smaller image means more resident waves; a full table is reported by the device and the launch repeated with twice the slots
     for (uint32_t cap_scale = 1; cap_scale <= 32; cap_scale *= 2) {
@@ -1251,6 +1251,7 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         K.off_piv = off;   off += 128u * 2u;
         K.off_basis = off; off += 64u * 2u;
         K.off_deps = off;  off += 64u * 2u;
+        K.off_rsd = off;   off += 66u * 2u;
         K.scratch_bytes = round_up(off, 16);
         K.off_vc = round_up(K.PM.tmpl_bytes, 16);                                 // V (m x (n+1)) and C (m x (rank+1)) of the elimination, behind M's template
         const uint32_t vc_end = K.off_vc + m * (n + 1u + R + 1u) * 4u;
@@ -1276,18 +1277,20 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
             uint32_t sz[4] = {0, 0, 0, 0};
             KCHK(hipMemcpy(sz, d_sz, 16, hipMemcpyDeviceToHost));
             if (sz[2]) { cleanup(); return device_error(plo::ERR_KDEC); }
-            pairs_max = sz[0];
+            pairs_max = sz[0]; ent_max = sz[1];
             if (const char *e = getenv("PLO_KMETHOD_PAIRS_DIV")) pairs_max /= (uint32_t)std::max(1l, strtol(e, nullptr, 10));   // test knob: undersized first table, exercises the repeat-with-more-slots path
         }
-        // layout of Dep's image from the hard bounds (rows <= m - rank, entries per row <= rank) and the sampled pair count
+        // layout of Dep's image: rows <= m - rank, entries per row <= rank (hard bounds); the number of entries and the pair count from the
+        // sample of the sizing launch (+60 %; measured on 4x4x4_49_156_L: +25 % and +40 % are exceeded by a few of 10^6 restarts and the whole launch is repeated, +60 % and +80 % never in 3 x 10^6: the rows of a restart are packed, a restart with more entries is reported -- ERR_TABLE -- and
+        // the launch repeated with the hard bound rows x rank, as for a full table).  Round 2 sized the arrays for rows x rank: 17.3 KB per
+        // wave on 4x4x4_49_156_L, 7 waves per CU.
         uint32_t capD = 64;
         while (capD < (cap_scale * pairs_max * 3u) / 4u + 16u) capD <<= 1;
-        rc = layout_plan(K.PD, ndeps, m, ndeps * R, p, R, ndeps * (R - 1u), capD);
+        uint32_t entD = (cap_scale == 1 && !getenv("PLO_KMETHOD_HARD_BOUNDS")) ? std::min<uint32_t>(ndeps * R, ent_max + (uint32_t)((uint64_t)ent_max * (getenv("PLO_KMETHOD_ENT_MARGIN") ? (uint32_t)atoi(getenv("PLO_KMETHOD_ENT_MARGIN")) : 60u) / 100u) + 16u) : ndeps * R;
+        if (const char *e = getenv("PLO_KMETHOD_ENT_DIV")) { if (cap_scale == 1) entD = std::max<uint32_t>(R, entD / (uint32_t)std::max(1l, strtol(e, nullptr, 10))); }   // test knob: undersized entry arrays, exercises the repeat-with-hard-bounds path
+        rc = layout_plan(K.PD, ndeps, m, entD, p, R, entD, capD);
         if (rc != PLO_OK) { cleanup(); return rc; }
-        std::vector<uint16_t> rsD(K.PD.rs_bytes / 2u, 0);
-        for (uint32_t j = 0; j <= ndeps; ++j) rsD[j] = (uint16_t)(j * R);
-        KCHK(hipMalloc((void **)&d_rsD, K.PD.rs_bytes)); KCHK(hipMemcpy(d_rsD, rsD.data(), K.PD.rs_bytes, hipMemcpyHostToDevice));
-        K.rsD = d_rsD;
+        K.rsD = nullptr;                                                          // Dep's row starts are computed per restart on the device
         K.region = round_up(std::max(std::max(K.PM.region_bytes, K.PD.region_bytes), vc_end), 16);
         uint32_t W = 0, lds = 0, bestw = 0;
         for (uint32_t w : {4u, 2u, 1u}) {
@@ -1297,6 +1300,8 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
             if (waves > bestw) { bestw = waves; W = w; lds = l; }
         }
         if (!W) { cleanup(); return fail(PLO_E_CAPACITY, "kernel-method state does not fit LDS"); }
+        if (getenv("PLO_KM_DEBUG")) fprintf(stderr, "# kernel method layout: region of M %u B (table %u slots), of Dep %u B (table %u slots, sampled pairs %u, entries %u of at most %u), elimination arrays end at %u B, scratch %u B; %u waves per workgroup, %u B of LDS, %u waves per CU\n",
+                                            K.PM.region_bytes, K.PM.cap, K.PD.region_bytes, K.PD.cap, pairs_max, K.PD.nnz, ndeps * R, vc_end, K.scratch_bytes, W, lds, bestw);
         KCHK(hipMalloc((void **)&d_best, 8)); KCHK(hipMemsetAsync(d_best, 0xFF, 8, g_stream));
         if (adds) KCHK(hipMalloc((void **)&d_adds, nrestarts * 4));
         if (muls) KCHK(hipMalloc((void **)&d_muls, nrestarts * 4));

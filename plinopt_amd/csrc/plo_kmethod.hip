@@ -39,8 +39,8 @@ struct KPlan {
     uint32_t mers;                 // k when p = 2^k - 1 (shift-and-add reduction in the elimination), else 0
     uint32_t region;               // bytes of the image region of a wave (max of the two plans)
     uint32_t off_vc;               // elimination work arrays V, C inside the image region, behind M's template
-    uint32_t off_depc, off_vrow, off_ord, off_piv, off_basis, off_deps, scratch_bytes;   // scratch behind the region
-    const uint64_t *rsD;           // row starts of Dep's image (u16, PD.rs_bytes)
+    uint32_t off_depc, off_vrow, off_ord, off_piv, off_basis, off_deps, off_rsd, scratch_bytes;   // scratch behind the region
+    const uint64_t *rsD;           // unused since round 3 (Dep's row starts are per restart: KScratch::rsd)
 };
 #ifdef PLO_KM_PROFILE
 __device__ unsigned long long g_kprof[8];   // lane 0 of every wave: cycles in image copy + decomposition, Free build, Optimizer on Free, Dep build, Optimizer on Dep; restarts
@@ -64,10 +64,10 @@ __device__ __forceinline__ uint32_t kinv(uint32_t x, uint32_t p, uint64_t mu) {
     return res;
 }
 
-struct KScratch { uint32_t *depc, *vrow; uint16_t *ord, *piv, *basis, *deps; };
+struct KScratch { uint32_t *depc, *vrow; uint16_t *ord, *piv, *basis, *deps, *rsd; };   // rsd: row starts of THIS restart's Dep (rows packed: the image is sized from sampled entry counts, not from rows x rank)
 __device__ __forceinline__ KScratch kscratch(const KPlan &K, uint8_t *scr) {
     return KScratch{(uint32_t *)(scr + K.off_depc), (uint32_t *)(scr + K.off_vrow),
-                    (uint16_t *)(scr + K.off_ord), (uint16_t *)(scr + K.off_piv), (uint16_t *)(scr + K.off_basis), (uint16_t *)(scr + K.off_deps)};
+                    (uint16_t *)(scr + K.off_ord), (uint16_t *)(scr + K.off_piv), (uint16_t *)(scr + K.off_basis), (uint16_t *)(scr + K.off_deps), (uint16_t *)(scr + K.off_rsd)};
 }
 
 // Steps 1-2 and the draw of NotIndep.  M's image must be in `reg`.  Returns the number of dependent rows KEPT in Dep
@@ -237,31 +237,45 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
             }
             PLO_WAVE_SYNC();
             if (sD < R) { bpos = S.vrow[sD]; bcol = S.basis[bpos]; }
+            // pass 1: the lengths; then the row starts of this restart (rows packed one behind the other)
+            for (uint32_t r0 = 0; r0 < kept; r0 += GD) {
+                const uint32_t j = r0 + gD; const bool act = j < kept && sD < R;
+                const bool has = act && S.depc[j * R + bpos] != 0u;
+                const uint64_t mk = __ballot(has) & gmD;
+                if (j < kept && sD == 0u) len[j] = (uint16_t)__popcll(mk);
+            }
+            PLO_WAVE_SYNC();
+            {
+                uint32_t l = lane < kept ? (uint32_t)len[lane] : 0u, inc = l;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += u; }
+                if (lane < kept) S.rsd[lane + 1u] = (uint16_t)inc;
+                if (lane == 0u) S.rsd[0] = 0;
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if (total > PD.nnz) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_TABLE); return 0; }      // more entries than the sampled bound: the host repeats with the hard one
+            }
+            PLO_WAVE_SYNC();
             for (uint32_t r0 = 0; r0 < kept; r0 += GD) {
                 const uint32_t j = r0 + gD; const bool act = j < kept && sD < R;
                 const uint32_t x = act ? S.depc[j * R + bpos] : 0u;
                 const bool has = x != 0u;
                 const uint64_t mk = __ballot(has) & gmD;
                 if (has) {
-                    const uint32_t pos = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull)), base = rsD[j];
+                    const uint32_t pos = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull)), base = S.rsd[j];
                     col[base + pos] = (uint16_t)bcol; val[base + pos] = x;
                     atomicOr((unsigned long long *)&cmask[bcol * 2u], 1ull << j);
                     if (absone(x, p)) atomicOr((unsigned long long *)&umask[bcol * 2u], 1ull << j);
                 }
-                if (j < kept && sD == 0u) len[j] = (uint16_t)__popcll(mk);
             }
         }
         PLO_WAVE_SYNC();
-        for (uint32_t idx = lane; idx < kept * R; idx += 64u) {               // inverses of all entries, 64 at a time
-            const uint32_t j = idx / R, t = idx - j * R;
-            if (t < len[j]) inv[rsD[j] + t] = kinv(val[rsD[j] + t], p, mu);
-        }
+        for (uint32_t idx = lane; idx < (uint32_t)S.rsd[kept]; idx += 64u) inv[idx] = kinv(val[idx], p, mu);      // inverses of all entries, 64 at a time
         PLO_WAVE_SYNC();
         // pair table (listpairs :30-41): G rows per trip, lane t of a group pairs entry t with every earlier entry x
         const uint32_t LPR = 1u << PD.lpr_log2, G = 64u >> PD.lpr_log2, g = lane >> PD.lpr_log2, t = lane & (LPR - 1u);
         for (uint32_t r0 = 0; r0 < kept; r0 += G) {
             const uint32_t row = r0 + g; const bool act = row < kept;
-            const uint32_t base = act ? rsD[row] : 0u, ln = act ? len[row] : 0u;
+            const uint32_t base = act ? (uint32_t)S.rsd[row] : 0u, ln = act ? len[row] : 0u;
             const bool have = t < ln;
             const uint32_t cy = have ? col[base + t] : 0u, vy = have ? val[base + t] : 0u;
             for (uint32_t x = 0; x + 1u < R; ++x) {
@@ -275,7 +289,7 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
     }
     if (__ballot(bad)) { if (lane == 0) atomicMax(errw, (uint32_t)ERR_TABLE); return 0; }
     KP_T(3);
-    const uint64_t r2 = run_candidate<false>(PD, reg, rsD, ps, lane, errw);
+    const uint64_t r2 = run_candidate<false>(PD, reg, S.rsd, ps, lane, errw);
     KP_T(4);
 #ifdef PLO_KM_PROFILE
     if (lane == 0) { for (int q_ = 0; q_ < 5; ++q_) atomicAdd(&g_kprof[q_], kp_acc[q_]); atomicAdd(&g_kprof[5], 1ull); }
@@ -286,7 +300,7 @@ __device__ uint64_t kmethod_candidate(const KPlan &K, uint8_t *reg, uint8_t *scr
 __device__ __forceinline__ void kmethod_stage_rs(const KPlan &K, uint64_t *lds64) {
     const uint32_t rwM = K.PM.rs_bytes >> 3, rwD = K.PD.rs_bytes >> 3, twM = K.PM.tmpl_bytes >> 3;
     for (uint32_t i = threadIdx.x; i < rwM; i += blockDim.x) lds64[i] = K.PM.tmpl[twM + i];
-    for (uint32_t i = threadIdx.x; i < rwD; i += blockDim.x) lds64[rwM + i] = K.rsD[i];
+    if (K.rsD) for (uint32_t i = threadIdx.x; i < rwD; i += blockDim.x) lds64[rwM + i] = K.rsD[i];
     __syncthreads();
 }
 

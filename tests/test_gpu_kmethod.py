@@ -93,6 +93,18 @@ def test_a_full_pair_table_is_repeated_with_more_slots(hip, monkeypatch):
     assert [(a, mu) + i for a, mu, i in zip(adds, muls, info)] == [M.kernel_restart(seed0 + k) for k in range(n)]
 
 
+def test_more_entries_than_sampled_is_repeated_with_the_hard_bound(hip, monkeypatch):
+    """Dep's arrays are sized from the entry counts of a sample of the decompositions (rows packed per restart); a restart with more
+    entries is reported by the device and the launch repeated with rows x rank (here the first size is forced 8 times too small)."""
+    from plinopt_amd import kernel_search
+    monkeypatch.setenv("PLO_KMETHOD_ENT_DIV", "8")
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), P)
+    n, seed0 = 100, 3
+    adds, muls, info, best, st = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, seed0, n)
+    assert [(a, mu) + i for a, mu, i in zip(adds, muls, info)] == [M.kernel_restart(seed0 + k) for k in range(n)]
+    assert st["launches"] >= 3                                # sizing + undersized + repeated
+
+
 @pytest.mark.parametrize("prime", [7, 101, 2147483647])
 @pytest.mark.parametrize("name", ["4x4x4_48_rational_L.sms", "3x3x6_40_L.sms", "2x2x2_7_DPS-accurate_L.sms"])
 def test_other_moduli(hip, name, prime):
