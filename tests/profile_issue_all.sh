@@ -6,7 +6,7 @@ TAG=${1:-r03b}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
-for WL in winograd cyclic 4x4x4_L 4x4x4_P kmethod tril cob; do
+for WL in ${WORKLOADS:-winograd cyclic 4x4x4_L 4x4x4_P kmethod tril cob}; do
   OUT=$R/gpurun_out/prof_${TAG}_${WL}
   mkdir -p $OUT
   ARGS="--workload $WL --no-cpu-baseline --steps 2 --warmup 0"
