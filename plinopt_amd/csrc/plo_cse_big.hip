@@ -686,9 +686,6 @@ __device__ __forceinline__ void defer_merge(const BigPlan &P, uint8_t *ws, BigSh
                 BSYNC();
                 PLO_BSTAMP(0);
                 if (pn < Pn) first4(pn, (uint32_t)__builtin_amdgcn_readlane((int)cTn, 0)); else { f0 = f1 = f2 = f3 = 0ull; }
-                // (most live triples have frequency 2..5: counted in a packed register, 8 bits each, and added to the histogram once per wave --
-                // 3000 atomic adds of a group on the same four LDS words serialise)
-                uint32_t hsmall = 0;
                 for (uint32_t s = tid; s < (1u << lb); s += nth) {
                     const uint64_t v = ltab[s];
                     if (v == PLO_LEMPTY) continue;
@@ -696,19 +693,10 @@ __device__ __forceinline__ void defer_merge(const BigPlan &P, uint8_t *ws, BigSh
                     if (cb < PLO_DBIAS + 2u) continue;                       // frequency below 2: never chosen, never rises -- dropped
                     const uint32_t c = cb - PLO_DBIAS; const uint64_t k = v >> 16;
                     if (c > P.maxf0) { wg_max(&sh.errflag, (uint32_t)BERR_FREQ); continue; }
-                    if (c < 6u) hsmall += 1u << ((c - 2u) << 3); else wg_add(&hist[c], 1u);
+                    wg_add(&hist[c], 1u);
                     const uint32_t j = dpart(k, pbits) - p;
                     const uint32_t idx = j < 64u ? wg_add(&sh.outcnt[j], 1u) : capp;
                     if (idx < capp) store[(uint64_t)(p + j) * rcap + idx] = (k << 16) | 0x8000ull | c; else { wg_max(&sh.errflag, (uint32_t)BERR_TABLE); wg_max(&sh.derr, 104u); }
-                }
-                {   // at most 16 slots per thread: a byte per level holds a thread's count; wave sums of the bytes (two at a time in 16-bit fields)
-                    uint32_t lo = hsmall & 0x00FF00FFu, hi = (hsmall >> 8) & 0x00FF00FFu;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { lo += (uint32_t)__shfl_xor((int)lo, o); hi += (uint32_t)__shfl_xor((int)hi, o); }
-                    if (lane == 0u) {
-                        if (lo & 0xFFFFu) wg_add(&hist[2], lo & 0xFFFFu); if (hi & 0xFFFFu) wg_add(&hist[3], hi & 0xFFFFu);
-                        if (lo >> 16) wg_add(&hist[4], lo >> 16); if (hi >> 16) wg_add(&hist[5], hi >> 16);
-                    }
                 }
                 BSYNC();
                 PLO_BSTAMP(1);
