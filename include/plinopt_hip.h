@@ -88,7 +88,8 @@ int plo_cse_plan_is_hbm(const plo_plan_t *plan);
  * out[0] CSE steps (OneSub iterations, include/plinopt_optimize.inl:237-312), [1] full pair-table scans,
  * [2] frequency-level rebuilds, [3] tie picks (:260-265) resolved by bisection on the key (more ties in one
  * column than the LDS list holds), [4] pairs that went through the spill list (no room in the LDS aggregation
- * table), [5] sweeps whose claimed-slot list overflowed, [6] candidates, [7] reserved. */
+ * table), [5] sweeps whose claimed-slot list overflowed, [6] candidates, [7] how often the plan was rebuilt with the eager
+ * pair table because a candidate outgrew the structures of the deferred updates (sized from the input's triples). */
 int plo_cse_plan_hbm_counters(const plo_plan_t *plan, uint32_t out[8]);
 int plo_cse_plan_destroy(plo_plan_t *plan);
 

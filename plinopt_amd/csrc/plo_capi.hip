@@ -91,6 +91,9 @@ struct plo_plan {
     bool big = false;
     plo::BigPlan B{};
     std::vector<void *> big_bufs;          // shared immutable device buffers
+    bool big_no_defer = false;             // a launch with deferred updates ran out of room in one of their structures: this plan keeps the eager table
+    uint32_t big_refits = 0;               // how often that happened (plo_cse_plan_hbm_counters)
+    uint32_t big_cap_scale = 1;            // eager table: slots = scale x (2 x initial triples of frequency >= 2), x4 whenever a candidate fills it
     void *d_ws = nullptr; uint64_t ws_slices = 0;
     unsigned long long *d_next = nullptr; uint32_t *d_stats = nullptr;
     uint32_t big_lds = 0;
@@ -302,7 +305,7 @@ int build_big_plan(plo_plan *pl)
     const uint32_t multcap = (uint32_t)std::min<uint64_t>((uint64_t)naive / 2 + 8, NC);
     uint64_t cap = 1024;
     // load <= 0.5 at the start: the retirement of a pruned triple probes to the first empty slot, and dead slots are not empty
-    while (cap < 2ull * keys.size() + 1024ull || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;
+    while (cap < (uint64_t)pl->big_cap_scale * (2ull * keys.size() + 1024ull) || cap < 2ull * nnz + 2ull * multcap + 64ull) cap <<= 1;
     if (const char *e = getenv("PLO_BIG_HBITS")) { const long hb = strtol(e, nullptr, 10); if (hb >= 10 && hb <= 30 && (1ull << hb) > keys.size() + keys.size() / 8) cap = 1ull << hb; }   // experiment knob
     const uint32_t hbits = ceil_log2((uint32_t)std::min<uint64_t>(cap, 1ull << 31));
     if (cap > (1ull << 30)) return fail(PLO_E_CAPACITY, "pair table above 2^30 slots");
@@ -322,7 +325,7 @@ int build_big_plan(plo_plan *pl)
       std::sort(ls.begin(), ls.end(), std::greater<uint32_t>());
       for (uint32_t i = 0; i < m && i < maxf; ++i) topsum += ls[i]; }
     std::vector<uint64_t> st0; std::vector<uint32_t> pc0;
-    if (B.prune && !getenv("PLO_BIG_EAGER")) {
+    if (B.prune && !getenv("PLO_BIG_EAGER") && !pl->big_no_defer) {
         uint32_t pbits = 0; while ((keys.size() >> pbits) > 1280u && pbits < 11u) ++pbits;
         const uint32_t Pn = 1u << pbits;
         pc0.assign(Pn, 0u);
@@ -497,6 +500,30 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
                     hs[24], hs[25], hs[26], hs[27], hs[16], hs[17], hs[18], hs[19], hs[20], hs[21], hs[22], hs[23], hs[28], hs[29], hs[30], hs[31]);
 #endif
         }
+    }
+    if (err == plo::BERR_TABLE && !pl->B.defer && pl->big_cap_scale < 256u) {
+        // eager table full: the live triples of frequency >= 2 can outnumber the input's (new columns pair with every column of the rows
+        // they enter); four times the slots and again (the workspace grows, fewer candidates are resident)
+        pl->big_cap_scale *= 4u; ++pl->big_refits;
+        for (void *d : pl->big_bufs) (void)hipFree(d);
+        pl->big_bufs.clear();
+        if (pl->d_ws) { (void)hipFree(pl->d_ws); pl->d_ws = nullptr; pl->ws_slices = 0; }
+        const int rc = build_big_plan(pl);
+        if (rc != PLO_OK) return rc;
+        return launch_big(pl, J, st);
+    }
+    if (err == plo::BERR_TABLE && pl->B.defer && !pl->big_no_defer) {
+        // The structures of the deferred updates are sized from the INPUT's triples (a partition's live triples: its initial share + 25 %;
+        // the log and the hot table from the longest rows); a candidate whose live triples grow beyond that -- random dense matrices
+        // with few distinct values do (tests/soak_hbm.py) -- is reported by the device.  The plan is rebuilt with the eager table of
+        // round 2 (sized for every pair instance of the input, dead slots reclaimed) and the launch repeated: same results, slower.
+        pl->big_no_defer = true; ++pl->big_refits;
+        for (void *d : pl->big_bufs) (void)hipFree(d);
+        pl->big_bufs.clear();
+        if (pl->d_ws) { (void)hipFree(pl->d_ws); pl->d_ws = nullptr; pl->ws_slices = 0; }
+        const int rc = build_big_plan(pl);
+        if (rc != PLO_OK) return rc;
+        return launch_big(pl, J, st);
     }
     if (err) {
         static const char *names[] = {"pair table", "frequency/row-count mismatch", "column bound", "level list", "window list", "multiplier list", "tie selection", "ProgramGen"};
@@ -695,7 +722,8 @@ int plo_cse_plan_hbm_counters(const plo_plan_t *pl, uint32_t out[8])
     if (!pl->big || !pl->d_stats) return fail(PLO_E_UNSUPPORTED, "the counters belong to the HBM-resident kernel family");
     uint32_t hs[64];
     HIPCHK(hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; ++k) out[k] = hs[32 + k];
+    for (int k = 0; k < 7; ++k) out[k] = hs[32 + k];
+    out[7] = pl->big_refits;
     return PLO_OK;
 }
 

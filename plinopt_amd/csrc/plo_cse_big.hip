@@ -139,6 +139,11 @@ __device__ __forceinline__ uint32_t binv(uint32_t x, uint32_t p, uint64_t mu, ui
 __device__ __forceinline__ bool babsone(uint32_t e, uint32_t p) { return e == 1u || e == p - 1u; }
 __device__ __forceinline__ uint32_t babs(uint32_t e, uint32_t p) { uint32_t a = e ? p - e : 0u; return a < e ? a : e; }
 
+// An insertion that has not found its key, an empty or a dead slot after this many probes reports the table full (the callers set
+// BERR_TABLE, the host rebuilds the plan with four times the slots): at the loads the table is planned for no probe sequence comes
+// near it, and a table that is really full -- a candidate whose live triples outgrow the input's (tests/soak_hbm.py) -- must not cost
+// 2^22 dependent memory round trips per key (seconds each: the launch looked hung).  Lookups end at the first empty slot.
+#define PLO_GPROBE_INS 16384u
 // frequency[key] -= 1; returns the frequency before (0 = key not found: corruption)
 __device__ __forceinline__ uint32_t gtab_dec(uint64_t *tab, uint64_t key, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
@@ -155,7 +160,7 @@ __device__ __forceinline__ uint32_t gtab_dec(uint64_t *tab, uint64_t key, uint32
 __device__ __forceinline__ uint32_t gtab_inc(uint64_t *tab, uint64_t key, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
     uint32_t s = ghash(key, hbits);
-    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+    for (uint32_t pr = 0; pr < PLO_GPROBE_INS; ++pr) {
         uint64_t v = gload64(&tab[s]);
         if ((v >> PLO_GVB) == key) { uint64_t old = wg_add((unsigned long long *)&tab[s], 1ull); return (uint32_t)(old & PLO_GVMASK) + 1u; }
         if ((v & PLO_GVMASK) == 0ull) {
@@ -182,7 +187,7 @@ __device__ __forceinline__ uint32_t gtab_find(const uint64_t *tab, uint64_t key,
 __device__ __forceinline__ bool gtab_add(uint64_t *tab, uint64_t key, uint32_t incv, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
     uint32_t s = ghash(key, hbits);
-    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+    for (uint32_t pr = 0; pr < PLO_GPROBE_INS; ++pr) {
         uint64_t v = gload64(&tab[s]);
         if (v == PLO_GEMPTY) {
             uint64_t old = wg_cas((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | incv));
@@ -199,7 +204,7 @@ __device__ __forceinline__ bool gtab_add(uint64_t *tab, uint64_t key, uint32_t i
 __device__ __forceinline__ bool gtab_flag(uint64_t *tab, uint64_t key, uint32_t flag, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
     uint32_t s = ghash(key, hbits);
-    for (uint32_t pr = 0; pr < (1u << 22); ++pr) {
+    for (uint32_t pr = 0; pr < PLO_GPROBE_INS; ++pr) {
         uint64_t v = gload64(&tab[s]);
         if (v == PLO_GEMPTY) {
             uint64_t old = wg_cas((unsigned long long *)&tab[s], (unsigned long long)v, (unsigned long long)((key << PLO_GVB) | flag));
@@ -237,7 +242,7 @@ __device__ __forceinline__ uint32_t gtab_subn(uint64_t *tab, uint64_t key, uint3
 __device__ __forceinline__ uint32_t gtab_addn(uint64_t *tab, uint64_t key, uint32_t d, uint32_t hbits) {
     const uint32_t mask = (1u << hbits) - 1u;
     uint32_t s = ghash(key, hbits);
-    for (uint32_t pr = 0; pr < (1u << 22); pr += PLO_GWIN) {
+    for (uint32_t pr = 0; pr < PLO_GPROBE_INS; pr += PLO_GWIN) {
         uint64_t v[PLO_GWIN];
 #pragma unroll
         for (uint32_t j = 0; j < PLO_GWIN; ++j) v[j] = gload64(&tab[(s + j) & mask]);
@@ -265,7 +270,7 @@ template <int N> __device__ __forceinline__ void gtab_addnN(uint64_t *tab, const
     uint32_t s[N]; bool pend[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) { s[q] = ghash(key[q], hbits); pend[q] = live[q]; o[q] = 0xFFFFFFFFu; }
-    for (uint32_t pr = 0; pr < (1u << 22); pr += PLO_GWIN) {
+    for (uint32_t pr = 0; pr < PLO_GPROBE_INS; pr += PLO_GWIN) {
         bool any = false;
 #pragma unroll
         for (int q = 0; q < N; ++q) any |= pend[q];

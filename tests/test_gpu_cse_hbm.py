@@ -98,3 +98,47 @@ def test_tiny_aggregation_table_takes_the_spill_path(hip, name, monkeypatch):
     M = OracleMatrix.from_sms(os.path.join(DATA, name), P)
     plan = _plan(M)
     assert plan.cost_many(seed0=11, n=150) == tuple(M.cost_many(seed0=11, nseeds=150, nthreads=8))
+
+
+def _soak_case(s):
+    """random matrix number s of tests/soak_hbm.py"""
+    import random
+    rng = random.Random(7000 + s)
+    m, n = rng.randint(150, 400), rng.randint(150, 320)
+    dens = rng.choice([0.2, 0.35, 0.5])
+    vals = [1, P - 1] + [rng.randint(2, P - 2) for _ in range(rng.randint(0, 3))]
+    rows = [{j: rng.choice(vals) for j in range(n) if rng.random() < dens} for _ in range(m)]
+    return m, n, [r if r else {0: 1} for r in rows]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("case,refits", [(5, 1), (164, 2), (1, 0)])
+def test_candidates_that_outgrow_the_planned_structures(hip, tmp_path, case, refits):
+    """The structures of the deferred updates (and the eager pair table behind them) are sized from the INPUT's triples.  On random dense
+    matrices with few distinct values the live triples of a candidate outgrow that (found by tests/soak_hbm.py: a fatal "pair table"
+    error, and with the eager table an insertion that probed 2^22 slots per key -- the launch looked hung).  The device reports it, the plan
+    is rebuilt (eager table, then four times its slots) and the launch repeated: costs equal the build's scalable host engine
+    (`bin/optimizer --replay`, which prints the oracle's text wherever the oracle can walk), seed by seed."""
+    import re
+    import subprocess
+    from plo_testlib import ROOT
+    from plinopt_amd import CSEPlan
+    m, n, rows = _soak_case(case)
+    rp, c, v = synth.to_csr(rows, P)
+    plan = CSEPlan(m, n, rp, c, v, P, hbm=True)
+    got = plan.cost_many(seed0=case * 10, n=3)
+    assert plan.hbm_counters()["eager_refits"] == refits
+    plan.close()
+    path = tmp_path / "m.sms"
+    with open(path, "w") as f:
+        f.write("%d %d M\n" % (m, n))
+        for i, r in enumerate(rows):
+            for j in sorted(r):
+                f.write("%d %d %d\n" % (i + 1, j + 1, r[j] if r[j] <= P // 2 else r[j] - P))
+        f.write("0 0 0\n")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+    for k in range(3):
+        r = subprocess.run([os.path.join(ROOT, "bin", "optimizer"), "-q", str(P), "--gpu", "0", "--replay", "--seed", str(case * 10 + k), str(path)], capture_output=True, text=True, timeout=120)
+        a, mu = int(re.search(r"# (\d+)\tadditions", r.stderr).group(1)), int(re.search(r"# (\d+)\tmultiplications", r.stderr).group(1))
+        assert (got[0][k], got[1][k]) == (a, mu), (case, k)
+
