@@ -663,11 +663,18 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
             plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
             plo_best_t b{}; plo_stats_t st{};
             int rc = L.cse_search(&A, q, seed0, loops, PLO_COST_SUM_THEN_ADD, &b, &st);
-            if (rc != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: GPU search failed (" << rc << "): " << L.last_error() << "\033[0m" << std::endl; return 2; }
-            dops = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
-            if (verbose > 0)
-                std::clog << "# GPU: " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms, "
-                          << (st.kernel_ms > 0 ? st.candidates / (st.kernel_ms * 1e-3) : 0.0) << " candidates/s" << std::endl;
+            if (rc == PLO_E_CAPACITY || rc == PLO_E_UNSUPPORTED) {
+                // a limit of the device kernels for this input (e.g. a column whose non +-1 entries span more than 64 rows in ProgramGen): said
+                // aloud, and the same restarts run on the host (as -K and bin/sparsifier do when the device refuses)
+                std::clog << "# -D on the GPU refused (" << L.last_error() << "): host search" << std::endl;
+                on_gpu = false;
+            } else if (rc != PLO_OK) { ++g_failures, std::cerr << "# \033[1;31mERROR: GPU search failed (" << rc << "): " << L.last_error() << "\033[0m" << std::endl; return 2; }
+            else {
+                dops = {b.adds, b.muls}; seed = b.seed; have = loops > 0;
+                if (verbose > 0)
+                    std::clog << "# GPU: " << st.candidates << " candidates, kernel " << st.kernel_ms << " ms, "
+                              << (st.kernel_ms > 0 ? st.candidates / (st.kernel_ms * 1e-3) : 0.0) << " candidates/s" << std::endl;
+            }
             L.shutdown();
         }
         if (!on_gpu) {

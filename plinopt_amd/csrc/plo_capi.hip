@@ -528,7 +528,9 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     if (err) {
         static const char *names[] = {"pair table", "frequency/row-count mismatch", "column bound", "level list", "window list", "multiplier list", "tie selection", "ProgramGen"};
         uint32_t site = 0; (void)hipMemcpy(&site, pl->d_stats + 43, sizeof site, hipMemcpyDeviceToHost);
-        return fail(err == plo::BERR_COLS || err == plo::BERR_DM || err == plo::BERR_HL ? PLO_E_CAPACITY : PLO_E_INTERNAL,
+        // BERR_PGEN: ProgramGen's Triangle keeps the rows of a column one per lane (more than 64 rows with a non +-1 entry in one column), or its
+        // multiset does not fit the table region: a limit of this build, not an inconsistency -- the tools then search on the host
+        return fail(err == plo::BERR_COLS || err == plo::BERR_DM || err == plo::BERR_HL ? PLO_E_CAPACITY : err == plo::BERR_PGEN ? PLO_E_UNSUPPORTED : PLO_E_INTERNAL,
                     std::string("device (HBM variant): ") + (err >= 11 && err <= 18 ? names[err - 11] : "unknown") + " error " + std::to_string(err) + (site ? " (site " + std::to_string(site) + ")" : ""));
     }
     return PLO_OK;

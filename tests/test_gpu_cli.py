@@ -258,3 +258,27 @@ def test_kernel_method_with_identity_goals_on_gpu(name):
     assert rc0 == 0 and out == out0
     rc, _, err2 = run([CHK, "-q", str(P), "-M", path], stdin=out)
     assert rc == 0 and "SUCCESS" in err2, err2
+
+
+def test_direct_method_refused_by_the_device_runs_on_the_host(tmp_path):
+    """100 rows whose 40 columns are almost full of pairwise different coefficients: after the CSE steps a column still holds a non +-1
+    entry in more than 64 rows, which ProgramGen's Triangle on the device (one row per lane) does not take -- `PLO_E_UNSUPPORTED`, not an
+    internal error (found by tests/soak_hbm.py).  `bin/optimizer -D` says so and runs the same restarts on the host: same program as
+    `--gpu 0`, and it verifies."""
+    import random
+    rng = random.Random(5)
+    path = tmp_path / "dense.sms"
+    with open(path, "w") as f:
+        f.write("100 40 M\n")
+        for i in range(100):
+            for j in range(40):
+                if rng.random() < 0.9:
+                    f.write("%d %d %d\n" % (i + 1, j + 1, rng.randint(2, 60000)))
+        f.write("0 0 0\n")
+    rc, out, err = run([OPT, "-q", str(P), "--only", "D", "-O", "6", "--seed", "3", str(path)])
+    assert rc == 0 and "# -D on the GPU refused (" in err and "host search" in err, err
+    rc0, out0, err0 = run([OPT, "-q", str(P), "--only", "D", "-O", "6", "--seed", "3", "--gpu", "0", str(path)])
+    assert rc0 == 0 and out == out0
+    rc, _, err2 = run([CHK, "-q", str(P), "-M", str(path)], stdin=out)
+    assert rc == 0 and "SUCCESS" in err2, err2
+
