@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak of the LDS-resident wave kernel against the CPU oracle (run on the GPU box: python tests/soak_wave.py [seconds]):
-random matrices of up to 64 x 64 (rows of at most 64 entries; +-1 only with up to 200 rows) over several moduli, 24 seeds each,
+random matrices of up to 64 x 64 (rows of at most 64 entries; +-1 only with up to 200 rows) over several moduli, 8 seeds each,
 bit-exact (adds, muls) per seed; a capacity refusal of the wave kernel (-> the HBM family) is counted, not an error."""
 import os
 import random
@@ -27,12 +27,15 @@ while time.time() - t0 < budget:
     vals = [1, p - 1] if unit else [1, p - 1] + [rng.randint(2, p - 2) % p or 1 for _ in range(rng.choice([1, 3, 30]))]
     rows = [{j: rng.choice(vals) for j in range(n) if rng.random() < dens} for _ in range(m)]
     rows = [r if r else {0: 1} for r in rows]
+    if sum(len(r) for r in rows) > 700:                         # (the literal oracle rescans the pair map at every step)
+        s += 1
+        continue
     rp, c, v = synth.to_csr(rows, p)
     M = OracleMatrix(m, n, rp, c, v, p)
     try:
         plan = CSEPlan(m, n, rp, c, v, p)
         hbm += 1 if plan.is_hbm else 0
-        got = plan.cost_many(seed0=s, n=24)
+        got = plan.cost_many(seed0=s, n=8)
         plan.close()
     except Exception as e:
         if getattr(e, "code", 0) in (capi.PLO_E_CAPACITY, capi.PLO_E_UNSUPPORTED):
@@ -40,7 +43,7 @@ while time.time() - t0 < budget:
             s += 1
             continue
         raise
-    exp = tuple(M.cost_many(seed0=s, nseeds=24, nthreads=8))
+    exp = tuple(M.cost_many(seed0=s, nseeds=8, nthreads=8))
     ran += 1
     if got != exp:
         bad += 1
