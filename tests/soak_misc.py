@@ -75,4 +75,33 @@ while time.time() - t0 < budget:                                # ---- in-place 
         bad += 1
         print("MISMATCH trilinear case", s - 1, m, na, nb, nc, unit, flush=True)
 print("# trilinear: %d triples, %d refused; total mismatches %d in %.0f s" % (ran2, refused2, bad, time.time() - t0), flush=True)
+if "--cob" in sys.argv:                                         # ---- change-of-basis enumeration (and its batch entry)
+    from plo_testlib import oracle_cob_search
+    from plinopt_amd import cob_search, cob_search_batch
+    ran3 = 0
+    t1 = time.time()
+    while time.time() - t1 < budget / 2:
+        rng = random.Random(13000 + s); s += 1
+        n, m = rng.randint(1, 13), rng.randint(1, 70)
+        row = rng.randint(0, n - 1); off = (row // 4) * 4
+        probs = []
+        for _ in range(rng.randint(1, 4)):
+            p = rng.choice([7, 101, 131071, 2147483629, 2147483647])
+            TM = [rng.choice([0, 0, 1, p - 1, 2, 3, 5]) % p for _ in range(n * m)]
+            Cand = [0] * (n * n)
+            for i in range(row):
+                for j in range(n):
+                    Cand[i * n + j] = rng.choice([0, 0, 1, p - 1, 2]) % p
+            C = rng.randint(1, 9)
+            coeffs = [0, 1, p - 1, 2 % p, (p - 2) % p, 3 % p, pow(2, -1, p), (p - pow(2, -1, p)) % p, 5 % p][:C]
+            w0 = rng.choice([-1, 0, m // 2, m])
+            probs.append((TM, Cand, coeffs, p, w0, 0 if w0 >= 0 else -1))
+        exp = [oracle_cob_search(n, m, TM, Cand, row, off, coeffs, p, w0, w1) for (TM, Cand, coeffs, p, w0, w1) in probs]
+        got, _ = cob_search_batch(n, m, row, off, probs)
+        one = [cob_search(n, m, TM, Cand, row, off, coeffs, p, w0, w1)[0] for (TM, Cand, coeffs, p, w0, w1) in probs]
+        ran3 += 1
+        if got != exp or one != exp:
+            bad += 1
+            print("MISMATCH CoB case", s - 1, n, m, row, flush=True)
+    print("# CoB: %d groups of 1-4 enumerations (single and batched launches), total mismatches %d" % (ran3, bad), flush=True)
 sys.exit(1 if bad else 0)
