@@ -104,4 +104,31 @@ if "--cob" in sys.argv:                                         # ---- change-of
             bad += 1
             print("MISMATCH CoB case", s - 1, n, m, row, flush=True)
     print("# CoB: %d groups of 1-4 enumerations (single and batched launches), total mismatches %d" % (ran3, bad), flush=True)
+if "--enum" in sys.argv:                                        # ---- schedule enumeration (-E) and the chained candidates of -G
+    from plinopt_amd import CSEPlan, CSEChain
+    ran4 = ran5 = 0
+    t1 = time.time()
+    while time.time() - t1 < budget / 2:
+        rng = random.Random(14000 + s); s += 1
+        p = rng.choice([7, 131071, 2147483629])
+        m, n = rng.randint(2, 14), rng.randint(2, 12)
+        vals = [1, p - 1] if rng.random() < 0.5 else [1, p - 1, 2 % p or 1, 3 % p or 1]
+        rows = [{j: rng.choice(vals) for j in range(n) if rng.random() < 0.5} for _ in range(m)]
+        rows = [r if r else {0: 1} for r in rows]
+        rp, c, v = synth.to_csr(rows, p)
+        M = OracleMatrix(m, n, rp, c, v, p)
+        try:
+            plan = CSEPlan(m, n, rp, c, v, p)
+            first = rng.choice([0, 0, 17, 1000])
+            got = plan.enum_cost_many(first, 96)
+            plan.close()
+        except capi.PloError as e:
+            if e.code in (capi.PLO_E_CAPACITY, capi.PLO_E_UNSUPPORTED):
+                continue
+            raise
+        ran4 += 1
+        if got != tuple(M.enum_cost_many(first, 96, nthreads=8)):
+            bad += 1
+            print("MISMATCH enumeration case", s - 1, m, n, p, flush=True)
+    print("# schedule enumeration: %d matrices x 96 schedules, total mismatches %d" % (ran4, bad), flush=True)
 sys.exit(1 if bad else 0)
