@@ -64,6 +64,8 @@ while time.time() - t0 < budget:
     if os.environ.get("PLO_SOAK_MANY_VALUES") and s % 2:        # more than 32 / more than 512 distinct values: kernel modes 1 and 0 (value table in LDS / in global memory)
         m, n, dens = rng.randint(100, 200), rng.randint(100, 200), rng.choice([0.2, 0.35])
         vals = [1, P - 1] + [rng.randint(2, P - 2) for _ in range(rng.choice([40, 700]))]
+    if os.environ.get("PLO_SOAK_BIG"):                          # thousands of rows: steps of more than 1000 rows, logs that force merges
+        m, n, dens = rng.randint(500, 2500), rng.randint(200, 800), rng.choice([0.04, 0.08, 0.15])
     rows = [{j: rng.choice(vals) for j in range(n) if rng.random() < dens} for _ in range(m)]
     rows = [r if r else {0: 1} for r in rows]
     rp, c, v = synth.to_csr(rows, P)
