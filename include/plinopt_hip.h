@@ -108,9 +108,10 @@ int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nsee
  * bin/optimizer --gpu N uses), one host thread and one device per shard (devices[k], or 0..ndev-1 when devices is NULL;
  * the same ordinal may be listed twice), each thread with its own stream and plan; the result is the minimum under the
  * total order (cmpOpCount key of include/plinopt_optimize.h:53-64, seed) -- what the `#pragma omp critical` of
- * include/plinopt_optimize.inl:1214-1237 keeps.  stats->kernel_ms is the slowest shard's kernel time.  The exchange is ndev
- * 16-byte results on the host (inside one process there is nothing for RCCL to move; across processes bench.py and
- * plinopt_amd/dist.py reduce the same word with one RCCL MIN all-reduce). */
+ * include/plinopt_optimize.inl:1214-1237 keeps.  stats->kernel_ms is the slowest shard's kernel time.  With two or more
+ * distinct devices the minimum also goes through ONE RCCL MIN all-reduce of the shards' packed words over a communicator of the
+ * devices (librccl loaded at run time; PLO_MULTI_REDUCE=host|rccl overrides) and must equal the host minimum; stats->reduce says
+ * whether it ran.  Across processes bench.py and plinopt_amd/dist.py reduce the same word with one RCCL MIN all-reduce. */
 int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode,
                          int ndev, const int *devices, plo_best_t *out, plo_stats_t *stats);
 
@@ -147,7 +148,7 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
  * oracle/plo_oracle.c plo_oracle_kernel_restart), then Optimizer() on Free and on Dep from one random stream (:1322-1333).
  * per_block > 1: the restarts of a block of per_block consecutive seeds share the decomposition of the block's first seed.
  * adds/muls (nrestarts entries), info (3 per restart: rank, NotIndep, number of dependent rows computed through Dep) and best may each be NULL.
- * M needs at most 64 rows and 64 columns and a kernel of positive dimension (PLO_E_UNSUPPORTED otherwise: the caller
+ * M needs at most 128 rows, 64 columns, 64 dependent rows and a kernel of positive dimension (PLO_E_UNSUPPORTED otherwise: the caller
  * falls back to host decompositions + plo_cse_chain_batch). */
 int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t nrestarts, uint32_t per_block, int cost_mode,
                       uint32_t *adds, uint32_t *muls, uint32_t *info, plo_best_t *best, plo_stats_t *stats);
