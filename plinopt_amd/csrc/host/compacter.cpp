@@ -2,30 +2,21 @@
 // bin/compacter -- post-pass on the straight-line program of the single winner
 // (reference src/compacter.cpp:27-68 `Compacter`, include/plinopt_programs.inl:
 // 1157-1455 `variablesTrimer`; every reference pipeline reads
-// `optimizer | compacter -s | SLPchecker`, bin/FDT.sh:58, Makefile:79-80).
-// Same contract, this build's own rewriting (tokens, not the reference's text
-// surgery): until nothing changes (or -O # rounds)
-//   * no-ops and dead temporaries are removed,
-//   * a variable that is only a copy of another one (`t3:=i3;`, `t9:=r4;`) is
-//     replaced by it everywhere,
-//   * with -s (default; -n switches it off) a temporary used exactly once is
-//     written in place of its use, its top-level signs folded into the use's sign
-//     and parentheses added only where a product or a quotient needs them,
-//   * a leading minus is rotated behind a positive term (`x:=-a+b;` -> `x:=b-a;`).
-// None of the rewrites adds a counted operation (`lineOperations`,
-// plinopt_programs.inl:116-133: a sign after `:=` or `(` is not an addition), and
-// the program computes the same outputs; the statistics line is the reference's
-// ("# N elements instead of M").  Host only: it runs once, on one program.
+// `optimizer | compacter -s | SLPchecker`, bin/FDT.sh:58, Makefile:79-80, and
+// bin/GDT.sh:41-65 pins the operation count of its output on the stored programs).
+// Prints the reference's text: the engine (plo_trim.hpp) follows variablesTrimer pass by
+// pass and is held line by line to the literal restatement oracle/plo_compact_oracle.py.
+// Statistics on stderr as the reference ("# N elements instead of M" per round).
+// Host only: it runs once, on one program.
 // Usage: compacter [-s|-n] [-O #] [stdin|file.slp]
 // ===========================================================================
-#include "plo_compact.hpp"
-
-using namespace plo;
-using namespace plo::compact;
+#include "plo_trim.hpp"
+#include <fstream>
+#include <iostream>
 
 int main(int argc, char **argv)
 {
-    bool simplSingle = true; std::string filename; size_t numloops = 0; char ouv = 'o';
+    bool simplSingle = true; std::string filename; size_t numloops = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
         if (a == "-h") {
@@ -39,14 +30,15 @@ int main(int argc, char **argv)
         else filename = a;
     }
     try {
-        std::vector<Line> P;
-        if (filename.empty()) P = parse(std::cin);
-        else { std::ifstream in(filename); if (!in) return -1; P = parse(in); }
-        const size_t PVs = prog_size(P);
+        plo::trim::Engine E;
+        plo::trim::Prog P;
+        if (filename.empty()) P = plo::trim::parse(std::cin, E.W);
+        else { std::ifstream in(filename); if (!in) return 0; P = plo::trim::parse(in, E.W); }
+        const size_t PVs = plo::trim::elements(P);
         std::clog << std::string(40, '#') << std::endl;
-        compact_program(P, simplSingle, letter_outputs(ouv), numloops);
-        print(std::cout, P);
-        std::clog << "# \033[1;32m" << prog_size(P) << "\telements\tinstead of " << PVs << "\033[0m" << std::endl;
+        E.run(P, simplSingle, numloops, &std::clog);
+        plo::trim::print(std::cout, P, E.W);
+        std::clog << "# \033[1;32m" << plo::trim::elements(P) << "\telements\tinstead of " << PVs << "\033[0m" << std::endl;
         std::clog << std::string(40, '#') << std::endl;
     } catch (const std::exception &e) {
         std::cerr << "# \033[1;31mERROR: " << e.what() << "\033[0m" << std::endl;

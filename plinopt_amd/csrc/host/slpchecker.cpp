@@ -6,19 +6,25 @@
 // reference Makefile:79-80).
 // ===========================================================================
 #include "plo_host.hpp"
+#include "plo_trim.hpp"
 
 using namespace plo;
 
 template <class F> int check(const F &f, const std::string &prg, const std::string &mat)
 {
-    SlpEval<F> ev(f);
+    // as SLPbuilder (src/SLPchecker.cpp:27-45): the whole program is parsed and its operations are counted and printed
+    // BEFORE the matrix is built -- bin/GDT.sh:44 reads these two lines whatever the evaluation says afterwards
+    std::stringstream text;
+    if (prg.empty()) text << std::cin.rdbuf();
+    else { std::ifstream in(prg); if (!in) { std::cerr << "# ERROR: cannot open " << prg << std::endl; return 2; } text << in.rdbuf(); }
     std::pair<size_t, size_t> ops;
-    if (prg.empty()) ops = ev.run(std::cin);
-    else { std::ifstream in(prg); if (!in) { std::cerr << "# ERROR: cannot open " << prg << std::endl; return 2; } ops = ev.run(in); }
+    { trim::Words W; std::istringstream in(text.str()); ops = trim::operations(trim::parse(in, W)); }
     std::clog << std::string(40, '#') << std::endl;
     std::clog << "# \033[1;32m" << ops.first << "\tadditions\033[0m" << std::endl;
     std::clog << "# \033[1;32m" << ops.second << "\tmultiplications\033[0m" << std::endl;
     std::clog << std::string(40, '#') << std::endl;
+    SlpEval<F> ev(f);
+    ev.run(text);
     if (mat.empty()) { auto A = ev.matrix(); write_sms(std::cout, f, A, std::is_same<F, QField>::value ? 'R' : 'M'); return 0; }
     std::ifstream mf(mat);
     if (!mf) { std::cerr << "# ERROR: cannot open " << mat << std::endl; return 2; }
