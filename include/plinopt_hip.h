@@ -55,8 +55,9 @@ typedef struct {
     uint32_t waves_per_wg;   /* candidates in flight per workgroup */
     uint32_t grid;           /* workgroups per launch */
     uint64_t algo_bytes;     /* algorithmic bytes per candidate, B_cand = 8*nnz + 12*P0 + 8 */
-    uint32_t reduce;         /* plo_cse_search_multi: 1 = the minimum over the devices went through one RCCL MIN all-reduce (and equals the host's) */
+    uint32_t reduce;         /* plo_*_search_multi: 1 = the minimum over the devices is the result of the RCCL MIN all-reduce (and equals the host's) */
     uint32_t reserved;
+    double   reduce_seconds; /* plo_*_search_multi: wall time inside the all-reduce (two 8-byte MIN all-reduces; communicator set-up excluded: cached) */
 } plo_stats_t;
 
 /* cost order of the restart loop, include/plinopt_optimize.h:53-64 */
@@ -109,11 +110,17 @@ int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nsee
  * the same ordinal may be listed twice), each thread with its own stream and plan; the result is the minimum under the
  * total order (cmpOpCount key of include/plinopt_optimize.h:53-64, seed) -- what the `#pragma omp critical` of
  * include/plinopt_optimize.inl:1214-1237 keeps.  stats->kernel_ms is the slowest shard's kernel time.  With two or more
- * distinct devices the minimum also goes through ONE RCCL MIN all-reduce of the shards' packed words over a communicator of the
- * devices (librccl loaded at run time; PLO_MULTI_REDUCE=host|rccl overrides) and must equal the host minimum; stats->reduce says
- * whether it ran.  Across processes bench.py and plinopt_amd/dist.py reduce the same word with one RCCL MIN all-reduce. */
+ * DISTINCT devices the minimum is taken by RCCL over a communicator of the devices (librccl loaded at run time, the
+ * communicator kept for the life of the process): one 8-byte MIN all-reduce of the cost key, one of the seed offset among the
+ * shards that hold the minimal key -- the lexicographic minimum whatever the width of the costs.  The host minimum is its check:
+ * a difference is a '#' diagnostic on stderr and the host value is returned.  stats->reduce says whether the all-reduce gave the
+ * result, stats->reduce_seconds its wall time.  PLO_MULTI_REDUCE=host|rccl overrides (rccl: also with one device; then a missing
+ * librccl is an error).  A shard the device refuses (PLO_E_CAPACITY / PLO_E_UNSUPPORTED) makes the call return that code.
+ * Across processes bench.py and plinopt_amd/dist.py reduce the same words with torch.distributed (RCCL). */
 int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode,
                          int ndev, const int *devices, plo_best_t *out, plo_stats_t *stats);
+/* communicators built by this process so far (one per distinct device set: a second call on the same devices builds none) */
+uint64_t plo_multi_comm_inits(void);
 
 /* Same candidates, every (adds, muls) written back: the parity-test entry.
  * seeds == NULL means seed0, seed0+1, ... */
@@ -152,6 +159,12 @@ int plo_cse_chain_batch(uint32_t npairs, const plo_csr_t *firsts, const plo_csr_
  * falls back to host decompositions + plo_cse_chain_batch). */
 int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t nrestarts, uint32_t per_block, int cost_mode,
                       uint32_t *adds, uint32_t *muls, uint32_t *info, plo_best_t *best, plo_stats_t *stats);
+/* The restart loop of KernelOptimiser (include/plinopt_optimize.inl:1299-1340) over `ndev` devices from one process: contiguous
+ * shards of the restart range, one host thread and one device each, minimum under (cmpOpCount key, seed) by the RCCL MIN
+ * all-reduces of plo_cse_search_multi (same conventions for devices, stats->reduce and PLO_MULTI_REDUCE).  per_block must be 1
+ * with more than one device.  BASELINE `bin/optimizer -K --gpu N`. */
+int plo_kernel_search_multi(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t nrestarts, uint32_t per_block, int cost_mode,
+                            int ndev, const int *devices, plo_best_t *best, plo_stats_t *stats);
 
 
 /* Change-of-basis (CoB) search of bin/sparsifier: one (block,row) enumeration of `localSparsifier`,
@@ -226,6 +239,14 @@ void plo_tril_plan_destroy(plo_tril_plan_t *plan);
 /* ops6[6k..6k+5] = ADD,SCA,MUL of variant 0 then of variant 1 for candidate k (seeds[k], or seed0+k when seeds==NULL) */
 int  plo_tril_cost_many(plo_tril_plan_t *plan, const uint64_t *seeds, uint64_t seed0, uint64_t n, uint32_t *ops6, plo_stats_t *stats);
 int  plo_tril_search(plo_tril_plan_t *plan, uint64_t seed0, uint64_t nseeds, plo_tril_best_t *best, plo_stats_t *stats);
+/* The restart loop of SearchTriLinearAlgorithm (include/plinopt_inplace.inl:837-924) over `ndev` devices from one process --
+ * BASELINE configs[3], `bin/trilplacer L R P` seed-sharded over the GPUs of a node with an RCCL MIN: contiguous shards of the seed
+ * range, one host thread, one device and one plan (plo_tril_plan_create_q of the three matrices) each; the winner is the minimum
+ * under (ADD, SCA) (:893-897), then (seed, variant), by the two MIN all-reduces of plo_cse_search_multi: (ADD << 32 | SCA), then
+ * ((seed - seed0) << 1 | variant) among the shards holding the minimal cost.  Same conventions for devices, stats and
+ * PLO_MULTI_REDUCE. */
+int  plo_tril_search_multi(const plo_qcsr_t *A, const plo_qcsr_t *B, const plo_qcsr_t *T, int expanded, uint64_t seed0, uint64_t nseeds,
+                           int ndev, const int *devices, plo_tril_best_t *best, plo_stats_t *stats);
 
 /* Pack / unpack the (cost, seed) word used by the grid reduction and by the
  * single 8-byte MIN all-reduce across ranks (the `#pragma omp critical`

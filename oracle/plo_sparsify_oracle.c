@@ -123,7 +123,7 @@ static int test_lin_comb(int *w0, int *w1, u32 *LCoB, u32 *Cand, u32 num, const 
 }
 
 /* ---- localSparsifier :206-347; TM: n x m, TCoB: n x n, both updated */
-static uint64_t g_candidates;
+static uint64_t g_candidates, g_carried, g_fallbacks;      /* g_carried: candidates evaluated with a coordinate outside their block (the fallback's w[p] = 1 kept by :305) */
 static void local_sparsifier(u32 *TCoB, u32 *TM, u32 n, u32 m, u32 maxnumcoeff)
 {
     u32 *LCoB = xmalloc(sizeof(u32) * (size_t)n * n);
@@ -165,23 +165,29 @@ static void local_sparsifier(u32 *TCoB, u32 *TM, u32 n, u32 m, u32 maxnumcoeff)
     u32 *Coeffs = xmalloc(sizeof(u32) * (maxnumcoeff + 8));
     const u32 C = build_coeffs(Coeffs, TM, n, m, maxnumcoeff);
     const u32 numlargeblocks = n >> 2, lastblock = n - (numlargeblocks << 2), numblocks = lastblock ? numlargeblocks + 1 : numlargeblocks;   /* :274-277 */
-    u32 *A = xmalloc(sizeof(u32) * (size_t)n * n), *w = xmalloc(sizeof(u32) * ((size_t)(numblocks << 2) + n));
+    const u32 multiple = numblocks << 2;                        /* :277 (>= n) */
+    u32 *A = xmalloc(sizeof(u32) * (size_t)n * n), *w = xmalloc(sizeof(u32) * ((size_t)multiple + 4));
     for (u32 block = 0; block < numblocks; ++block) {
+        memset(w, 0, sizeof(u32) * ((size_t)multiple + 4));     /* w.resize(0); w.resize(multiple) :283 -- ONCE PER BLOCK */
         const u32 off = block << 2, first = n - off < 4 ? n - off : 4;
         for (u32 num = 0; num < first; ++num) {
             memcpy(A, LCoB, sizeof(u32) * (size_t)n * n);       /* matrixCopy(A, LCoB) :288 */
             int w0 = -1, w1 = -1; int found = (block == 0 && num == 0);
             if (found) { w0 = rnHw; w1 = cnHw; }                /* :289-294 */
             for (u32 i = 0; i < C; ++i) for (u32 j = 0; j < C; ++j) for (u32 k = 0; k < C; ++k) for (u32 l = 0; l < C; ++l) {   /* :299-314 */
-                memset(w, 0, sizeof(u32) * ((size_t)(numblocks << 2) + n));
-                w[off] = Coeffs[i]; w[off + 1] = Coeffs[j]; w[off + 2] = Coeffs[k]; w[off + 3] = Coeffs[l];
-                /* w.resize(TM.rowdim()): positions beyond n are dropped */
+                /* w.resize(multiple) :305 zero-fills the positions n.. only: what w holds below n STAYS -- after the canonical
+                 * fallback of an earlier row of this block (below) that is its w[p] = 1, for p outside the block */
+                for (u32 x = n; x < multiple + 4; ++x) w[x] = 0;
+                w[off] = Coeffs[i]; w[off + 1] = Coeffs[j]; w[off + 2] = Coeffs[k]; w[off + 3] = Coeffs[l];      /* :306-309 */
+                /* w.resize(TM.rowdim()) :311: positions beyond n are dropped (test_lin_comb reads n words) */
                 ++g_candidates;
+                for (u32 x = 0; x < n; ++x) if (w[x] && (x < off || x >= off + 4)) { ++g_carried; break; }
                 found |= test_lin_comb(&w0, &w1, LCoB, A, num + off, w, TM, n, m);
             }
             for (u32 pp = 0; !found && pp < n; ++pp) {           /* canonical fallback :317-326 */
                 w0 = -1; w1 = -1;
-                memset(w, 0, sizeof(u32) * n); w[pp] = 1 % P_;
+                memset(w, 0, sizeof(u32) * ((size_t)multiple + 4)); w[pp] = 1 % P_;      /* w.resize(0); w.resize(rowdim); w[p]=1 :320-321 */
+                if (pp == 0) ++g_fallbacks;
                 found |= test_lin_comb(&w0, &w1, LCoB, A, num + off, w, TM, n, m);
             }
         }
@@ -306,7 +312,7 @@ int plo_oracle_sp_local(uint32_t n, uint32_t m, uint32_t *TM, uint32_t *TCoB, ui
 int plo_oracle_sparsify(uint32_t m, uint32_t n, const uint32_t *M, uint32_t p, uint32_t blocksize, uint32_t maxnumcoeff, int initial_elimination,
                         uint32_t *CoB, uint32_t *Res, uint64_t *candidates)
 {
-    P_ = p; g_candidates = 0;
+    P_ = p; g_candidates = 0; g_carried = 0; g_fallbacks = 0;
     int rc = 0;
     if (blocksize <= 1) { rc = sparse_alternate(CoB, Res, M, m, n, maxnumcoeff) ? 0 : 1; if (candidates) *candidates = g_candidates; return rc; }
     u32 *U = xmalloc(sizeof(u32) * (size_t)n * m), *L = xmalloc(sizeof(u32) * (size_t)n * n);
@@ -336,3 +342,9 @@ int plo_oracle_sparsify(uint32_t m, uint32_t n, const uint32_t *M, uint32_t p, u
     if (candidates) *candidates = g_candidates;
     return rc;
 }
+
+/* how many candidates of the last plo_oracle_sparsify call carried a coordinate outside their block (tests: the fixture that
+ * pins plinopt_sparsify.inl:305 must make this positive) */
+uint64_t plo_oracle_sparsify_carried(void) { return g_carried; }
+/* how many rows of the last call were filled by the canonical fallback (:317-326) */
+uint64_t plo_oracle_sparsify_fallbacks(void) { return g_fallbacks; }

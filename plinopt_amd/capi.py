@@ -18,7 +18,7 @@ PLAN_HBM = 1
 EXPORTS = [
     "plo_init", "plo_shutdown", "plo_last_error", "plo_device_count",
     "plo_cse_plan_create", "plo_cse_plan_create_ex", "plo_cse_plan_is_hbm", "plo_cse_plan_hbm_counters", "plo_cse_plan_destroy",
-    "plo_cse_search_plan", "plo_cse_search", "plo_cse_search_multi",
+    "plo_cse_search_plan", "plo_cse_search", "plo_cse_search_multi", "plo_multi_comm_inits", "plo_kernel_search_multi", "plo_tril_search_multi",
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch", "plo_kernel_search",
     "plo_cse_enum_cost_many_plan", "plo_cse_enum_search_plan",
@@ -45,7 +45,7 @@ class Stats(ctypes.Structure):
                 ("candidates", ctypes.c_uint64), ("launches", ctypes.c_uint32),
                 ("lds_bytes", ctypes.c_uint32), ("waves_per_wg", ctypes.c_uint32),
                 ("grid", ctypes.c_uint32), ("algo_bytes", ctypes.c_uint64),
-                ("reduce", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("reduce", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("reduce_seconds", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -142,6 +142,11 @@ def lib():
         L.plo_tril_plan_destroy.restype = None
         L.plo_tril_cost_many.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_uint64, u32p, ctypes.POINTER(Stats)]
         L.plo_tril_search.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(TrilBest), ctypes.POINTER(Stats)]
+        L.plo_kernel_search_multi.argtypes = [ctypes.POINTER(CSR), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                              ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(Best), ctypes.POINTER(Stats)]
+        L.plo_tril_search_multi.argtypes = [ctypes.POINTER(QCSR), ctypes.POINTER(QCSR), ctypes.POINTER(QCSR), ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
+                                            ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(TrilBest), ctypes.POINTER(Stats)]
+        L.plo_multi_comm_inits.restype = ctypes.c_uint64
         L.plo_pack_cost.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
         L.plo_pack_cost.restype = ctypes.c_uint64
         _lib = L

@@ -46,6 +46,7 @@ struct HipLib {
     decltype(&plo_cse_enum_search_plan) enum_search = nullptr;
     decltype(&plo_cse_chain_batch) chain_batch = nullptr;
     decltype(&plo_kernel_search) kernel_search = nullptr;   // optional: -K with the decompositions on the device
+    decltype(&plo_kernel_search_multi) kernel_search_multi = nullptr;   // optional: the same over N devices from this process
     bool load(const char *argv0) {
         std::vector<std::string> cand;
         for (const char *v : {"PLO_HIP_LIB", "PLINOPT_HIP_LIB"}) if (const char *e = getenv(v)) cand.emplace_back(e);   // (one name for the tools and plinopt_amd/capi.py; the older one still works)
@@ -63,6 +64,7 @@ struct HipLib {
         enum_search = (decltype(enum_search))dlsym(h, "plo_cse_enum_search_plan");
         chain_batch = (decltype(chain_batch))dlsym(h, "plo_cse_chain_batch");
         kernel_search = (decltype(kernel_search))dlsym(h, "plo_kernel_search");
+        kernel_search_multi = (decltype(kernel_search_multi))dlsym(h, "plo_kernel_search_multi");
         return init && last_error && cse_search && shutdown && chain_create && chain_search && chain_destroy && plan_create && plan_destroy && enum_search && chain_batch;
     }
 };
@@ -237,7 +239,7 @@ template <class F> std::string kernel_text(const F &f, const KernelDecomp<F> &kd
 // seeds: block d uses the decomposition drawn from its first seed, and every seed of the block is one run of the two
 // Optimizer calls on it (the reference draws a new decomposition for every restart; with a per-restart elimination on
 // the host the GPU would idle).  Returns false when the method could not run.
-struct KShard { bool done = false; Ops ops; uint64_t seed = 0, ncand = 0; double kms = 0; int shards = 0; } g_kshard;   // -K searched by --gpu N shards (main) before this process touched the HIP runtime
+struct KShard { bool done = false; Ops ops; uint64_t seed = 0, ncand = 0; double kms = 0; int shards = 0; std::string how; } g_kshard;   // -K searched by the --gpu N shards (run(): plo_kernel_search_multi, or forked children with --fork-shards)
 bool g_host_decomp = false;        // --host-decomp: -K eliminates on the host and ships the images (plo_cse_chain_batch)
 uint64_t g_kernel_block = 1;      // restarts per decomposition (--kernel-block; the reference draws one decomposition per restart, :1299-1340)
 #define PLO_KERNEL_BLOCK g_kernel_block
@@ -313,7 +315,7 @@ template <class F> bool kernel_method(const F &f, const SparseMat<typename F::El
     if (g_kshard.done) {                                               // searched by N forked shards, one device each (main): only the replay is left
         best = g_kshard.ops; seed = g_kshard.seed; bdec = seed; have = true; kms = g_kshard.kms; ncand = g_kshard.ncand; d = nblocks; on_device = true;
         g_kshard.done = false;
-        if (verbose > 0) std::clog << "# " << g_kshard.shards << " shards (one GPU each): -K" << std::endl;
+        if (verbose > 0) std::clog << "# " << g_kshard.shards << " shards (" << g_kshard.how << "): -K" << std::endl;
     }
     // All of it on the device (plo_kernel_search: the wave of a restart eliminates, builds both images and runs both
     // Optimizer calls): matrices of at most 128 rows and 64 columns with at most 64 dependent rows.  --host-decomp keeps the decompositions on the host (round-1 path).
@@ -540,13 +542,22 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         std::clog << "# -K/-G/-A/-N skipped: host elimination of a " << lM.rowdim() << 'x' << lM.coldim() << " matrix is not attempted (use -D)" << std::endl;
         tryAB = tryKernel = tryLU = allkernels = false;
     }
-    // --gpu N, N >= 2: the direct method's seed range in N contiguous shards, one forked child and one device per shard,
-    // minimum under (cmpOpCount, seed) in the parent -- before anything in this process touches the HIP runtime.
+    // --gpu N, N >= 2: the seed range of -D and of -K in N contiguous shards, the minimum under (cmpOpCount, seed).
+    // Default: ONE process, one host thread and one device per shard inside the library (plo_cse_search_multi,
+    // plo_kernel_search_multi), the minimum by RCCL MIN all-reduces -- the seed space sharded over the GPUs of the node as
+    // north_star names it; this process forks nothing.  --fork-shards (and the host-engine test knob) keep one forked child per
+    // device instead: every fork happens here, BEFORE anything in this process touches the HIP runtime (a runtime does not
+    // survive fork), and the library's multi-device entries are not used at all then.
     struct { bool done = false; Ops ops; uint64_t seed = 0; } sharded;
-    // Default since round 3: ONE process, one host thread and one device per shard inside the library (plo_cse_search_multi) -- the
-    // seed space sharded over the GPUs of the node as north_star names it; --fork-shards keeps the forked children (one process per
-    // device), which is also what the host-engine test knob uses.
-    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0 && !g_fork_shards && !(getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host")) {
+    const bool shard_host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob: every shard on the host engine
+    const bool use_forks = g_fork_shards || shard_host_engine;
+    bool d_refused = false;                                 // the device refused -D's plan: the restarts run on the host, said aloud
+    auto reduce_note = [](const plo_stats_t &st) {
+        std::ostringstream os;
+        if (st.reduce) os << ", minimum by RCCL MIN all-reduce in " << st.reduce_seconds * 1e3 << " ms"; else os << ", minimum on the host";
+        return os.str();
+    };
+    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0 && !use_forks) {
         HipLib L;
         if (!L.load(argv0) || !L.cse_search_multi) { ++g_failures; std::cerr << "# \033[1;31mERROR: shard failed: libplinopt_hip.so " << (L.cse_search ? "lacks plo_cse_search_multi" : "cannot be loaded") << "\033[0m" << std::endl; return 2; }
         std::vector<uint32_t> rp(1, 0), cc, vv;
@@ -555,12 +566,17 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
         plo_best_t b{}; plo_stats_t st{};
         const int rc = L.cse_search_multi(&A, q, seed0, loops, PLO_COST_SUM_THEN_ADD, gpu, devs.data(), &b, &st);
-        if (rc != PLO_OK) { ++g_failures; std::cerr << "# \033[1;31mERROR: shard failed: " << L.last_error() << "\033[0m" << std::endl; return 2; }
-        sharded.ops = {b.adds, b.muls}; sharded.seed = b.seed; sharded.done = b.seed != ~0ull;
-        if (verbose > 0) std::clog << "# " << gpu << " shards (one GPU and one host thread each, one process): " << st.candidates << " candidates, slowest kernel " << st.kernel_ms << " ms" << (st.reduce ? ", minimum by one RCCL MIN all-reduce" : ", minimum on the host") << std::endl;
+        if (rc == PLO_E_CAPACITY || rc == PLO_E_UNSUPPORTED) {                          // as one device does: a limit of the kernels for this input
+            std::clog << "# -D on the GPUs refused (" << L.last_error() << "): host search" << std::endl;
+            d_refused = true;
+        } else if (rc != PLO_OK) { ++g_failures; std::cerr << "# \033[1;31mERROR: shard failed: " << L.last_error() << "\033[0m" << std::endl; return 2; }
+        else {
+            sharded.ops = {b.adds, b.muls}; sharded.seed = b.seed; sharded.done = b.seed != ~0ull;
+            if (verbose > 0) std::clog << "# " << gpu << " shards (one GPU and one host thread each, one process): " << st.candidates << " candidates, slowest kernel " << st.kernel_ms << " ms" << reduce_note(st) << std::endl;
+        }
     }
-    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0 && !sharded.done) {
-        const bool host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob: every shard on the host engine
+    if constexpr (std::is_same<F, ZpField>::value) if (tryDirect && q != 0 && gpu >= 2 && loops > 0 && use_forks) {
+        const bool host_engine = shard_host_engine;
         std::vector<uint32_t> rp(1, 0), cc, vv;
         for (auto &r : lM.rows) { for (auto &e : r) { cc.push_back((uint32_t)e.first); vv.push_back((uint32_t)e.second); } rp.push_back((uint32_t)cc.size()); }
         auto shard = [&](int, int device, uint64_t s0, uint64_t cnt) {
@@ -579,31 +595,55 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
             plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
             plo_best_t b{}; plo_stats_t st{};
             const int rc = L.cse_search(&A, q, s0, cnt, PLO_COST_SUM_THEN_ADD, &b, &st);
-            if (rc != PLO_OK) { snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error()); return o; }
+            if (rc != PLO_OK) { o.rc = rc; snprintf(o.msg, sizeof o.msg, "device %d: %s", device, L.last_error()); return o; }
             o.ok = 1; o.a = b.adds; o.b = b.muls; o.seed = b.seed; o.candidates = st.candidates; o.kernel_ms = st.kernel_ms;
             L.shutdown();
             return o;
         };
         std::vector<ShardOut> outs;
         if (!forked_shards(gpu, seed0, loops, shard, outs)) {
-            for (auto &o : outs) if (!o.ok) ++g_failures, std::cerr << "# \033[1;31mERROR: shard failed: " << o.msg << "\033[0m" << std::endl;
-            return 2;
+            bool refused = true;
+            for (auto &o : outs) if (!o.ok && o.rc != PLO_E_UNSUPPORTED && o.rc != PLO_E_CAPACITY) refused = false;
+            if (!refused) {
+                for (auto &o : outs) if (!o.ok) ++g_failures, std::cerr << "# \033[1;31mERROR: shard failed: " << o.msg << "\033[0m" << std::endl;
+                return 2;
+            }
+            std::clog << "# -D on the GPUs refused (" << outs[0].msg << "): host search" << std::endl;
+            d_refused = true;
+        } else {
+            bool have = false; uint64_t total = 0; double kmax = 0;
+            for (auto &o : outs) {
+                total += o.candidates; kmax = std::max(kmax, o.kernel_ms);
+                if (o.a == 0xFFFFFFFFu && o.b == 0xFFFFFFFFu) continue;
+                const Ops ops{o.a, o.b};
+                if (!have || cmp_op_count(ops, sharded.ops) || (!cmp_op_count(sharded.ops, ops) && o.seed < sharded.seed)) { sharded.ops = ops; sharded.seed = o.seed; have = true; }
+            }
+            sharded.done = have;
+            if (verbose > 0) std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one forked process and one GPU each)") << ": " << total << " candidates, slowest kernel " << kmax << " ms" << std::endl;
         }
-        bool have = false; uint64_t total = 0; double kmax = 0;
-        for (auto &o : outs) {
-            total += o.candidates; kmax = std::max(kmax, o.kernel_ms);
-            if (o.a == 0xFFFFFFFFu && o.b == 0xFFFFFFFFu) continue;
-            const Ops ops{o.a, o.b};
-            if (!have || cmp_op_count(ops, sharded.ops) || (!cmp_op_count(sharded.ops, ops) && o.seed < sharded.seed)) { sharded.ops = ops; sharded.seed = o.seed; have = true; }
-        }
-        sharded.done = have;
-        if (verbose > 0) std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one GPU each)") << ": " << total << " candidates, slowest kernel " << kmax << " ms" << std::endl;
     }
     // the same for -K (decompositions on the device, one per restart): N shards of the restart range
-    if constexpr (std::is_same<F, ZpField>::value) if (tryKernel && !kfi && q != 0 && gpu >= 2 && loops > 0 && !g_host_decomp && g_kernel_block == 1 && lM.rowdim() <= 128 && lM.coldim() <= 64) {
+    if constexpr (std::is_same<F, ZpField>::value) if (tryKernel && !kfi && q != 0 && gpu >= 2 && loops > 0 && !g_host_decomp && g_kernel_block == 1 && lM.rowdim() <= 128 && lM.coldim() <= 64 && !shard_host_engine) {
         KernelDecomp<F> kd0;
         if (kernel_decomp(f, lM, seed0, kd0)) {                                       // (a zero dimensional kernel is reported by kernel_method)
             std::vector<uint32_t> rp, cc, vv; to_csr(lM, rp, cc, vv);
+            if (!use_forks) {
+                HipLib L;
+                if (!L.load(argv0) || !L.kernel_search_multi) { ++g_failures; std::cerr << "# \033[1;31mERROR: -K shard failed: libplinopt_hip.so " << (L.cse_search ? "lacks plo_kernel_search_multi" : "cannot be loaded") << "\033[0m" << std::endl; return 2; }
+                std::vector<int> devs((size_t)gpu); for (int r = 0; r < gpu; ++r) devs[(size_t)r] = shard_device(r);
+                plo_csr_t A{(uint32_t)lM.rowdim(), (uint32_t)lM.coldim(), rp.data(), cc.data(), vv.data()};
+                plo_best_t b{}; plo_stats_t st{};
+                const int rc = L.kernel_search_multi(&A, q, seed0, loops, 1u, PLO_COST_SUM_THEN_ADD, gpu, devs.data(), &b, &st);
+                if (rc == PLO_E_UNSUPPORTED || rc == PLO_E_CAPACITY) {
+                    // a plan the device refuses (state beyond LDS, table bounds) is what the single-device path answers with host
+                    // decompositions + the batched chain kernel: leave the method to kernel_method then
+                    if (verbose > 0) std::clog << "# -K: the device refused the one-wave restart (" << L.last_error() << "): host decompositions + batched chain kernel on one device" << std::endl;
+                } else if (rc != PLO_OK) { ++g_failures; std::cerr << "# \033[1;31mERROR: -K shard failed: " << L.last_error() << "\033[0m" << std::endl; return 2; }
+                else if (b.seed != ~0ull) {
+                    g_kshard.ops = {b.adds, b.muls}; g_kshard.seed = b.seed; g_kshard.ncand = st.candidates; g_kshard.kms = st.kernel_ms; g_kshard.done = true; g_kshard.shards = gpu;
+                    g_kshard.how = "one GPU and one host thread each, one process" + reduce_note(st);
+                }
+            } else {
             auto shard = [&](int, int device, uint64_t s0, uint64_t cnt) {
                 ShardOut o{};
                 if (cnt == 0) { o.ok = 1; o.a = o.b = 0xFFFFFFFFu; return o; }
@@ -620,8 +660,6 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
             std::vector<ShardOut> outs;
             bool kshards_ok = forked_shards(gpu, seed0, loops, shard, outs), refused = false;
             if (!kshards_ok) {
-                // A shard whose plan the device refuses (PLO_E_UNSUPPORTED / PLO_E_CAPACITY: state beyond LDS, table bounds) is what the
-                // single-device path answers with host decompositions + the batched chain kernel: leave the method to kernel_method then.
                 refused = true;
                 for (auto &o : outs) if (!o.ok && o.rc != PLO_E_UNSUPPORTED && o.rc != PLO_E_CAPACITY) refused = false;
                 if (!refused) {
@@ -638,7 +676,8 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
                 const Ops ops{o.a, o.b};
                 if (!have || cmp_op_count(ops, g_kshard.ops) || (!cmp_op_count(g_kshard.ops, ops) && o.seed < g_kshard.seed)) { g_kshard.ops = ops; g_kshard.seed = o.seed; have = true; }
             }
-            g_kshard.done = have; g_kshard.shards = gpu;
+            g_kshard.done = have; g_kshard.shards = gpu; g_kshard.how = "one forked process and one GPU each";
+            }
         }
     }
     if (tryAB) {                                                                      // :1436-1440 (inner dimension = column count)
@@ -653,7 +692,7 @@ int run(const F &f, const QMat &MQ, size_t loops, uint64_t seed0, int gpu, bool 
         Ops dops; uint64_t seed = 0; bool have = false;
         bool on_gpu = false;
         if (sharded.done) { on_gpu = true; dops = sharded.ops; seed = sharded.seed; have = loops > 0; }
-        if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0 && !sharded.done) {
+        if constexpr (std::is_same<F, ZpField>::value) if (q != 0 && gpu > 0 && !sharded.done && !d_refused) {
             on_gpu = true;
             HipLib L;
             if (!L.load(argv0)) return 2;

@@ -25,6 +25,7 @@ struct HipTril {
     void *h = nullptr;
     decltype(&plo_init) init = nullptr; decltype(&plo_last_error) last_error = nullptr;
     decltype(&plo_tril_plan_create_q) create = nullptr; decltype(&plo_tril_plan_destroy) destroy = nullptr; decltype(&plo_tril_search) search = nullptr;
+    decltype(&plo_tril_search_multi) search_multi = nullptr;
     bool load() {
         std::vector<std::string> cand;
         for (const char *v : {"PLO_HIP_LIB", "PLINOPT_HIP_LIB"}) if (const char *e = getenv(v)) cand.emplace_back(e);   // (one name for the tools and plinopt_amd/capi.py; the older one still works)
@@ -35,7 +36,7 @@ struct HipTril {
         if (!h) { std::cerr << "# \033[1;31mERROR: cannot load libplinopt_hip.so: " << dlerror() << "\033[0m\n"; return false; }
         init = (decltype(init))dlsym(h, "plo_init"); last_error = (decltype(last_error))dlsym(h, "plo_last_error");
         create = (decltype(create))dlsym(h, "plo_tril_plan_create_q"); destroy = (decltype(destroy))dlsym(h, "plo_tril_plan_destroy");
-        search = (decltype(search))dlsym(h, "plo_tril_search");
+        search = (decltype(search))dlsym(h, "plo_tril_search"); search_multi = (decltype(search_multi))dlsym(h, "plo_tril_search_multi");
         return init && last_error && create && destroy && search;
     }
 };
@@ -59,14 +60,15 @@ int main(int argc, char **argv) {
 #ifdef _OPENMP
     if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(std::min(omp_get_max_threads(), 64));   // cgroup-limited boxes report all host cores
 #endif
-    size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; bool expanded = false; std::vector<std::string> files;
+    size_t loops = 30; uint64_t seed0 = 0; int gpu = 1; bool expanded = false, fork_shards = false; std::vector<std::string> files;
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
-        if (a == "-h") { std::clog << "Usage: " << argv[0] << " L.sms R.sms P.sms [-O #] [--seed s] [--gpu 0|1|N: N >= 2 shards the restarts over N GPUs]\n"; return 0; }
+        if (a == "-h") { std::clog << "Usage: " << argv[0] << " L.sms R.sms P.sms [-e] [-O #] [--seed s] [--gpu 0|1|N: N >= 2 shards the restarts over N GPUs] [--fork-shards]\n"; return 0; }
         else if (a == "-O" && i + 1 < argc) loops = (size_t)atoll(argv[++i]);
         else if (a == "--seed" && i + 1 < argc) seed0 = strtoull(argv[++i], nullptr, 10);
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
         else if (a == "-m") { }        // reference: selects the Maple check of an INPLACE_CHECKER build (src/trilplacer.cpp:79,155); nothing to do here
+        else if (a == "--fork-shards") fork_shards = true;   // --gpu N with one forked child per device instead of one host thread per device inside the library
         else if (a == "-e") expanded = true;           // src/trilplacer.cpp:80,114-137: double-size products, two entries of c per AXPY
         else files.push_back(a);
     }
@@ -117,10 +119,28 @@ int main(int argc, char **argv) {
                 }
                 return lb;
             };
+            const bool host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob: every shard on the host loop
             try {
-                if (gpu >= 2 && (device_ok || (getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host"))) {
-                    // --gpu N: N contiguous seed shards, one forked child and one device each; minimum under Key in the parent
-                    const bool host_engine = getenv("PLO_SHARD_ENGINE") && std::string(getenv("PLO_SHARD_ENGINE")) == "host";   // test knob
+                if (gpu >= 2 && device_ok && !fork_shards && !host_engine) {
+                    // --gpu N (BASELINE configs[3]): N contiguous seed shards over N devices from THIS process -- one host thread, one
+                    // device and one plan per shard inside the library, the minimum under Key by RCCL MIN all-reduces (plo_tril_search_multi)
+                    HipTril L;
+                    if (!L.load() || !L.search_multi) throw std::runtime_error("libplinopt_hip.so cannot be loaded or lacks plo_tril_search_multi");
+                    plo_qcsr_t a{(uint32_t)A.rowdim(), (uint32_t)A.coldim(), ca.rp.data(), ca.col.data(), ca.num.data(), ca.den.data()};
+                    plo_qcsr_t b{(uint32_t)B.rowdim(), (uint32_t)B.coldim(), cb.rp.data(), cb.col.data(), cb.num.data(), cb.den.data()};
+                    plo_qcsr_t t{(uint32_t)T.rowdim(), (uint32_t)T.coldim(), ct.rp.data(), ct.col.data(), ct.num.data(), ct.den.data()};
+                    std::vector<int> devs((size_t)gpu); for (int r = 0; r < gpu; ++r) devs[(size_t)r] = shard_device(r);
+                    plo_tril_best_t r{}; plo_stats_t st{};
+                    if (L.search_multi(&a, &b, &t, expanded ? 1 : 0, seed0, loops, gpu, devs.data(), &r, &st) != PLO_OK) throw std::runtime_error(L.last_error());
+                    on_gpu = true; kms = st.kernel_ms;
+                    std::clog << "# " << gpu << " shards (one GPU and one host thread each, one process)";
+                    if (st.reduce) std::clog << ", minimum by RCCL MIN all-reduce in " << st.reduce_seconds * 1e3 << " ms"; else std::clog << ", minimum on the host";
+                    std::clog << std::endl;
+                    const Tricount g{r.add, r.sca, r.mul};
+                    if (better(g, best)) { best = g; bseed = r.seed; bvar = (int)r.variant; }
+                } else if (gpu >= 2 && (device_ok || host_engine)) {
+                    // --gpu N --fork-shards: one forked child and one device per shard (every fork before this process touches the HIP
+                    // runtime); minimum under Key in the parent
                     auto shard = [&](int, int device, uint64_t s0, uint64_t cnt) {
                         ShardOut o{};
                         if (cnt == 0) { o.ok = 1; o.a = o.b = 0xFFFFFFFFu; return o; }
@@ -142,7 +162,7 @@ int main(int argc, char **argv) {
                     Key lb{~(size_t)0, ~(size_t)0, 0, 0}; uint32_t mul = (uint32_t)A.rowdim();
                     for (auto &o : outs) { if (o.a == 0xFFFFFFFFu && o.b == 0xFFFFFFFFu) continue; const Key k{o.a, o.b, o.seed, (int)o.variant}; if (k < lb) { lb = k; mul = o.c; } kms = std::max(kms, o.kernel_ms); }
                     on_gpu = !host_engine;
-                    std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one GPU each)") << std::endl;
+                    std::clog << "# " << gpu << " shards" << (host_engine ? " (host engine)" : " (one forked process and one GPU each)") << std::endl;
                     const Tricount g{std::get<0>(lb), std::get<1>(lb), mul};
                     if (better(g, best)) { best = g; bseed = std::get<2>(lb); bvar = std::get<3>(lb); }
                 } else if (gpu && device_ok) {

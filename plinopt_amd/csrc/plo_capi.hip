@@ -22,7 +22,10 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <functional>
+#include <array>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -404,6 +407,7 @@ int build_big_plan(plo_plan *pl)
     B.o_len = take((uint64_t)m * 4); B.o_ucount = take(NC * 4); B.o_cntM = take(NC * 4);
     B.o_dm = take((uint64_t)B.dmcap * 8); B.o_hl = take((uint64_t)B.hlcap * 16); B.o_aff = take((uint64_t)m * 32);
     B.o_ncrptr = take((NC + 2) * 4); B.o_ncr = take(((uint64_t)nnz + 64) * 4);
+    B.o_tl = take(((uint64_t)nnz + 64) * 4); B.o_clen = take(NC * 4); B.o_keep = take(((uint64_t)m + 64) * 4);
     B.o_multc = take((uint64_t)multcap * 4); B.o_multv = take((uint64_t)multcap * 4);
     B.o_tcnt = take(NC * 4); B.o_tptr2 = take((NC + 2) * 4); B.o_tlist = take(((uint64_t)nnz + 64) * 4); B.o_cols2 = take(NC * 4); B.o_spill = take(((uint64_t)nnz + 64) * 8);
     B.ws_stride = off;
@@ -494,7 +498,8 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
                 for (int c_ = 0; c_ < 4; ++c_) { fprintf(stderr, "#   rows/step %-8s ms per candidate: level %.1f select %.1f rows %.1f sweep %.1f flush1 %.1f flush2 %.1f tail %.1f\n", cls[c_],
                     g2[c_ * 8 + 0] / 1e5 / g2[32], g2[c_ * 8 + 1] / 1e5 / g2[32], g2[c_ * 8 + 2] / 1e5 / g2[32], g2[c_ * 8 + 3] / 1e5 / g2[32], g2[c_ * 8 + 4] / 1e5 / g2[32], (g2[c_ * 8 + 6] + g2[c_ * 8 + 5]) / 1e5 / g2[32], g2[c_ * 8 + 7] / 1e5 / g2[32]); } } }
             { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[3]) fprintf(stderr, "#   sweep of the steps with >= 256 rows, all candidates: %llu trips by %llu wave-sweeps; cycles per trip: chunk wait + stores %.0f, aggregation of both chunks %.0f, rest of the loop %.0f; per wave-sweep %.0f cycles, %.1f trips; probe rounds per trip %.2f, active lanes per trip %.1f\n", gp[3], gp[5], (double)gp[0] / gp[3], (double)gp[1] / gp[3], (double)gp[2] / gp[3], (double)gp[4] / gp[5], (double)gp[3] / gp[5], (double)gp[6] / gp[3], (double)gp[7] / gp[3]); }
-            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && (gp[14] || gp[15])) fprintf(stderr, "#   flush 1, all candidates: entries whose pair with a has a as SECOND column %llu, with b %llu\n", gp[14], gp[15]); }
+            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[3] && pl->B.defer && pl->B.mode == 2u) fprintf(stderr, "#   aggregation of a trip (lane 0 of every wave, big steps), cycles: ratio-id lookup %.0f, pair read %.0f, compare-and-swap %.0f, bitmap + count %.0f\n", (double)gp[14] / gp[3], (double)gp[8] / gp[3], (double)gp[9] / gp[3], (double)gp[10] / gp[3]); }
+            { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && (gp[14] || gp[15]) && !pl->B.defer) fprintf(stderr, "#   flush 1, all candidates: entries whose pair with a has a as SECOND column %llu, with b %llu\n", gp[14], gp[15]); }
             { unsigned long long gp[16] = {0}; if (hipMemcpyFromSymbol(gp, HIP_SYMBOL(plo::g_prof), sizeof gp) == hipSuccess && gp[11]) fprintf(stderr, "#   flush 1 of the steps with >= 256 rows: %llu wave-trips by %llu wave-flushes; cycles per trip: fetch + decode %.0f, probe loads %.0f, stores + bookkeeping %.0f; per wave-flush %.0f cycles, %.1f trips\n", gp[11], gp[13], (double)gp[8] / gp[11], (double)gp[9] / gp[11], (double)gp[10] / gp[11], (double)gp[12] / gp[13], (double)gp[11] / gp[13]); }
             fprintf(stderr, "#   steps by rows/step [>=256, 64.., 16.., <16]: %u %u %u %u; sweep1 us %u %u %u %u; sweep2 us %u %u %u %u; fallbacks %u %u; flushed keys %u %u\n",
                     hs[24], hs[25], hs[26], hs[27], hs[16], hs[17], hs[18], hs[19], hs[20], hs[21], hs[22], hs[23], hs[28], hs[29], hs[30], hs[31]);
@@ -672,7 +677,7 @@ int plo_init(int device)
     if (ce != hipSuccess || n <= 0)
         return fail(PLO_E_HIP, std::string("no HIP device visible (") + hipGetErrorString(ce) + "): libplinopt_hip has no CPU fallback");
     if (device < 0 || device >= n) return fail(PLO_E_ARG, "device ordinal out of range");
-    if (g_device == device && g_stream) return PLO_OK;
+    if (g_device == device && g_stream) { HIPCHK(hipSetDevice(device)); return PLO_OK; }      // (the calling thread may have been moved to another device since)
     if (g_device >= 0 && g_device != device) plo_shutdown();          // scratch and stream of the device left behind
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -945,9 +950,13 @@ int plo_cse_search(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nsee
     return rc;
 }
 
-// The restart range in `ndev` contiguous shards, one host thread and one device per shard; the minimum under (cost, seed).
+} // extern "C" (the helpers below are C++)
+// ---- one process, N devices -------------------------------------------------------------------------------------------
+// The restart range in `ndev` contiguous shards, one host thread and one device per shard (thread-local device contexts); the
+// minimum under (cost key, seed) by RCCL MIN all-reduces over a communicator of the devices.  Shared by plo_cse_search_multi,
+// plo_kernel_search_multi and plo_tril_search_multi (below, behind the single-device entries they call).
 namespace {
-// RCCL, loaded at run time (librccl.so.1 of the ROCm installation; no link-time dependency): the MIN all-reduce of plo_cse_search_multi.
+// RCCL, loaded at run time (librccl.so.1 of the ROCm installation; no link-time dependency).
 struct Rccl {
     typedef void *comm_t;
     int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
@@ -966,36 +975,141 @@ struct Rccl {
 Rccl &rccl() { static Rccl r; return r; }
 enum { RCCL_UINT64 = 5, RCCL_MIN = 3 };      // ncclUint64, ncclMin of rccl/rccl.h
 
-// MIN over the devices of one 64-bit word each (one ncclAllReduce per device inside a group, issued by this thread); false when
-// RCCL is not there or a call fails (the caller then reduces on the host -- the result is the same word either way).
-bool rccl_min_u64(const std::vector<int> &devs, std::vector<unsigned long long> &words, std::string &why)
+// The calling thread's current device is put back when a multi-device entry returns (the all-reduce walks the devices with
+// hipSetDevice on the caller's thread; the process-wide context of plo_init still names the caller's device and stream).
+struct DeviceGuard { int dev = -1; DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; } ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); } };
+
+// One communicator per device set for the life of the process (ncclCommInitAll over 8 GPUs takes seconds: not per call), with a
+// stream and a 16-byte buffer per device.  Never destroyed: the HIP runtime may be gone when static destructors run.
+struct CommSet { std::vector<Rccl::comm_t> comms; std::vector<hipStream_t> strm; std::vector<unsigned long long *> dbuf; double init_seconds = 0; };
+std::mutex g_comm_mu;
+std::map<std::vector<int>, CommSet> &comm_cache() { static auto *m = new std::map<std::vector<int>, CommSet>(); return *m; }
+uint64_t g_comm_inits = 0;                    // communicators built so far (tests: a second call on the same devices builds none)
+
+CommSet *comm_for(const std::vector<int> &devs, std::string &why)
+{
+    auto &cache = comm_cache();
+    auto it = cache.find(devs);
+    if (it != cache.end()) return &it->second;
+    Rccl &R = rccl();
+    const int n = (int)devs.size();
+    CommSet cs; cs.comms.assign((size_t)n, nullptr); cs.strm.assign((size_t)n, nullptr); cs.dbuf.assign((size_t)n, nullptr);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool good = R.CommInitAll(cs.comms.data(), n, devs.data()) == 0;
+    if (!good) why = "ncclCommInitAll failed";
+    for (int i = 0; good && i < n; ++i) {
+        good = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipStreamCreateWithFlags(&cs.strm[(size_t)i], hipStreamNonBlocking) == hipSuccess &&
+               hipMalloc((void **)&cs.dbuf[(size_t)i], 16) == hipSuccess;
+        if (!good) why = "device buffer for the all-reduce";
+    }
+    if (!good) {
+        for (int i = 0; i < n; ++i) { if (cs.dbuf[(size_t)i] || cs.strm[(size_t)i]) { (void)hipSetDevice(devs[(size_t)i]); if (cs.dbuf[(size_t)i]) (void)hipFree(cs.dbuf[(size_t)i]); if (cs.strm[(size_t)i]) (void)hipStreamDestroy(cs.strm[(size_t)i]); } if (cs.comms[(size_t)i]) R.CommDestroy(cs.comms[(size_t)i]); }
+        return nullptr;
+    }
+    cs.init_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ++g_comm_inits;
+    return &(cache[devs] = std::move(cs));
+}
+
+// Lexicographic minimum of the devices' (hi, lo) words, left in every w[i]: ONE MIN all-reduce of hi, then one of lo among the
+// ranks that hold the minimal hi (the others contribute all ones) -- the two-stage form of plinopt_amd/dist.py allreduce_best, so
+// that no cost is too wide for the word.  `seconds` = wall time of the two all-reduces (communicator set-up excluded: it is
+// cached).  false when RCCL is not there or a call fails (the caller keeps the host minimum and says so).
+bool rccl_min_pair(const std::vector<int> &devs, std::vector<std::array<unsigned long long, 2>> &w, double &seconds, std::string &why)
 {
     Rccl &R = rccl();
     if (!R.ok) { why = "librccl not loadable"; return false; }
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    CommSet *cs = comm_for(devs, why);
+    if (!cs) return false;
     const int n = (int)devs.size();
-    std::vector<Rccl::comm_t> comms((size_t)n, nullptr);
-    std::vector<unsigned long long *> dbuf((size_t)n, nullptr); std::vector<hipStream_t> strm((size_t)n, nullptr);
-    bool good = R.CommInitAll(comms.data(), n, devs.data()) == 0;
-    if (!good) why = "ncclCommInitAll failed";
-    for (int i = 0; good && i < n; ++i) {
-        good = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipStreamCreateWithFlags(&strm[(size_t)i], hipStreamNonBlocking) == hipSuccess &&
-               hipMalloc((void **)&dbuf[(size_t)i], 8) == hipSuccess && hipMemcpy(dbuf[(size_t)i], &words[(size_t)i], 8, hipMemcpyHostToDevice) == hipSuccess;
-        if (!good) why = "device buffer for the all-reduce";
-    }
-    if (good) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto stage = [&](int k) -> bool {                                              // all-reduce of word k of every device
+        bool good = true;
+        for (int i = 0; good && i < n; ++i) good = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipMemcpyAsync(cs->dbuf[(size_t)i], &w[(size_t)i][(size_t)k], 8, hipMemcpyHostToDevice, cs->strm[(size_t)i]) == hipSuccess;
+        if (!good) { why = "upload of the packed word"; return false; }
         R.GroupStart();
-        for (int i = 0; i < n; ++i) good = good && R.AllReduce(dbuf[(size_t)i], dbuf[(size_t)i], 1, RCCL_UINT64, RCCL_MIN, comms[(size_t)i], strm[(size_t)i]) == 0;
+        for (int i = 0; i < n; ++i) good = R.AllReduce(cs->dbuf[(size_t)i], cs->dbuf[(size_t)i], 1, RCCL_UINT64, RCCL_MIN, cs->comms[(size_t)i], cs->strm[(size_t)i]) == 0 && good;
         good = (R.GroupEnd() == 0) && good;
-        if (!good) why = "ncclAllReduce failed";
-    }
-    for (int i = 0; good && i < n; ++i) {
-        good = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipStreamSynchronize(strm[(size_t)i]) == hipSuccess && hipMemcpy(&words[(size_t)i], dbuf[(size_t)i], 8, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!good) { why = "ncclAllReduce failed"; return false; }
+        for (int i = 0; good && i < n; ++i) good = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipMemcpyAsync(&w[(size_t)i][(size_t)k], cs->dbuf[(size_t)i], 8, hipMemcpyDeviceToHost, cs->strm[(size_t)i]) == hipSuccess && hipStreamSynchronize(cs->strm[(size_t)i]) == hipSuccess;
         if (!good) why = "reading the reduced word";
-    }
-    for (int i = 0; i < n; ++i) { if (dbuf[(size_t)i] || strm[(size_t)i]) { (void)hipSetDevice(devs[(size_t)i]); if (dbuf[(size_t)i]) (void)hipFree(dbuf[(size_t)i]); if (strm[(size_t)i]) (void)hipStreamDestroy(strm[(size_t)i]); } if (comms[(size_t)i]) R.CommDestroy(comms[(size_t)i]); }
+        return good;
+    };
+    std::vector<unsigned long long> hi0((size_t)n);
+    for (int i = 0; i < n; ++i) hi0[(size_t)i] = w[(size_t)i][0];
+    bool good = stage(0);
+    if (good) { for (int i = 0; i < n; ++i) if (hi0[(size_t)i] != w[(size_t)i][0]) w[(size_t)i][1] = ~0ull; good = stage(1); }
+    seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return good;
 }
+
+// what a shard hands back: its best candidate as a (hi, lo) word pair ordered like the search's total order
+struct MultiShard { int rc = PLO_OK; std::string msg; uint64_t s0 = 0, cnt = 0; plo_stats_t st{}; unsigned long long hi = ~0ull, lo = ~0ull; };
+
+// body(shard, device ordinal) runs on its own host thread with its own device context, between plo_init and plo_shutdown
+int multi_run(int ndev, const int *devices, uint64_t seed0, uint64_t nseeds, std::vector<MultiShard> &sh, const std::function<int(MultiShard &, int)> &body)
+{
+    sh.assign((size_t)ndev, MultiShard{});
+    std::vector<std::thread> th;
+    for (int r = 0; r < ndev; ++r) th.emplace_back([&, r]() {
+        MultiShard &S = sh[(size_t)r];
+        const uint64_t q = nseeds / (uint64_t)ndev, rem = nseeds % (uint64_t)ndev;                // the same blocks as the forked shards of the tools
+        S.s0 = seed0 + (uint64_t)r * q + std::min<uint64_t>((uint64_t)r, rem); S.cnt = q + ((uint64_t)r < rem ? 1 : 0);
+        if (S.cnt == 0) return;
+        const int dev = devices ? devices[r] : r;
+        DevCtx ctx; t_ctx = &ctx;                                                                 // this thread's device, stream and limits
+        S.rc = plo_init(dev);
+        if (S.rc == PLO_OK) S.rc = body(S, dev);
+        if (S.rc != PLO_OK) S.msg = "device " + std::to_string(dev) + ": " + g_err;
+        plo_shutdown();
+        t_ctx = nullptr;
+    });
+    for (auto &t : th) t.join();
+    // a refusal (PLO_E_CAPACITY / PLO_E_UNSUPPORTED) is reported as such when every failed shard says so: the caller may fall back
+    for (auto &S : sh) if (S.rc != PLO_OK && S.rc != PLO_E_CAPACITY && S.rc != PLO_E_UNSUPPORTED) return fail(S.rc, S.msg);
+    for (auto &S : sh) if (S.rc != PLO_OK) return fail(S.rc, S.msg);
+    return PLO_OK;
+}
+
+// The minimum of the shards' words: on the host, and -- with two or more DISTINCT devices (PLO_MULTI_REDUCE=rccl: also for one;
+// =host: never) -- by rccl_min_pair over the devices.  The all-reduce result is the one used; the host minimum is its check, and
+// a difference is a diagnostic on stderr with the host minimum kept (never an error: the host value is right by construction).
+// Returns the winning shard (-1: no shard has a candidate); agg gets the summed statistics, `reduce` and the all-reduce time.
+int multi_min(const std::vector<MultiShard> &sh, int ndev, const int *devices, plo_stats_t &agg, int &winner)
+{
+    winner = -1;
+    agg = plo_stats_t{};
+    for (size_t r = 0; r < sh.size(); ++r) {
+        const MultiShard &S = sh[r];
+        if (S.cnt == 0) continue;
+        agg.candidates += S.st.candidates; agg.launches += S.st.launches; agg.kernel_ms = std::max(agg.kernel_ms, S.st.kernel_ms);
+        agg.grid = S.st.grid; agg.lds_bytes = S.st.lds_bytes; agg.waves_per_wg = S.st.waves_per_wg; agg.algo_bytes = S.st.algo_bytes;
+        if (S.hi == ~0ull && S.lo == ~0ull) continue;
+        if (winner < 0 || S.hi < sh[(size_t)winner].hi || (S.hi == sh[(size_t)winner].hi && S.lo < sh[(size_t)winner].lo)) winner = (int)r;
+    }
+    const char *mode = getenv("PLO_MULTI_REDUCE");
+    const bool want = mode ? !strcmp(mode, "rccl") : ndev >= 2;
+    if (!want || winner < 0) return PLO_OK;
+    std::vector<int> devs; std::vector<std::array<unsigned long long, 2>> words;
+    for (int r = 0; r < ndev; ++r) { devs.push_back(devices ? devices[r] : r); words.push_back({sh[(size_t)r].hi, sh[(size_t)r].lo}); }
+    bool distinct = true; for (size_t i = 0; i < devs.size(); ++i) for (size_t j = 0; j < i; ++j) distinct = distinct && devs[i] != devs[j];
+    if (!distinct) return PLO_OK;                                                  // (a communicator needs distinct devices: PLO_GPU_DEVICES=0,0 in the tests)
+    std::string why; double secs = 0;
+    if (rccl_min_pair(devs, words, secs, why)) {
+        agg.reduce = 1; agg.reduce_seconds = secs;
+        for (auto &w : words) if (w[0] != sh[(size_t)winner].hi || w[1] != sh[(size_t)winner].lo) {
+            fprintf(stderr, "# libplinopt_hip: RCCL MIN all-reduce gave (%llx, %llx), the host minimum is (%llx, %llx): host minimum kept\n", w[0], w[1], sh[(size_t)winner].hi, sh[(size_t)winner].lo);
+            agg.reduce = 0; break;
+        }
+    } else if (mode) return fail(PLO_E_HIP, std::string("PLO_MULTI_REDUCE=rccl: ") + why);
+    return PLO_OK;
+}
 } // namespace
+
+extern "C" {
+
+uint64_t plo_multi_comm_inits(void) { return g_comm_inits; }
 
 int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_t nseeds, int cost_mode, int ndev, const int *devices,
                          plo_best_t *out, plo_stats_t *stats)
@@ -1003,59 +1117,23 @@ int plo_cse_search_multi(const plo_csr_t *A, uint32_t p, uint64_t seed0, uint64_
     if (!A || !out) return fail(PLO_E_ARG, "null argument");
     if (ndev < 1 || ndev > 64) return fail(PLO_E_ARG, "device count outside [1,64]");
     if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
-    struct Shard { int rc = PLO_OK; std::string msg; plo_best_t b{}; plo_stats_t st{}; uint64_t cnt = 0; };
-    std::vector<Shard> sh((size_t)ndev);
-    std::vector<std::thread> th;
-    auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < ndev; ++r) th.emplace_back([&, r]() {
-        Shard &S = sh[(size_t)r];
-        const uint64_t q = nseeds / (uint64_t)ndev, rem = nseeds % (uint64_t)ndev;                // the same blocks as the forked shards of the tools
-        const uint64_t s0 = seed0 + (uint64_t)r * q + std::min<uint64_t>((uint64_t)r, rem), cnt = q + ((uint64_t)r < rem ? 1 : 0);
-        S.cnt = cnt; S.b.adds = S.b.muls = 0xFFFFFFFFu; S.b.seed = ~0ull;
-        if (cnt == 0) return;
-        DevCtx ctx; t_ctx = &ctx;                                                                 // this thread's device, stream and limits
-        S.rc = plo_init(devices ? devices[r] : r);
-        if (S.rc == PLO_OK) S.rc = plo_cse_search(A, p, s0, cnt, cost_mode, &S.b, &S.st);
-        if (S.rc != PLO_OK) S.msg = "device " + std::to_string(devices ? devices[r] : r) + ": " + g_err;
-        plo_shutdown();
-        t_ctx = nullptr;
+    DeviceGuard guard;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<MultiShard> sh; std::vector<plo_best_t> bests((size_t)ndev);
+    auto key = [&](const plo_best_t &b) -> unsigned long long {                                   // cmpOpCount orders of plinopt_optimize.h:53-64
+        switch (cost_mode) { case PLO_COST_ADD_THEN_MUL: return ((unsigned long long)b.adds << 32) | b.muls; case PLO_COST_SUM: return ((unsigned long long)b.adds + b.muls) << 32; default: return (((unsigned long long)b.adds + b.muls) << 32) | b.adds; } };
+    int rc = multi_run(ndev, devices, seed0, nseeds, sh, [&](MultiShard &S, int) {
+        plo_best_t &b = bests[(size_t)(&S - sh.data())];
+        const int r_ = plo_cse_search(A, p, S.s0, S.cnt, cost_mode, &b, &S.st);
+        if (r_ == PLO_OK && b.seed != ~0ull) { S.hi = key(b); S.lo = b.seed - seed0; }
+        return r_;
     });
-    for (auto &t : th) t.join();
-    for (auto &S : sh) if (S.rc != PLO_OK) return fail(S.rc, S.msg);
-    auto key = [&](const plo_best_t &b) -> std::pair<uint64_t, uint64_t> {                        // cmpOpCount orders of plinopt_optimize.h:53-64, then the seed
-        switch (cost_mode) { case PLO_COST_ADD_THEN_MUL: return {b.adds, b.muls}; case PLO_COST_SUM: return {(uint64_t)b.adds + b.muls, 0}; default: return {(uint64_t)b.adds + b.muls, b.adds}; } };
-    out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull; bool have = false;
-    plo_stats_t agg{};
-    for (auto &S : sh) {
-        if (S.cnt == 0) continue;
-        agg.candidates += S.st.candidates; agg.launches += S.st.launches; agg.kernel_ms = std::max(agg.kernel_ms, S.st.kernel_ms);
-        agg.grid = S.st.grid; agg.lds_bytes = S.st.lds_bytes; agg.waves_per_wg = S.st.waves_per_wg; agg.algo_bytes = S.st.algo_bytes;
-        if (S.b.seed == ~0ull) continue;
-        if (!have || key(S.b) < key(*out) || (key(S.b) == key(*out) && S.b.seed < out->seed)) { *out = S.b; have = true; }
-    }
-    // The same minimum as ONE RCCL MIN all-reduce over the devices (xGMI): every device contributes its shard's packed word
-    // key << 32 | (seed - seed0) -- the order above when both key fields fit 16 bits and the range 32 -- and every device receives the
-    // winner's.  Default with two or more devices (PLO_MULTI_REDUCE=host keeps the host loop only, =rccl also reduces a single
-    // device's word); the host minimum above is kept as the check: a different word is an error.
-    {
-        const char *mode = getenv("PLO_MULTI_REDUCE");
-        const bool want = mode ? !strcmp(mode, "rccl") : ndev >= 2;
-        bool fits = have && nseeds <= 0xFFFFFFFFull;
-        for (auto &S : sh) if (S.cnt && S.b.seed != ~0ull) fits = fits && key(S.b).first < 65536 && key(S.b).second < 65536;
-        if (want && fits) {
-            std::vector<int> devs; std::vector<unsigned long long> words;
-            for (int r = 0; r < ndev; ++r) { const Shard &S = sh[(size_t)r]; devs.push_back(devices ? devices[r] : r);
-                words.push_back(S.cnt && S.b.seed != ~0ull ? ((unsigned long long)key(S.b).first << 48) | ((unsigned long long)key(S.b).second << 32) | (unsigned long long)(S.b.seed - seed0) : ~0ull); }
-            bool distinct = true; for (size_t i = 0; i < devs.size(); ++i) for (size_t j = 0; j < i; ++j) distinct = distinct && devs[i] != devs[j];
-            std::string why;
-            if (!distinct) agg.reduce = 0;                                           // (a communicator needs distinct devices: PLO_GPU_DEVICES=0,0 in the tests)
-            else if (rccl_min_u64(devs, words, why)) {
-                const unsigned long long mine = ((unsigned long long)key(*out).first << 48) | ((unsigned long long)key(*out).second << 32) | (unsigned long long)(out->seed - seed0);
-                for (unsigned long long w : words) if (w != mine) return fail(PLO_E_HIP, "RCCL MIN all-reduce and host minimum disagree");
-                agg.reduce = 1;
-            } else if (mode) return fail(PLO_E_HIP, "PLO_MULTI_REDUCE=rccl: " + why);
-        }
-    }
+    if (rc != PLO_OK) return rc;
+    plo_stats_t agg{}; int win = -1;
+    rc = multi_min(sh, ndev, devices, agg, win);
+    if (rc != PLO_OK) return rc;
+    out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull;
+    if (win >= 0) *out = bests[(size_t)win];
     agg.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats) *stats = agg;
     return PLO_OK;
@@ -1799,6 +1877,75 @@ int plo_tril_search(plo_tril_plan_t *pl, uint64_t seed0, uint64_t nseeds, plo_tr
     best->add = (uint32_t)(w >> 48); best->sca = (uint32_t)(w >> 32) & 0xFFFFu; best->mul = pl->P.M[0].m;
     best->variant = (uint32_t)(w & 1ull); best->seed = seed0 + ((w & 0xFFFFFFFFull) >> 1);
     st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PLO_OK;
+}
+
+int plo_kernel_search_multi(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t nrestarts, uint32_t per_block, int cost_mode,
+                            int ndev, const int *devices, plo_best_t *out, plo_stats_t *stats)
+{
+    if (!M || !out) return fail(PLO_E_ARG, "null argument");
+    if (ndev < 1 || ndev > 64) return fail(PLO_E_ARG, "device count outside [1,64]");
+    if (cost_mode < 0 || cost_mode > 2) return fail(PLO_E_ARG, "unknown cost mode");
+    if (per_block != 1u && ndev > 1) return fail(PLO_E_ARG, "shards of the kernel method take one decomposition per restart (per_block = 1)");
+    DeviceGuard guard;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<MultiShard> sh; std::vector<plo_best_t> bests((size_t)ndev);
+    auto key = [&](const plo_best_t &b) -> unsigned long long {
+        switch (cost_mode) { case PLO_COST_ADD_THEN_MUL: return ((unsigned long long)b.adds << 32) | b.muls; case PLO_COST_SUM: return ((unsigned long long)b.adds + b.muls) << 32; default: return (((unsigned long long)b.adds + b.muls) << 32) | b.adds; } };
+    int rc = multi_run(ndev, devices, seed0, nrestarts, sh, [&](MultiShard &S, int) {
+        plo_best_t &b = bests[(size_t)(&S - sh.data())];
+        const int r_ = plo_kernel_search(M, p, S.s0, S.cnt, per_block, cost_mode, nullptr, nullptr, nullptr, &b, &S.st);
+        if (r_ == PLO_OK && b.seed != ~0ull) { S.hi = key(b); S.lo = b.seed - seed0; }
+        return r_;
+    });
+    if (rc != PLO_OK) return rc;
+    plo_stats_t agg{}; int win = -1;
+    rc = multi_min(sh, ndev, devices, agg, win);
+    if (rc != PLO_OK) return rc;
+    out->adds = out->muls = 0xFFFFFFFFu; out->seed = ~0ull;
+    if (win >= 0) *out = bests[(size_t)win];
+    agg.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = agg;
+    return PLO_OK;
+}
+
+int plo_tril_search_multi(const plo_qcsr_t *A, const plo_qcsr_t *B, const plo_qcsr_t *T, int expanded, uint64_t seed0, uint64_t nseeds,
+                          int ndev, const int *devices, plo_tril_best_t *best, plo_stats_t *stats)
+{
+    if (!A || !B || !T || !best) return fail(PLO_E_ARG, "null argument");
+    if (ndev < 1 || ndev > 64) return fail(PLO_E_ARG, "device count outside [1,64]");
+    if (nseeds == 0 || nseeds >= (1ull << 62)) return fail(PLO_E_ARG, "1 .. 2^62-1 candidates per call");
+    DeviceGuard guard;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<MultiShard> sh; std::vector<plo_tril_best_t> bests((size_t)ndev);
+    int rc = multi_run(ndev, devices, seed0, nseeds, sh, [&](MultiShard &S, int) {
+        plo_tril_best_t &b = bests[(size_t)(&S - sh.data())];
+        plo_tril_plan_t *plan = nullptr;
+        int r_ = plo_tril_plan_create_q(A, B, T, expanded, &plan);
+        if (r_ != PLO_OK) return r_;
+        // (a launch takes at most 2^31-1 candidates: longer shards go in pieces, minimum under the same order)
+        bool have = false;
+        for (uint64_t done = 0; r_ == PLO_OK && done < S.cnt;) {
+            const uint64_t piece = std::min<uint64_t>(S.cnt - done, (1ull << 31) - 1ull);
+            plo_tril_best_t pb{}; plo_stats_t ps{};
+            r_ = plo_tril_search(plan, S.s0 + done, piece, &pb, &ps);
+            if (r_ != PLO_OK) break;
+            S.st.candidates += ps.candidates; S.st.launches += ps.launches; S.st.kernel_ms += ps.kernel_ms; S.st.grid = ps.grid; S.st.lds_bytes = ps.lds_bytes; S.st.waves_per_wg = ps.waves_per_wg; S.st.algo_bytes = ps.algo_bytes;
+            const unsigned long long hi = ((unsigned long long)pb.add << 32) | pb.sca, lo = ((pb.seed - seed0) << 1) | (pb.variant & 1u);      // the order of include/plinopt_inplace.inl:893-897, then (seed, variant)
+            if (!have || hi < S.hi || (hi == S.hi && lo < S.lo)) { S.hi = hi; S.lo = lo; b = pb; have = true; }
+            done += piece;
+        }
+        plo_tril_plan_destroy(plan);
+        return r_;
+    });
+    if (rc != PLO_OK) return rc;
+    plo_stats_t agg{}; int win = -1;
+    rc = multi_min(sh, ndev, devices, agg, win);
+    if (rc != PLO_OK) return rc;
+    if (win < 0) return fail(PLO_E_INTERNAL, "no candidate reported");
+    *best = bests[(size_t)win];
+    agg.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = agg;
     return PLO_OK;
 }
 

@@ -30,9 +30,12 @@
 //              re-reads HL instead of the 16 MB table.
 //   tie pick   prefix over cntM -> first column; the few DM keys of that column
 //              are sorted in LDS -> k-th tie in map order (OneSub :244-265).
-//   rows(a)    row lists per column (static transpose for input columns, an
-//              append-only pool for created columns, stale entries filtered);
-//              +-1 counts per column kept incrementally (RemOneCSE :70-77).
+//   rows(a)    row lists per column (a per-candidate copy of the static transpose for input
+//              columns, an append-only pool for created columns).  A step walks the SHORTER
+//              list of its two columns; the rows of that list that no longer hold the column,
+//              or lose it in this step, are dropped from it on the way (round 4: the lists
+//              used to keep every stale row -- 2.26e6 rows searched per candidate on config 5
+//              for 1.21e6 rows rewritten); +-1 counts per column kept incrementally (:70-77).
 //   aggregate  the rows rewritten by one step retire/create the same triples ~21
 //              times: an LDS table of 2^13 (column, ratio) entries sums them per
 //              sweep; both retirements of an entry (its pair with a and with b)
@@ -77,7 +80,8 @@ struct BigPlan {
     const uint64_t *tab0;
     uint8_t *ws; uint64_t ws_stride;
     uint64_t o_tab, o_ent, o_col, o_val, o_inv, o_len, o_ucount, o_cntM, o_dm, o_hl, o_aff, o_ncrptr, o_ncr, o_multc, o_multv,
-             o_tcnt, o_tptr2, o_tlist, o_cols2, o_spill;
+             o_tcnt, o_tptr2, o_tlist, o_cols2, o_spill,
+             o_tl, o_clen, o_keep;            // per-candidate row lists of the input columns (compacted as they are walked), live length per column, scratch
     // deferred cold updates (DEFER, see "deferred" below): hot table + partitioned store + update log instead of one big table
     uint32_t defer, pbits, capp, plcap, logcap, logtrig, hwin, hotbits_min, hotbits_max, lgrp;
     const uint64_t *st0; const uint32_t *pcount0;     // store image: 2^pbits partitions of capp entries (key48<<16 | count16), entries per partition
@@ -414,6 +418,49 @@ __device__ __forceinline__ bool agg_add_rid_bm(uint32_t *aggk, uint32_t *aggc32,
     return false;
 }
 
+// First round of the same probe, written without a loop (round 4).  One trip of the flat sweep finds 64 keys; 99.8 % of them are in
+// their home pair or claim a slot of it, so the common case is ONE pair read and at most three predicated LDS operations: the add on
+// a hit, the compare-and-swap of an empty slot, the bitmap bit of a fresh claim.  The probe loop above -- breaks, a `continue` after a
+// lost claim, a result flag -- compiled to ~60 scalar and ~70 vector instructions of exec-mask bookkeeping per trip, which is what the
+// sweep was bound by (4 waves per SIMD issue one instruction per cycle group each: 108 VALU + 100 SALU per trip).  Returns true when
+// the key is NOT settled (both slots hold other keys, or the claim lost to another key): the caller sends those lanes, ~0.2 % of them,
+// through the loop.
+__device__ __forceinline__ bool agg_add_rid_first(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *bm) {
+    const uint32_t s = ((uint32_t)__umul24(key, 0x9E3779u) >> (32u - aggbits)) & ~1u;
+    const unsigned long long kk = __hip_atomic_load((unsigned long long *)(aggk + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t k0 = (uint32_t)kk, k1 = (uint32_t)(kk >> 32);
+    const bool hit0 = k0 == key, hit = hit0 || k1 == key, emp0 = k0 == 0xFFFFFFFFu, tryc = !hit && (emp0 || k1 == 0xFFFFFFFFu);
+    const uint32_t sec = hit ? (hit0 ? 0u : 1u) : (emp0 ? 0u : 1u), t = s + sec;
+    uint32_t old = 0u;
+    if (tryc) old = wg_cas(&aggk[t], 0xFFFFFFFFu, key);
+    const bool fresh = tryc && old == 0xFFFFFFFFu, ok = hit || fresh || (tryc && old == key);      // (old == key: a lane with the same key claimed the slot first)
+    if (fresh) wg_or(&bm[t >> 5], 1u << (t & 31u));
+    if (ok) wg_add(&aggc32[s >> 1], sec ? 0x10000u : 1u);
+    return !ok;
+}
+
+#ifdef PLO_BIG_PROFILE
+// the same with a clock after every LDS round trip (profile build): acc[0] pair read, [1] compare-and-swap, [2] bitmap + count
+__device__ __forceinline__ bool agg_add_rid_first_prof(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *bm, unsigned long long *acc) {
+    const unsigned long long c0 = clock64();
+    const uint32_t s = ((uint32_t)__umul24(key, 0x9E3779u) >> (32u - aggbits)) & ~1u;
+    const unsigned long long kk = __hip_atomic_load((unsigned long long *)(aggk + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t k0 = (uint32_t)kk, k1 = (uint32_t)(kk >> 32);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long c1 = clock64();
+    const bool hit0 = k0 == key, hit = hit0 || k1 == key, emp0 = k0 == 0xFFFFFFFFu, tryc = !hit && (emp0 || k1 == 0xFFFFFFFFu);
+    const uint32_t sec = hit ? (hit0 ? 0u : 1u) : (emp0 ? 0u : 1u), t = s + sec;
+    uint32_t old = 0u;
+    if (tryc) old = wg_cas(&aggk[t], 0xFFFFFFFFu, key);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long c2 = clock64();
+    const bool fresh = tryc && old == 0xFFFFFFFFu, ok = hit || fresh || (tryc && old == key);
+    if (fresh) wg_or(&bm[t >> 5], 1u << (t & 31u));
+    if (ok) wg_add(&aggc32[s >> 1], sec ? 0x10000u : 1u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long c3 = clock64();
+    acc[0] += c1 - c0; acc[1] += c2 - c1; acc[2] += c3 - c2;
+    return !ok;
+}
+#endif
+
 // packed row entry: column (15 bits) | +-1 flag (bit 15) | value index (16 bits)
 #define PLO_ECOL(e_) ((e_) & 0x7FFFu)
 #define PLO_EUNIT(e_) (((e_) >> 15) & 1u)
@@ -427,7 +474,7 @@ __device__ __forceinline__ int row_find(const uint32_t *ent, uint32_t base, uint
 
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
-    uint32_t a, b, r, aggn, nspill; uint64_t kprime; uint64_t selkey;
+    uint32_t a, b, r, aggn, nspill, keepn; uint64_t kprime; uint64_t selkey;
     uint32_t nbisect, spilltot, listover;   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
     uint32_t logn, hotn, hotbits, nforced, hotops, logtot_lo, logtot_hi;   // DEFER: log fill, claimed hot slots, hot table size; diagnostics: merges forced by log/hot pressure, updates served by the hot table, log entries written
     uint32_t derr; unsigned long long tmg[4], tmb[4]; uint32_t ngrp; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
@@ -443,6 +490,11 @@ struct BigShared {
 };
 
 #define BSYNC() __syncthreads()
+#ifdef PLO_BIG_NOFENCE
+#define PLO_SCHED_FENCE() do { } while (0)
+#else
+#define PLO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)      /* the machine scheduler keeps the stages of the hand-ordered trip apart */
+#endif
 #ifdef PLO_BIG_PROFILE
 #define PLO_STAMP(q_) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); sh.tph[q_] += t_ - tstamp; sh.tpc[sh.M >= 256u ? 0 : sh.M >= 64u ? 1 : sh.M >= 16u ? 2 : 3][q_] += t_ - tstamp; tstamp = t_; } } while (0)
 #else
@@ -814,8 +866,14 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
             for (uint32_t e = lane; e < nq; e += 128u) { const uint64_t x0 = sp[e], x1 = e + 64u < nq ? sp[e + 64u] : 0ull; dp[e] = x0; if (e + 64u < nq) dp[e + 64u] = x1; }
         }
     }
+    uint32_t *tl = (uint32_t *)(ws + P.o_tl), *clen = (uint32_t *)(ws + P.o_clen), *keep = (uint32_t *)(ws + P.o_keep);
+    {   // this candidate's copy of the input columns' row lists (compacted in place as the steps walk them)
+        const uint32_t q4 = (P.nnz + 3u) >> 2;
+        const uint4 *t4 = (const uint4 *)P.trows; uint4 *d4 = (uint4 *)tl;
+        for (uint32_t k = tid; k < q4; k += 2u * nth) { uint4 x = t4[k], y; const bool b1 = k + nth < q4; if (b1) y = t4[k + nth]; d4[k] = x; if (b1) d4[k + nth] = y; }
+    }
     for (uint32_t i = tid; i < m; i += nth) len[i] = P.rs[i + 1] - P.rs[i];
-    for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; }
+    for (uint32_t c = tid; c < P.NCmax; c += nth) { ucount[c] = c < n ? P.ucount0[c] : 0u; cntM[c] = 0u; clen[c] = c < n ? P.tptr[c + 1] - P.tptr[c] : 0u; }
     for (uint32_t f = tid; f <= P.maxf0; f += nth) hist[f] = P.hist0[f];
     const uint32_t acb = P.agg_cb; const uint64_t AEMPTY = ~0ull << acb;
     if constexpr (MODE == 2) { for (uint32_t s = tid; s < (1u << aggbits); s += nth) { aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0; } }
@@ -1023,27 +1081,27 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
         // ---- RemOneCSE :60-194
         const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
-        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; }      // (nothing here uses `swap`: the two counts stay in flight while the row lists are walked)
+        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; sh.keepn = 0; }      // (nothing here uses `swap`: the two counts stay in flight while the row lists are walked)
         if constexpr (FAST) { for (uint32_t w = tid; w < ((1u << aggbits) + 31u) / 32u; w += nth) aggbm[w] = 0u; }      // (the tie pick used the buffer)
         BSYNC();
 #define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
         {   // rows holding the triple: walk the shorter row list of the two columns
-            const uint32_t *la, *lb; uint32_t na, nb;
-            if (a < n) { la = P.trows + P.tptr[a]; na = P.tptr[a + 1] - P.tptr[a]; } else { la = ncr + ncrptr[a - n]; na = ncrptr[a - n + 1] - ncrptr[a - n]; }
-            if (b < n) { lb = P.trows + P.tptr[b]; nb = P.tptr[b + 1] - P.tptr[b]; } else { lb = ncr + ncrptr[b - n]; nb = ncrptr[b - n + 1] - ncrptr[b - n]; }
-            const uint32_t *lst = na <= nb ? la : lb; const uint32_t ln = na <= nb ? na : nb;
+            uint32_t *la = a < n ? tl + P.tptr[a] : ncr + ncrptr[a - n], *lb = b < n ? tl + P.tptr[b] : ncr + ncrptr[b - n];
+            const uint32_t na = gload32(&clen[a]), nb = gload32(&clen[b]);          // live lengths: what earlier walks left of the lists
+            const bool walk_a = na <= nb;
+            const uint32_t *lst = walk_a ? la : lb; const uint32_t ln = walk_a ? na : nb;
             // Two rows per thread and trip, both columns of both rows searched in lock step: the four binary searches have
             // their loads in flight together (8 dependent memory round trips for two rows instead of 36).  A search keeps
             // the last entry it saw at its upper bound: when it ends that is the entry at the found position.
             uint32_t *newrows = ncr + ncrptr[lm - n];
-            auto emit = [&](uint32_t i, uint32_t base, uint32_t L, uint32_t pa, uint32_t pb, uint32_t ea, uint32_t eb) {
+            auto emit = [&](uint32_t i, uint32_t base, uint32_t L, uint32_t pa, uint32_t pb, uint32_t ea, uint32_t eb) -> bool {      // true: the row holds the triple
                 uint32_t inv_r;
                 if constexpr (MODE == 2) {
-                    if (rval[rtid[PLO_EVI(eb) * PLO_RSTRIDE + PLO_EVI(ea)]] != r) return;
+                    if (rval[rtid[PLO_EVI(eb) * PLO_RSTRIDE + PLO_EVI(ea)]] != r) return false;
                     inv_r = rval[rtid[PLO_EVI(ea) * PLO_RSTRIDE + PLO_EVI(eb)]];
                 } else {
                     const uint2 A = VT(PLO_EVI(ea)), B = VT(PLO_EVI(eb));
-                    if (B.x != bmul(r, A.x, p, mu, mers)) return;
+                    if (B.x != bmul(r, A.x, p, mu, mers)) return false;
                     inv_r = bmul(A.x, B.y, p, mu, mers);
                 }
                 const uint32_t idx = wg_add(&sh.naff, 1u);
@@ -1065,10 +1123,54 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                 if (PLO_EUNIT(ea)) wg_sub(&ucount[a], 1u);                     // :70-77 counts, kept incrementally
                 if (PLO_EUNIT(eb)) wg_sub(&ucount[b], 1u);
                 if (PLO_EUNIT(swap ? eb : ea)) wg_add(&ucount[lm], 1u);
+                return true;
             };
+            // a searched row stays in the walked list iff it still holds the list's column and does not lose it in this step; the kept
+            // rows go to a scratch list and are copied to the front of the walked one behind the barrier below (no order is needed)
+#ifdef PLO_BIG_NOCOMPACT
+            auto keep_row = [&](uint32_t, bool, bool) { };                      // (A/B switch: the lists keep their stale rows, as in rounds 1-3)
+#else
+            auto keep_row = [&](uint32_t i, bool has_col, bool affected) { if (has_col && !affected) keep[wg_add(&sh.keepn, 1u)] = i; };
+#endif
 #ifdef PLO_BIG_PROFILE
             if (tid == 0) { sh.tb2[0] += 100ull * ln; sh.tb2[2] += 100ull * (na <= nb ? nb : na); }
 #endif
+#ifdef PLO_BIG_QUATSEARCH
+            // (round 4 experiment, measured SLOWER: row search 91 -> 141 ms per candidate at full load, 49 -> 66 ms alone -- the phase is bound by the number of
+            // scattered 4-byte requests a CU can issue, not by the number of dependent rounds: 6 loads x 4 rounds cost more than 2 x 7.)
+            // One row per thread, both columns searched in lock step by QUATERNARY search: three probes per search and round, all
+            // six loads in flight together, a quarter of the range left -- 3 dependent memory round trips for a row of 64 entries
+            // (5 for 1024) where the binary search of rounds 1-3 needed 7 (11).  The phase is latency-bound (a step's rows are
+            // searched once, by idle threads mostly), so the extra requests are free.  A search keeps the entry it saw at its
+            // upper bound: when it ends that is the entry at the found position.
+            for (uint32_t k = tid; k < ln; k += nth) {
+                const uint32_t i0 = lst[k];
+                const uint32_t bs0 = P.rs[i0], L0 = len[i0];
+                uint32_t lo[2] = {0u, 0u}, hi[2] = {L0, L0}, ev[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                for (;;) {
+                    uint32_t v[2][3], pq[2][3]; bool any = false;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t w = hi[q] - lo[q]; const bool go = w != 0u; any |= go;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { pq[q][j] = lo[q] + (((uint32_t)(j + 1) * w) >> 2); v[q][j] = go ? ent[bs0 + pq[q][j]] : 0u; }
+                    }
+                    if (!any) break;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) if (hi[q] != lo[q]) {
+                        const uint32_t c = q ? b : a;
+                        if (PLO_ECOL(v[q][0]) >= c) { hi[q] = pq[q][0]; ev[q] = v[q][0]; }
+                        else if (PLO_ECOL(v[q][1]) >= c) { lo[q] = pq[q][0] + 1u; hi[q] = pq[q][1]; ev[q] = v[q][1]; }
+                        else if (PLO_ECOL(v[q][2]) >= c) { lo[q] = pq[q][1] + 1u; hi[q] = pq[q][2]; ev[q] = v[q][2]; }
+                        else lo[q] = pq[q][2] + 1u;
+                    }
+                }
+                // (an upper bound that never moved is the row length: ev stays all ones, whose column field matches no column)
+                {   const bool fa = PLO_ECOL(ev[0]) == a && lo[0] < L0, fb = PLO_ECOL(ev[1]) == b && lo[1] < L0;
+                    const bool aff0 = fa && fb && emit(i0, bs0, L0, lo[0], lo[1], ev[0], ev[1]);
+                    keep_row(i0, walk_a ? fa : fb, aff0); }
+            }
+#else
             for (uint32_t k = tid; k < ln; k += 2u * nth) {
                 const bool two = k + nth < ln;
                 const uint32_t i0 = lst[k], i1 = two ? lst[k + nth] : i0;
@@ -1087,12 +1189,26 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                         if (lo[q] < hi[q]) { if (PLO_ECOL(v[q]) < ((q & 1) ? b : a)) lo[q] = mid[q] + 1u; else { hi[q] = mid[q]; ev[q] = v[q]; } }
                 }
                 // (an upper bound that never moved is the row length: ev stays all ones, whose column field matches no column)
-                if (PLO_ECOL(ev[0]) == a && PLO_ECOL(ev[1]) == b && lo[0] < L0 && lo[1] < L0) emit(i0, bs0, L0, lo[0], lo[1], ev[0], ev[1]);
-                if (two && PLO_ECOL(ev[2]) == a && PLO_ECOL(ev[3]) == b && lo[2] < L1 && lo[3] < L1) emit(i1, bs1, L1, lo[2], lo[3], ev[2], ev[3]);
+                {   const bool fa = PLO_ECOL(ev[0]) == a && lo[0] < L0, fb = PLO_ECOL(ev[1]) == b && lo[1] < L0;
+                    const bool aff0 = fa && fb && emit(i0, bs0, L0, lo[0], lo[1], ev[0], ev[1]);
+                    keep_row(i0, walk_a ? fa : fb, aff0); }
+                if (two) { const bool fa = PLO_ECOL(ev[2]) == a && lo[2] < L1, fb = PLO_ECOL(ev[3]) == b && lo[3] < L1;
+                    const bool aff1 = fa && fb && emit(i1, bs1, L1, lo[2], lo[3], ev[2], ev[3]);
+                    keep_row(i1, walk_a ? fa : fb, aff1); }
             }
+#endif
         }
         PLO_BIG_FENCE(); BSYNC();
         const uint32_t naff = sh.naff;
+#ifndef PLO_BIG_NOCOMPACT
+        {   // the walked list, compacted (it is read next in a later step, many barriers from here)
+            const uint32_t nk = sh.keepn, lc = gload32(&clen[a]) <= gload32(&clen[b]) ? a : b;
+            uint32_t *dst = lc < n ? tl + P.tptr[lc] : ncr + ncrptr[lc - n];
+            for (uint32_t k = tid; k < nk; k += nth) dst[k] = keep[k];
+            BSYNC();                                                           // (every thread has read both lengths)
+            if (tid == 0) clen[lc] = nk;
+        }
+#endif
         PLO_STAMP(2);
         if (naff != M) { if (tid == 0) wg_max(&sh.errflag, (uint32_t)BERR_FREQ); BSYNC(); break; }   // frequency must equal the row count
         // The sweep over the affected rows: rewrite each row (:96-110) and retire its old pairs (:115-118) in one pass over
@@ -1103,20 +1219,36 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
         {
             // via, vib: value indices of the row's two removed entries (they name v_a and v_b)
 #ifdef PLO_BIG_PROFILE
-            uint32_t probe_iters = 0;
+            uint32_t probe_iters = 0; unsigned long long pq[3] = {0, 0, 0}, prt = 0;
 #endif
-            auto retire_entry = [&](uint32_t e, uint32_t via, uint32_t vib, uint2 VA, uint2 VB) {
+            auto retire_entry = [&](uint32_t e, uint32_t via, uint32_t vib, uint2 VA, uint2 VB, bool noagg = false) {      // noagg: the LDS table had no room for it (already tried)
                 const uint32_t c = PLO_ECOL(e);
                 // x = v_a/v_c (c < a) or v_c/v_a (c > a) names both retired pairs; y = v_a/v_c names the pair with the new column
                 // (x itself, or 1/x: kept beside x in the entry when the bits allow, so that the flush needs no inversion)
                 uint32_t x, y, q2, ins;                                        // q2: ratio of the pair with b; ins: ratio of the pair with the new column (both only on the fallback path)
                 if constexpr (MODE == 2) {
                     const uint32_t vi = PLO_EVI(e);
+#ifdef PLO_BIG_PROFILE
+                    const unsigned long long cr0 = clock64();
+#endif
                     const uint32_t xid = rtid[c < a ? (via * PLO_RSTRIDE) | vi : (vi * PLO_RSTRIDE) | via];      // one lookup, no branch
 #ifdef PLO_BIG_PROFILE
-                    if constexpr (FAST) { if (agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm, &probe_iters)) return; }
+                    if constexpr (FAST) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prt += clock64() - cr0;
+                        const bool pend = agg_add_rid_first_prof(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm, pq);
+                        if (!__builtin_amdgcn_ballot_w64(pend)) return;
+                        if (!pend || agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm, &probe_iters)) return;
+                    }
+#elif !defined(PLO_BIG_FIRSTPROBE)
+                    if constexpr (FAST) { if (!noagg) { if (agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm)) return; } }
 #else
-                    if constexpr (FAST) { if (agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm)) return; }
+                    if constexpr (FAST) {
+                        if (!noagg) {
+                        const bool pend = agg_add_rid_first(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm);
+                        if (!__builtin_amdgcn_ballot_w64(pend)) return;                  // (wave-uniform: nine trips in ten end here)
+                        if (!pend || agg_add_rid_bm(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, aggbm)) return;
+                        }
+                    }
 #endif
                     else if (agg_add_rid(aggk, aggc32, aggbits, (c << PLO_RIDB) | xid, &sh.aggn, agglist, listcap)) return;
                     const uint32_t bc = rval[rtid[vib * PLO_RSTRIDE + vi]];                                  // v_b / v_c
@@ -1227,6 +1359,74 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                         z_ = f_ - S_; ad_ = rb_ + z_;
                         e_ = ent[ok && f_ < T ? ad_ : safe];
                     };
+#if defined(PLO_BIG_PIPETRIP) && !defined(PLO_BIG_PROFILE)
+                    // Round 4: the trip as ONE hand-ordered instruction stream.  Measured with a clock behind every LDS round trip (profile
+                    // build, profiles/r04_sweep_trip_clocks.txt): per trip the wave waited in turn for the record permutes of the next trip
+                    // (~130 cycles), the ratio-identifier lookup (73), the pair read (126) and the compare-and-swap of the few claiming
+                    // lanes (240) -- a chain of ~570 cycles of LDS latency in a trip of ~1,700, with 2 to 4 waves per SIMD to hide it.
+                    // Here (1) the lookup of THIS trip's identifiers is issued first, (2) the next trip's four permutes behind it, (3) the
+                    // pair read as soon as the identifier is back, (4) the next trip's entry request, (5) this trip's stores -- so the
+                    // three latencies overlap -- and (6) a claim is OPTIMISTIC: the compare-and-swap is issued, the bitmap bit and the count
+                    // are added at once, and its returned word is looked at one trip later; a claim that lost its slot to another key (0.2 %
+                    // of the lanes) takes its count back and goes through the probe loop then.  Counts are read by the flush, behind the
+                    // barrier that ends the sweep, so a count that sits on a wrong slot for one trip is seen by nobody.
+                    uint32_t adc, zc, ppc, rzc, ec; prep(0u, adc, zc, ppc, rzc, ec);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): see PLAINTRIP below
+                    uint32_t dk = 0xFFFFFFFFu, dold = 0u, de = 0u, drz = 0u;          // the claim of the trip before: key | second slot << 31, returned word, entry, record bits
+                    auto settle = [&]() {
+                        const bool lost = dk != 0xFFFFFFFFu && dold != 0xFFFFFFFFu && dold != (dk & 0x7FFFFFFFu);
+                        if (__builtin_amdgcn_ballot_w64(lost)) {
+                            if (lost) {
+                                const uint32_t key = dk & 0x7FFFFFFFu, s = ((uint32_t)__umul24(key, 0x9E3779u) >> (32u - aggbits)) & ~1u;
+                                wg_sub(&aggc32[s >> 1], (dk >> 31) ? 0x10000u : 1u);
+                                if (!agg_add_rid_bm(aggk, aggc32, aggbits, key, aggbm)) retire_entry(de, (drz >> 15) & 31u, (drz >> 21) & 31u, make_uint2(0, 0), make_uint2(0, 0), true);
+                            }
+                        }
+                        dk = 0xFFFFFFFFu;
+                    };
+                    for (uint32_t t = 0; t < ntw; ++t) {
+                        // (1) this trip's ratio identifiers (idle lanes look up a valid entry too: no branch around the read)
+                        const uint32_t cE = PLO_ECOL(ec), viE = PLO_EVI(ec) & 31u, viaE = (rzc >> 15) & 31u;
+                        const uint32_t xidE = rtid[cE < a ? (viaE * PLO_RSTRIDE) | viE : (viE * PLO_RSTRIDE) | viaE];
+                        PLO_SCHED_FENCE();
+                        // (2) the next trip's row records
+                        const uint32_t t_ = t + 1u; const bool okn = t_ < ntw;
+                        const uint32_t ml = okn ? RL(mrl, t_ & 31u) : 0u, mh = okn ? RL(mrh, t_ & 31u) : 0u;
+                        const uint32_t m1l = (ml >> 1) | (mh << 31), m1h = mh >> 1;
+                        const int qa = (int)((qlo + (ml & 1u) + __builtin_amdgcn_mbcnt_hi(m1h, __builtin_amdgcn_mbcnt_lo(m1l, 0u))) << 2);
+                        qlo += (uint32_t)__builtin_popcount(ml) + (uint32_t)__builtin_popcount(mh);
+                        const uint32_t rbn = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)R0.y), Sn = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)S);
+                        const uint32_t ppn = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)R0.x), rzn = (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)R0.z);
+                        PLO_SCHED_FENCE();
+                        // (3) this trip's pair of aggregation slots
+                        const uint32_t keyE = (cE << PLO_RIDB) | xidE, sE = ((uint32_t)__umul24(keyE, 0x9E3779u) >> (32u - aggbits)) & ~1u;
+                        const unsigned long long kk = __hip_atomic_load((unsigned long long *)(aggk + sE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        PLO_SCHED_FENCE();
+                        // (4) the next trip's entry
+                        const uint32_t fn = w0 + (t_ << 6) + lane, zn = fn - Sn, adn = rbn + zn;
+                        const uint32_t en = ent[okn && fn < T ? adn : safe];
+                        PLO_SCHED_FENCE();
+                        // (5) this trip's row rewrite (:96-110), stores unconditional (idle lanes write their dump word)
+                        const uint32_t pa = ppc & 0xFFFFu, pb = ppc >> 16;
+                        const bool in = w0 + (t << 6) + lane < T, act = in && zc != pa && zc != pb;
+                        ent[act && zc > pa ? adc - 1u - (zc > pb ? 1u : 0u) : dump] = ec;
+                        ent[in && zc + 1u == (rzc & 0x3FFFu) ? adc - 1u : dump] = (((rzc >> selsh) & 63u) << 15) | lm;
+                        PLO_SCHED_FENCE();
+                        // (6) the claims of the trip before, then this trip's keys
+                        settle();
+                        const uint32_t k0 = (uint32_t)kk, k1 = (uint32_t)(kk >> 32);
+                        const bool hit0 = k0 == keyE, hit = hit0 || k1 == keyE, emp0 = k0 == 0xFFFFFFFFu;
+                        const bool tryc = act && !hit && (emp0 || k1 == 0xFFFFFFFFu), full = act && !hit && !tryc;
+                        const uint32_t sec = hit ? (hit0 ? 0u : 1u) : (emp0 ? 0u : 1u), tE = sE + sec;
+                        if (tryc) { dold = wg_cas(&aggk[tE], 0xFFFFFFFFu, keyE); wg_or(&aggbm[tE >> 5], 1u << (tE & 31u)); dk = keyE | (sec << 31); de = ec; drz = rzc; }
+                        if (act && !full) wg_add(&aggc32[sE >> 1], sec ? 0x10000u : 1u);
+                        if (__builtin_amdgcn_ballot_w64(full)) {              // both slots hold other keys: the probe loop (one trip in ten)
+                            if (full) { if (!agg_add_rid_bm(aggk, aggc32, aggbits, keyE, aggbm)) retire_entry(ec, viaE, (rzc >> 21) & 31u, make_uint2(0, 0), make_uint2(0, 0), true); }
+                        }
+                        adc = adn; zc = zn; ppc = ppn; rzc = rzn; ec = en;
+                    }
+                    settle();
+#else
                     uint32_t adc, zc, ppc, rzc, ec; prep(0u, adc, zc, ppc, rzc, ec);
                     // (the wait counters of the loop header merge both incoming edges: with the first entry still in flight here every
                     // trip would wait for all but one memory operation, i.e. for the stores of the trip before)
@@ -1255,6 +1455,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
 #endif
                         adc = adn; zc = zn; ppc = ppn; rzc = rzn; ec = en;
                     }
+#endif
                 }
             }
             } else
@@ -1320,7 +1521,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                 }
             }
 #ifdef PLO_BIG_PROFILE
-            if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[0], pw0); atomicAdd(&sh.pw[1], pw1); atomicAdd(&sh.pw[2], pw2); atomicAdd(&sh.pw[3], ptr); atomicAdd(&sh.pw[4], clock64() - ts_); atomicAdd(&sh.pw[5], 1ull); atomicAdd(&sh.pw[6], pit); atomicAdd(&sh.pw[7], pact); }
+            if (lane == 0 && M >= 256u) { atomicAdd(&sh.pw[0], pw0); atomicAdd(&sh.pw[1], pw1); atomicAdd(&sh.pw[2], pw2); atomicAdd(&sh.pw[3], ptr); atomicAdd(&sh.pw[4], clock64() - ts_); atomicAdd(&sh.pw[5], 1ull); atomicAdd(&sh.pw[6], pit); atomicAdd(&sh.pw[7], pact); atomicAdd(&sh.pw[8], pq[0]); atomicAdd(&sh.pw[9], pq[1]); atomicAdd(&sh.pw[10], pq[2]); atomicAdd(&sh.pw[14], prt); }
 #endif
         }
 #undef RL
@@ -1602,7 +1803,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
         PLO_STAMP(5);
         // row list of the new column, multiplier reuse (:153-169), counters
         {
-            if (tid == 0) { ncrptr[lm - n + 1u] = ncrptr[lm - n] + naff; sh.part[0] = 0; }      // (the row search wrote the rows)
+            if (tid == 0) { ncrptr[lm - n + 1u] = ncrptr[lm - n] + naff; clen[lm] = naff; sh.part[0] = 0; }      // (the row search wrote the rows)
         }
         BSYNC();
         if (!P.unit) {

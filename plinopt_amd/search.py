@@ -191,6 +191,39 @@ def kernel_search(M, p, seed0, nrestarts, per_block=1, cost_mode=capi.COST_SUM_T
     return (list(adds) if want_costs else None), (list(muls) if want_costs else None), inf, (b.adds, b.muls, b.seed), st.as_dict()
 
 
+def kernel_search_multi(M, p, seed0, nrestarts, devices, cost_mode=capi.COST_SUM_THEN_ADD):
+    """`plo_kernel_search_multi`: the restart loop of the kernel method over the listed devices from this process (one host thread
+    and one device per contiguous shard, minimum by the RCCL MIN all-reduces).  Returns ((adds, muls, seed), stats)."""
+    L = capi.lib()
+    m, n, rp, col, val = M
+    A, keep = capi.make_csr(m, n, rp, col, val)
+    dv = (ctypes.c_int * len(devices))(*devices)
+    b, st = capi.Best(), capi.Stats()
+    capi.check(L.plo_kernel_search_multi(ctypes.byref(A), p, seed0, nrestarts, 1, cost_mode, len(devices), dv, ctypes.byref(b), ctypes.byref(st)))
+    del keep
+    return (b.adds, b.muls, b.seed), st.as_dict()
+
+
+def tril_search_multi(m, mats, seed0, nseeds, devices, expanded=False):
+    """`plo_tril_search_multi` (BASELINE configs[3]): the restart loop of SearchTriLinearAlgorithm over the listed devices from this
+    process.  mats = three (n, rowptr, col, num[, den]) triples as for TrilPlan.  Returns (((ADD, SCA, MUL), seed, variant), stats)."""
+    L = capi.lib()
+    keep, cs = [], []
+    for t in mats:
+        n, rowptr, col, val = t[:4]
+        den = t[4] if len(t) == 5 else [1] * len(val)
+        a = ((ctypes.c_uint32 * len(rowptr))(*rowptr), (ctypes.c_uint32 * max(len(col), 1))(*col), (ctypes.c_int64 * max(len(val), 1))(*[int(x) for x in val]),
+             (ctypes.c_int64 * max(len(den), 1))(*[int(x) for x in den]))
+        keep.append(a)
+        cs.append(capi.QCSR(m, n, a[0], a[1], a[2], a[3]))
+    dv = (ctypes.c_int * len(devices))(*devices)
+    b, st = capi.TrilBest(), capi.Stats()
+    capi.check(L.plo_tril_search_multi(ctypes.byref(cs[0]), ctypes.byref(cs[1]), ctypes.byref(cs[2]), int(bool(expanded)), seed0, nseeds, len(devices), dv,
+                                       ctypes.byref(b), ctypes.byref(st)))
+    del keep
+    return ((b.add, b.sca, b.mul), b.seed, b.variant), st.as_dict()
+
+
 def cob_search(n, m, TM, Cand, row, offsetblock, coeffs, p, w0=-1, w1=-1, groups=None):
     """One (block,row) enumeration of `localSparsifier` (reference include/plinopt_sparsify.inl:282-314) on the
     GPU: |coeffs|^4 candidate rows through `testLinComb`.  TM (n x m) and Cand (n x n) are flat row-major lists of

@@ -1,5 +1,7 @@
-"""`--gpu N` (N >= 2) of bin/optimizer and bin/trilplacer: the restarts in N contiguous seed shards, one forked child per
-shard, minimum under the tools' total order in the parent (plo_host.hpp `forked_shards`).  The winner and the printed
+"""`--gpu N` (N >= 2) of bin/optimizer and bin/trilplacer: the restarts in N contiguous seed shards -- by default one host thread
+and one device per shard inside the library (plo_cse_search_multi, plo_kernel_search_multi, plo_tril_search_multi; the minimum
+by RCCL MIN all-reduces), with --fork-shards one forked child per shard and the minimum under the tools' total order in the
+parent (plo_host.hpp `forked_shards`).  The winner and the printed
 program must be those of the unsharded search (reference: the iterations of `#pragma omp parallel for` are independent,
 include/plinopt_optimize.inl:1204-1238, plinopt_inplace.inl:837-924).  CPU: every shard on the host engine
 (PLO_SHARD_ENGINE=host); GPU (-m gpu): every shard on device 0 of the box (PLO_GPU_DEVICES=0,0,...)."""
@@ -67,7 +69,52 @@ def test_optimizer_two_shards_on_the_gpu(hip):
     assert out1 == out2 and _found(err1, "# Found D") == _found(err2, "# Found D")
     assert "# 2 shards (one GPU and one host thread each, one process): 20001 candidates" in err2       # plo_cse_search_multi
     rc3, out3, err3 = _run([OPT, "-q", str(P), "-D", "-O", "20001", "--seed", "3", "--gpu", "2", "--fork-shards", path], {"PLO_GPU_DEVICES": "0,0"})
-    assert rc3 == 0 and out3 == out1 and "# 2 shards (one GPU each): 20001 candidates" in err3, err3                     # one forked child per device
+    assert rc3 == 0 and out3 == out1 and "# 2 shards (one forked process and one GPU each): 20001 candidates" in err3, err3   # one forked child per device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--fork-shards"]])
+def test_optimizer_default_methods_with_two_shards(hip, extra):
+    """`bin/optimizer -q p --gpu 2 file` with the default methods (-D, -K and -G all on): -D and -K are sharded, nothing is forked
+    after this process has touched the HIP runtime (in-library threads by default; with --fork-shards every fork comes first),
+    and the result is the one device's."""
+    path = os.path.join(DATA, "4x4x4_49_156_L.sms")
+    rc1, out1, err1 = _run([OPT, "-q", str(P), "-O", "2001", "--seed", "3", path])
+    rc2, out2, err2 = _run([OPT, "-q", str(P), "-O", "2001", "--seed", "3", "--gpu", "2"] + extra + [path], {"PLO_GPU_DEVICES": "0,0"})
+    assert rc1 == 0 and rc2 == 0, err1 + err2
+    assert out1 == out2
+    for tag in ("# Found D", "# Found K", "# Found G"):
+        assert _found(err1, tag) == _found(err2, tag) and _found(err1, tag), tag
+    assert "2 shards" in err2 and "-K" in err2
+    assert ("one forked process" in err2) == bool(extra)
+
+
+@pytest.mark.gpu
+def test_in_library_kernel_and_tril_searches_over_devices(hip, monkeypatch):
+    """plo_kernel_search_multi and plo_tril_search_multi: shards on device 0 (1, 2, 3 threads) give the single-device winner;
+    with PLO_MULTI_REDUCE=rccl a one-rank communicator runs the two MIN all-reduces, is built ONCE for the device set and reused."""
+    from plinopt_amd import TrilPlan, capi, kernel_search, kernel_search_multi, tril_search_multi
+    from plo_testlib import OracleMatrix, OracleTril
+    M = OracleMatrix.from_sms(os.path.join(DATA, "4x4x4_49_156_L.sms"), P)
+    one = kernel_search((M.m, M.n, M.rowptr, M.col, M.val), P, 5, 2000, want_costs=False)[3]
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        got, st = kernel_search_multi((M.m, M.n, M.rowptr, M.col, M.val), P, 5, 2000, devs)
+        assert got == one and st["candidates"] == 2000 and st["reduce"] == 0
+    O = OracleTril.from_sms(*(os.path.join(DATA, "4x4x4_49_156" + x) for x in ("_L.sms", "_R.sms", "_P.sms")))
+    mats = [(n, rp, col, [int(x) for x in num]) for n, (rp, col, num, den) in zip(O.dims, O.csr)]
+    G = TrilPlan(O.m, mats)
+    tone = G.search(11, 1500)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        got, st = tril_search_multi(O.m, mats, 11, 1500, devs)
+        assert got == tone and st["candidates"] == 1500
+    monkeypatch.setenv("PLO_MULTI_REDUCE", "rccl")
+    n0 = capi.lib().plo_multi_comm_inits()
+    got, st = tril_search_multi(O.m, mats, 11, 1500, [0])
+    assert got == tone and st["reduce"] == 1 and st["reduce_seconds"] > 0
+    got, st = kernel_search_multi((M.m, M.n, M.rowptr, M.col, M.val), P, 5, 2000, [0])
+    assert got == one and st["reduce"] == 1
+    assert capi.lib().plo_multi_comm_inits() - n0 <= 1            # one communicator for the device set {0}, reused by the second call
+    assert G.search(11, 1500) == tone                              # the caller's device and context are untouched
 
 
 @pytest.mark.gpu
@@ -112,3 +159,6 @@ def test_trilplacer_two_shards_on_the_gpu(hip):
     rc2, out2, err2 = _run([TRIL] + files + ["-O", "3001", "--seed", "9", "--gpu", "2"], {"PLO_GPU_DEVICES": "0,0"})
     assert rc1 == 0 and rc2 == 0, err1 + err2
     assert out1 == out2 and _found(err1, "# Found") == _found(err2, "# Found")
+    assert "# 2 shards (one GPU and one host thread each, one process)" in err2                           # plo_tril_search_multi
+    rc3, out3, err3 = _run([TRIL] + files + ["-O", "3001", "--seed", "9", "--gpu", "2", "--fork-shards"], {"PLO_GPU_DEVICES": "0,0"})
+    assert rc3 == 0 and out3 == out1 and "one forked process" in err3, err3

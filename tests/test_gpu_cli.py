@@ -234,8 +234,9 @@ def test_all_row_orders_on_gpu_equal_the_oracle(name):
 
 
 def test_kernel_method_sharded_over_devices_equals_one_device():
-    """-K --gpu 3: the restart range in three shards, one forked child per shard (here all on device 0: PLO_GPU_DEVICES), every shard
-    = plo_kernel_search on its block; same winner, counts, decomposition and program as one device."""
+    """-K --gpu 3: the restart range in three shards (here all on device 0: PLO_GPU_DEVICES), every shard = plo_kernel_search on its
+    block -- one host thread per shard inside the library by default (plo_kernel_search_multi), one forked child per shard with
+    --fork-shards; same winner, counts, decomposition and program as one device."""
     path = os.path.join(DATA, "4x4x4_49_156_L.sms")
     env = dict(os.environ, PLO_GPU_DEVICES="0,0,0")
     r3 = subprocess.run([OPT, "-q", str(P), "--only", "K", "-O", "3001", "--seed", "11", "--gpu", "3", path], capture_output=True, text=True, timeout=600, env=env)
@@ -244,8 +245,10 @@ def test_kernel_method_sharded_over_devices_equals_one_device():
     pat = r"# Found K: (\d+)\|(\d+) instead of \d+\|\d+\t\[seed (\d+)\] \(rank (\d+)\+(\d+), (\d+) dependent rows\)"
     g3, g1 = re.search(pat, r3.stderr), re.search(pat, err1)
     assert g3 and g1 and g3.groups() == g1.groups(), (r3.stderr, err1)
-    assert "# 3 shards (one GPU each): -K" in r3.stderr and "# GPU (K): 3001 candidates on 3001 decompositions" in r3.stderr
+    assert "# 3 shards (one GPU and one host thread each, one process, minimum on the host): -K" in r3.stderr and "# GPU (K): 3001 candidates on 3001 decompositions" in r3.stderr
     assert r3.stdout == out1
+    rf = subprocess.run([OPT, "-q", str(P), "--only", "K", "-O", "3001", "--seed", "11", "--gpu", "3", "--fork-shards", path], capture_output=True, text=True, timeout=600, env=env)
+    assert rf.returncode == 0 and rf.stdout == out1 and "# 3 shards (one forked process and one GPU each): -K" in rf.stderr, rf.stderr
 
 
 @pytest.mark.parametrize("name", ["4x4x4_49_156_L.sms", "2x2x2_7_DPS-accurate_L.sms", "4x4x4_48_rational_L.sms"])
