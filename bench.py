@@ -167,6 +167,23 @@ def dist_setup(args):
     return rank, local_rank, world, dev, barrier, max_over_ranks
 
 
+PER_RANK_COLUMNS = ["kernel (HIP events)", "search wall (library call)", "all-reduce wall (includes waiting for the slowest rank)"]
+
+
+def gather_per_rank(dev, world, kernel_ms, search_s, reduce_s):
+    """every rank's kernel time, wall time of its searches and wall time inside the all-reduces over the timed steps, in ms (one row per
+    rank): where a loss of scaling would come from -- a slow rank, launch overhead, or the reduction"""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([kernel_ms, search_s * 1e3, reduce_s * 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+    else:
+        rows = [mine]
+    return [[round(float(x), 3) for x in g.tolist()] for g in rows]
+
+
 def issue_roofline(name, kernel, per_launch_ms):
     """For the kernels whose state lives in LDS the HBM roofline says nothing: report instruction issue instead, from the
     committed rocprofv3 counters of the same workload (profiles/r03_issue.json, else r02_issue.json: SQ_INSTS_* / SQ_BUSY_CYCLES).
@@ -322,10 +339,16 @@ def bench_tril(args):
     warm = args.warmup if args.warmup is not None else 2
     gb = batch * world                               # seeds of one step over all ranks: contiguous shards, no data-path collective
 
-    def one(k):
+    wall = [0.0, 0.0]                                # this rank's time inside the library call and inside the all-reduce, timed steps
+
+    def one(k, timed=False):
         s0 = k * gb
+        t_a = time.perf_counter()
         r = G.search(s0 + rank * batch, batch)       # ((ADD, SCA, MUL), seed, variant) of this rank's shard
+        t_b = time.perf_counter()
         seed, variant, word, fl = allreduce_tril_best(r, s0, device=dev, fields=True)      # ONE MIN all-reduce (order ADD, SCA, seed, variant)
+        if timed:
+            wall[0] += t_b - t_a; wall[1] += time.perf_counter() - t_b
         return r, seed, variant, fl
 
     for k in range(warm):
@@ -335,12 +358,13 @@ def bench_tril(args):
     best = None
     t0 = time.perf_counter()
     for k in range(steps):
-        r, seed, variant, fl = one(warm + k)
+        r, seed, variant, fl = one(warm + k, True)
         kms += G.last_stats["kernel_ms"]
         key = (fl[0], fl[1], seed, variant)                 # (ADD, SCA) decoded by the reduction itself, whichever word layout it used
         best = key if best is None or key < best else best
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    per_rank_ms = gather_per_rank(dev, world, kms, wall[0], wall[1])
     if rank != 0:
         return
     st = G.last_stats
@@ -352,6 +376,7 @@ def bench_tril(args):
            "config": {"workload": desc, "matrices": name, "per_gpu_batch": batch, "global_batch": gb, "rows": O.m, "dims": list(O.dims),
                       "parallelism": "seed-shard x%d + 1 MIN all-reduce/step" % world},
            "best": {"add": best[0], "sca": best[1], "seed": best[2], "variant": best[3]},
+           "per_rank_ms": {"columns": PER_RANK_COLUMNS, "rows": per_rank_ms, "steps": steps},
            "roofline": {"bound": "hbm", "achieved": algo / (per * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel": "plo::tril_kernel", "kernel_ms_per_launch": per, "algo_bytes_per_candidate": st["algo_bytes"],
                         "note": "atom lists are LDS-resident (one wavefront per candidate); HBM sees the three CSR images (L2-resident) and one "
@@ -385,10 +410,16 @@ def bench_kmethod(args):
     warm = args.warmup if args.warmup is not None else 2
     gb = batch * world
 
-    def one(k):
+    wall = [0.0, 0.0]
+
+    def one(k, timed=False):
         s0 = 1 + k * gb
+        t_a = time.perf_counter()
         _, _, _, b, st = kernel_search((m, n, rp, c, v), p, s0 + rank * batch, batch, want_costs=False)
+        t_b = time.perf_counter()
         seed, word, fl = allreduce_best((b[0], b[1], b[2]), s0, device=dev, fields=True)
+        if timed:
+            wall[0] += t_b - t_a; wall[1] += time.perf_counter() - t_b
         return b, seed, fl, st
 
     for k in range(warm):
@@ -398,11 +429,12 @@ def bench_kmethod(args):
     best = None
     t0 = time.perf_counter()
     for k in range(steps):
-        b, seed, word, st = one(warm + k)                   # word: the decoded cost fields (sum, adds), comparable across steps whatever layout was reduced
+        b, seed, word, st = one(warm + k, True)             # word: the decoded cost fields (sum, adds), comparable across steps whatever layout was reduced
         kms += st["kernel_ms"]
         best = (word, seed) if best is None or (word, seed) < best else best
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    per_rank_ms = gather_per_rank(dev, world, kms, wall[0], wall[1])
     if rank != 0:
         return
     per = kms / steps
@@ -412,6 +444,7 @@ def bench_kmethod(args):
            "config": {"workload": desc, "matrix": fname, "rows": m, "cols": n, "nnz": len(c), "modulus": p, "per_gpu_batch": batch, "global_batch": gb,
                       "parallelism": "seed-shard x%d + 1 MIN all-reduce/step" % world},
            "best": {"seed": best[1]},
+           "per_rank_ms": {"columns": PER_RANK_COLUMNS, "rows": per_rank_ms, "steps": steps},
            "roofline": issue_roofline("kmethod", "plo::kmethod_kernel", per) or {"bound": "issue", "achieved": 0.0, "peak": 1.0, "unit": "scalar wave-instructions/clk/CU", "frac": 0.0, "traffic": None},
            "kernel": {"lds_bytes": st["lds_bytes"], "waves_per_wg": st["waves_per_wg"], "grid": st["grid"], "launches_per_step": st["launches"]}}
     if not args.no_cpu_baseline and world == 1:
@@ -521,13 +554,7 @@ def main():
     total = float(global_batch) * args.steps
     value = total / dt
     # where a loss of scaling would come from: every rank's kernel time, search wall time and time inside the all-reduce
-    per_rank = torch.tensor([kernel_ms, search_s * 1e3, reduce_s * 1e3], dtype=torch.float64, device=dev)
-    if world > 1:
-        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
-        dist.all_gather(gathered, per_rank)
-    else:
-        gathered = [per_rank]
-    per_rank_ms = [[round(float(x), 3) for x in g.tolist()] for g in gathered]
+    per_rank_ms = gather_per_rank(dev, world, kernel_ms, search_s, reduce_s)
     if rank == 0:
         # dominant kernel: cse_wave_kernel; algorithmic bytes per candidate B_cand
         per_launch_ms = kernel_ms / max(launches, 1)
@@ -544,8 +571,7 @@ def main():
                        "global_batch": global_batch, "parallelism": "seed-shard x%d + 1 MIN all-reduce/step" % world,
                        "nnz": len(c), "rows": m, "cols": n},
             "best": {"packed": best_word[0], "seed": best_word[1], "adds_plus_muls": best_word[2][0], "adds": best_word[2][1]},
-            "per_rank_ms": {"columns": ["kernel (HIP events)", "search wall (library call)", "all-reduce wall (includes waiting for the slowest rank)"],
-                            "rows": per_rank_ms, "steps": args.steps},
+            "per_rank_ms": {"columns": PER_RANK_COLUMNS, "rows": per_rank_ms, "steps": args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "plo::cse_wave_kernel", "kernel_ms_per_launch": search_ms,
@@ -554,14 +580,23 @@ def main():
                          "note": "state is LDS-resident by design; HBM fraction ~0, limiter is LDS/VALU issue (DESIGN.md)"},
             "kernel": {"lds_bytes": stats["lds_bytes"], "waves_per_wg": stats["waves_per_wg"], "grid": stats["grid"]},
         }
+        tr = None
         try:    # measured HBM bytes (PMC) from the committed profile of this workload, scaled to one launch
-            tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
-            tr = json.load(open(tj if os.path.exists(tj) else os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(args.workload)
+            tj = [os.path.join(ROOT, "profiles", f) for f in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")]
+            tr = json.load(open([f for f in tj if os.path.exists(f)][0])).get(args.workload)
             if tr:
                 out["roofline"]["traffic"] = (tr["fetch_bytes_per_candidate"] + tr["write_bytes_per_candidate"]) * batch
                 out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " + tr["source"]
                 out["roofline"]["measured_hbm_GBps"] = out["roofline"]["traffic"] / (search_ms * 1e-3) / 1e9
                 out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / (algo_bytes * batch)
+                # gfx950: FETCH_SIZE reads 1/2 of the bytes of WIDE (16 B per lane) streaming reads (MI355X_MICROARCH.md, HBM); this kernel's
+                # reads are 4- and 8-byte accesses apart from the image copies, so the counter is given as it is and, beside it, the
+                # bound with every fetched byte doubled
+                out["roofline"]["traffic_fetch_x2"] = (2.0 * tr["fetch_bytes_per_candidate"] + tr["write_bytes_per_candidate"]) * batch
+                out["roofline"]["traffic_over_algorithmic_fetch_x2"] = out["roofline"]["traffic_fetch_x2"] / (algo_bytes * batch)
+                if "l2_hit_rate" in tr:
+                    out["roofline"]["l2_hit_rate"] = tr["l2_hit_rate"]
+                    out["roofline"]["l2_requests_per_candidate"] = tr.get("l2_requests_per_candidate")
                 if "kernel_source_sha16" in tr:        # the counters were taken on one version of the kernel: say so when it has changed since
                     import hashlib
                     now = hashlib.sha256(open(os.path.join(ROOT, "plinopt_amd", "csrc", "plo_cse_big.hip"), "rb").read()).hexdigest()[:16]
@@ -569,12 +604,24 @@ def main():
         except Exception:
             pass
         if plan.is_hbm:
-            out["roofline"]["note"] = ("candidate state (5 MB packed rows, 27 MB partitioned triple store + update log, lists) is HBM-resident. Round 3: updates of triples "
-                                       "below the window of top frequency levels are deferred (8-byte log records, merged per partition in LDS) instead of random "
-                                       "read-modify-writes of a 64 MB table: measured HBM traffic 1.88 GB per candidate = 31x the algorithmic bytes (round 2: 51x), "
-                                       "4.7e7 L2 requests per candidate (round 2: 6.9e7) (rocprofv3 PMC, profiles/r03a_*). A candidate ALONE on the chip needs 0.48 s, "
-                                       "512 together 0.68 s each: the kernel is bound by the dependent chain of one workgroup per candidate (8 waves; the sweep's "
-                                       "LDS aggregation is VALU-issue bound at 16 waves per CU), not by this streaming `frac` (DESIGN.md 2.3, 6)")
+            # every figure of the note comes from the JSON files it cites (profiles/r04_traffic.json, profiles/r04_phase_clocks.json)
+            note = ("candidate state (5 MB packed rows, 27 MB partitioned triple store + update log, row lists) is HBM-resident; updates of triples below "
+                    "the window of top frequency levels are deferred (8-byte log records, merged per partition in LDS)")
+            if tr:
+                note += ("; measured HBM traffic %.2f GB per candidate = %.1fx the algorithmic bytes, %.2e L2 requests per candidate, L2 hit rate %.0f %% (%s)"
+                         % ((tr["fetch_bytes_per_candidate"] + tr["write_bytes_per_candidate"]) / 1e9, out["roofline"]["traffic_over_algorithmic"],
+                            tr.get("l2_requests_per_candidate", 0.0), 100.0 * tr.get("l2_hit_rate", 0.0), tr["source"].split(" ")[0]))
+            try:
+                pc = [os.path.join(ROOT, "profiles", f) for f in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if f.endswith("_phase_clocks.json")][0]
+                d = json.load(open(pc))
+                la, ll = d["alone"]["last_candidate"], d["loaded"]["last_candidate"]
+                ph = lambda x: "merges %d, tie pick %d, row search %d, sweep %d, flush %d" % tuple(round(x[k] / 1e3) for k in ("level_and_merges_us", "tie_pick_us", "row_search_us", "sweep_us", "flush_us"))
+                note += ("; a candidate ALONE on the chip takes %.0f ms, %d together %.0f ms each: the kernel is bound by the dependent chain of one 8-wave workgroup "
+                         "per candidate, not by this streaming `frac`; phase clocks in ms, alone: %s; at full load: %s (%s)"
+                         % (d["alone"]["kernel_ms"], d["loaded"]["grid"], d["loaded"]["kernel_ms"] * d["loaded"]["grid"] / d["loaded"]["ncand"], ph(la), ph(ll), os.path.relpath(pc, ROOT)))
+            except Exception:
+                pass
+            out["roofline"]["note"] = note + " (DESIGN.md 2.3)"
             out["kernel"]["family"] = "plo::cse_big_kernel (one workgroup per candidate)"
             out["roofline"]["kernel"] = "plo::cse_big_kernel"
         if not plan.is_hbm:

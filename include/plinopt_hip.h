@@ -92,6 +92,11 @@ int plo_cse_plan_is_hbm(const plo_plan_t *plan);
  * table), [5] sweeps whose claimed-slot list overflowed, [6] candidates, [7] how often the plan was rebuilt with the eager
  * pair table because a candidate outgrew the structures of the deferred updates (sized from the input's triples). */
 int plo_cse_plan_hbm_counters(const plo_plan_t *plan, uint32_t out[8]);
+/* the same, the first n <= 10 counters: [8] windows of the flat sweep beyond the first one of a batch of rows (a wave takes the entries
+ * of its rows 2048 at a time; PLO_BIG_FWIN makes the window smaller in the tests), counted on wave 0; [9] rows walked by the row search
+ * (the length of the shorter row list of a step's two columns, summed over steps: reference include/plinopt_optimize.inl:92-94 walks
+ * every row). */
+int plo_cse_plan_hbm_counters_ex(const plo_plan_t *plan, uint32_t *out, uint32_t n);
 int plo_cse_plan_destroy(plo_plan_t *plan);
 
 /* Replaces the body of `#pragma omp parallel for` in CSEOptimiser,
@@ -231,8 +236,9 @@ int  plo_tril_plan_create_x(const plo_icsr_t *A, const plo_icsr_t *B, const plo_
 /* Rational coefficients num/den (den == NULL: all 1), as the reference's matrices are (Givaro::Rational, include/plinopt_inplace.inl:19):
  * the atoms of the device programs carry the coefficients' images modulo the 31-bit prime 2147483629 (an additive atom its signed
  * coefficient, a multiplicative atom its factor: what cumulate/isnoop/complexity, :96-144, depend on); the tool replays and checks the
- * winner over Q.  All entries +-1: the kernel of rounds 1-2.  PLO_E_UNSUPPORTED: an empty row, a row of more than 64 entries, an
- * entry that vanishes modulo the prime, or expanded != 0 with coefficients other than +-1. */
+ * winner over Q.  All entries +-1: the kernel of rounds 1-2.  expanded != 0 takes rational coefficients too (round 4: the scaling
+ * atoms *y, *a and the atoms of z = -y c y and c of include/plinopt_inplace.inl:532-535, 561-565).  PLO_E_UNSUPPORTED: an empty row,
+ * a row of more than 64 entries, or an entry that vanishes modulo the prime. */
 typedef struct { uint32_t m, n; const uint32_t *rowptr; const uint32_t *col; const int64_t *num; const int64_t *den; } plo_qcsr_t;
 int  plo_tril_plan_create_q(const plo_qcsr_t *A, const plo_qcsr_t *B, const plo_qcsr_t *T, int expanded, plo_tril_plan_t **plan);
 void plo_tril_plan_destroy(plo_tril_plan_t *plan);

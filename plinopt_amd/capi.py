@@ -17,7 +17,7 @@ PLAN_HBM = 1
 # every symbol include/plinopt_hip.h declares
 EXPORTS = [
     "plo_init", "plo_shutdown", "plo_last_error", "plo_device_count",
-    "plo_cse_plan_create", "plo_cse_plan_create_ex", "plo_cse_plan_is_hbm", "plo_cse_plan_hbm_counters", "plo_cse_plan_destroy",
+    "plo_cse_plan_create", "plo_cse_plan_create_ex", "plo_cse_plan_is_hbm", "plo_cse_plan_hbm_counters", "plo_cse_plan_hbm_counters_ex", "plo_cse_plan_destroy",
     "plo_cse_search_plan", "plo_cse_search", "plo_cse_search_multi", "plo_multi_comm_inits", "plo_kernel_search_multi", "plo_tril_search_multi",
     "plo_cse_cost_many_plan", "plo_cse_cost_many",
     "plo_cse_chain_create", "plo_cse_chain_destroy", "plo_cse_chain_search", "plo_cse_chain_cost_many", "plo_cse_chain_batch", "plo_kernel_search",
@@ -104,6 +104,7 @@ def lib():
                                              ctypes.POINTER(ctypes.c_void_p)]
         L.plo_cse_plan_is_hbm.argtypes = [ctypes.c_void_p]
         L.plo_cse_plan_hbm_counters.argtypes = [ctypes.c_void_p, u32p]
+        L.plo_cse_plan_hbm_counters_ex.argtypes = [ctypes.c_void_p, u32p, ctypes.c_uint32]
         L.plo_cse_plan_destroy.argtypes = [ctypes.c_void_p]
         L.plo_cse_search_plan.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
                                           ctypes.POINTER(Best), ctypes.POINTER(Stats)]

@@ -43,13 +43,27 @@ struct HipCob {
     }
 };
 
+// An enumeration of fewer candidate rows than this is walked on the host even with --gpu 1: the (block, row) enumerations of a run
+// are sequential by definition (each tests independence against every row chosen before, include/plinopt_sparsify.inl:172-175,
+// 282-314), so a small one costs a launch + two copies (~0.1 ms) for microseconds of work -- measured on BASELINE configs[2] as
+// written, `sparsifier -c 4` (32 enumerations of 256 rows): 0.175 s on the GPU against 0.008 s on the host.  The GPU pays from
+// about 12 coefficients (2e4 rows) on; --gpu-min-rows N moves the threshold (0: everything on the GPU).
+uint64_t g_gpu_min_rows = 20000;
+
 // GPU backend of the enumeration (Z_p only)
 struct CobGpuBackend : CobBackend<ZpField> {
-    HipCob &L; double kernel_ms = 0; uint64_t launches = 0;
+    HipCob &L; double kernel_ms = 0; uint64_t launches = 0, small_on_host = 0;
+    CobHostBackend<ZpField> host;
     explicit CobGpuBackend(HipCob &l) : L(l) {}
     CobBest best(const ZpField &f, const DMat<uint32_t> &TM, const DMat<uint32_t> &Cand, size_t row, size_t off,
                  const std::vector<uint32_t> &coeffs, int w0, int w1) override {
         const size_t n = TM.size(), m = n ? TM[0].size() : 0;
+        if ((uint64_t)coeffs.size() * coeffs.size() * coeffs.size() * coeffs.size() < g_gpu_min_rows) {
+            const uint64_t c0 = host.candidates;
+            CobBest r = host.best(f, TM, Cand, row, off, coeffs, w0, w1);
+            this->candidates += host.candidates - c0; ++small_on_host;
+            return r;
+        }
         std::vector<uint32_t> tm(n * m), cd(n * n);
         for (size_t i = 0; i < n; ++i) { std::copy(TM[i].begin(), TM[i].end(), tm.begin() + i * m); std::copy(Cand[i].begin(), Cand[i].end(), cd.begin() + i * n); }
         plo_cob_best_t b{}; plo_stats_t st{};
@@ -69,13 +83,19 @@ struct CobGpuBackend : CobBackend<ZpField> {
 // independence test).  The two runs must name the same candidate and that candidate is re-evaluated over Q on the host
 // (independence by rank, both zero counts); anything else sends this (block, row) to the host enumeration over Q.
 struct CobGpuQBackend : CobBackend<QField> {
-    HipCob &L; double kernel_ms = 0; uint64_t fallbacks = 0, gpu_calls = 0, launches = 0;
+    HipCob &L; double kernel_ms = 0; uint64_t fallbacks = 0, gpu_calls = 0, launches = 0, small_on_host = 0;
     CobHostBackend<QField> host;
     explicit CobGpuQBackend(HipCob &l) : L(l) {}
     static int64_t lcm64(int64_t a, int64_t b) { int64_t x = a, y = b; while (y) { int64_t t = x % y; x = y; y = t; } __int128 r = (__int128)a / x * b; if (r > ((__int128)1 << 40)) throw std::overflow_error("denominators too large"); return (int64_t)r; }
     CobBest best(const QField &f, const DMat<Rat> &TM, const DMat<Rat> &Cand, size_t row, size_t off, const std::vector<Rat> &coeffs, int w0, int w1) override {
         const size_t n = TM.size(), m = n ? TM[0].size() : 0, C = coeffs.size();
         static const uint32_t primes[2] = {2147483647u, 2147483629u};
+        if ((uint64_t)C * C * C * C < g_gpu_min_rows) {                           // too small to pay for a launch: see g_gpu_min_rows
+            const uint64_t c0 = host.candidates;
+            CobBest r = host.best(f, TM, Cand, row, off, coeffs, w0, w1);
+            this->candidates += host.candidates - c0; ++small_on_host;
+            return r;
+        }
         try {
             // integer images: TM by one common factor, the coefficients by one common factor, every chosen row by its own
             int64_t dT = 1, dC = 1;
@@ -197,6 +217,7 @@ int main(int argc, char **argv)
                       << "  -U [1|0]: initial LU factorization (default) or not\n"
                       << "  -M/-P/-S/-L: selects the ouput format\n"
                       << "  --gpu #: 1 = enumerate the candidate rows on the MI355X (default), 0 = host only\n"
+                      << "  --gpu-min-rows #: enumerations of fewer candidate rows stay on the host (default 20000; 0 = all on the GPU)\n"
                       << "  --host-q: without -q (rationals) enumerate on the host (default: on the GPU modulo two primes, winners checked over Q)\n";
             exit(-1);
         } else if (a == "-q" && i + 1 < argc) q = strtoull(argv[++i], nullptr, 10);
@@ -209,6 +230,7 @@ int main(int argc, char **argv)
         else if (a == "-U" && i + 1 < argc) initialElimination = atoi(argv[++i]) != 0;
         else if (a == "--gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
         else if (a == "--host-q") gpu_q = false;
+        else if (a == "--gpu-min-rows" && i + 1 < argc) g_gpu_min_rows = strtoull(argv[++i], nullptr, 10);
         else filename = a;
     }
     try {
@@ -228,7 +250,8 @@ int main(int argc, char **argv)
                 if (!L.load() || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return 2; }
                 CobGpuBackend B(L);
                 int rc = tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
-                std::clog << "# GPU: " << B.launches << " launches, enumeration kernels " << B.kernel_ms << " ms, " << (B.kernel_ms > 0 ? B.candidates / (B.kernel_ms * 1e-3) : 0.0) << " candidate rows/s" << std::endl;
+                std::clog << "# GPU: " << B.launches << " launches, enumeration kernels " << B.kernel_ms << " ms, " << (B.kernel_ms > 0 ? B.candidates / (B.kernel_ms * 1e-3) : 0.0) << " candidate rows/s"
+                          << "; " << B.small_on_host << " enumerations of fewer than " << g_gpu_min_rows << " rows on the host (--gpu-min-rows)" << std::endl;
                 return rc;
             }
             CobHostBackend<ZpField> B;
@@ -241,7 +264,8 @@ int main(int argc, char **argv)
             if (!L.load() || L.init(0) != PLO_OK) { std::cerr << "# \033[1;31mERROR: cannot use the GPU: " << (L.last_error ? L.last_error() : "library missing") << "\033[0m" << std::endl; return 2; }
             CobGpuQBackend B(L);
             int rc = tsparsifier(f, rebind(MQ, f), B, fmt, blocksize, maxnumcoeff, initialElimination);
-            std::clog << "# GPU (Q, two 31-bit primes + check over Q): " << B.gpu_calls << " enumerations in " << B.launches << " launches (both moduli of an enumeration in one), kernels " << B.kernel_ms << " ms, " << B.fallbacks << " on the host" << std::endl;
+            std::clog << "# GPU (Q, two 31-bit primes + check over Q): " << B.gpu_calls << " enumerations in " << B.launches << " launches (both moduli of an enumeration in one), kernels " << B.kernel_ms << " ms, " << B.fallbacks << " on the host; "
+                      << B.small_on_host << " enumerations of fewer than " << g_gpu_min_rows << " rows on the host (--gpu-min-rows)" << std::endl;
             return rc;
         }
         CobHostBackend<QField> B;

@@ -4,9 +4,10 @@
 // stdout = the program (a_i, b_j restored, c_k += the bilinear map), clog = '#' statistics
 // ("ADD / SCA / AXPY" as the reference :170-180).  The restart loop of
 // SearchTriLinearAlgorithm (include/plinopt_inplace.inl:837-924) runs on the GPU through
-// plo_tril_search of libplinopt_hip.so when the three matrices are +-1 matrices without
-// empty rows; the winner is replayed on the host to print it.  Other inputs, or --gpu 0,
-// use the host loop (OpenMP).  -e: the expanded variant (TransposedDoubleAlgorithm on DoubleExpand(P^T)).
+// plo_tril_search[_multi] of libplinopt_hip.so when the three matrices have no empty row and no
+// row of more than 64 entries (rational coefficients as residues modulo a 31-bit prime); the winner
+// is replayed on the host over Q to print it.  Other inputs, or --gpu 0, use the host loop (OpenMP).
+// -e: the expanded variant (TransposedDoubleAlgorithm on DoubleExpand(P^T)), on the device too.
 // ==========================================================================
 #include "plo_inplace.hpp"
 #include "../../../include/plinopt_hip.h"
@@ -49,7 +50,13 @@ ICsr icsr(const QMat &M) {
     ICsr c;
     for (const auto &row : M.rows) {
         if (row.empty() || row.size() > 64) c.full = false;
-        for (const auto &e : row) { c.col.push_back((uint32_t)e.first); if (!(e.second.d == 1 && (e.second.n == 1 || e.second.n == -1))) c.unit = false; c.num.push_back((int64_t)e.second.n); c.den.push_back((int64_t)e.second.d); }
+        for (const auto &e : row) {
+            c.col.push_back((uint32_t)e.first);
+            if (!(e.second.d == 1 && (e.second.n == 1 || e.second.n == -1))) c.unit = false;
+            // (Rat is 128 bits wide; the C-ABI takes 64-bit numerators and denominators: a wider coefficient keeps the matrix on the host)
+            if (e.second.n > (__int128)INT64_MAX || e.second.n < -(__int128)INT64_MAX || e.second.d > (__int128)INT64_MAX || e.second.d < -(__int128)INT64_MAX) c.full = false;
+            c.num.push_back((int64_t)e.second.n); c.den.push_back((int64_t)e.second.d);
+        }
         c.rp.push_back((uint32_t)c.col.size());
     }
     return c;
@@ -85,8 +92,8 @@ int main(int argc, char **argv) {
         bool on_gpu = false; double kms = 0;
         if (loops > 0) {
             ICsr ca = icsr(A), cb = icsr(B), ct = icsr(T);
-            // device path: no empty row, rows of at most 64 entries; with -e only +-1 coefficients (TransposedDoubleAlgorithm on the device is the unit form)
-            const bool device_ok = ca.full && cb.full && ct.full && (!expanded || (ca.unit && cb.unit && ct.unit));
+            // device path: no empty row, rows of at most 64 entries, coefficients that fit 64 bits (-e included: round 4)
+            const bool device_ok = ca.full && cb.full && ct.full;
             using Key = std::tuple<size_t, size_t, uint64_t, int>;      // (ADD, SCA, seed, variant): the order of :893-897 made total
             // restarts s0 .. s0+cnt-1 on one device (plo_tril_search); throws on failure
             auto gpu_search = [&](int device, uint64_t s0, uint64_t cnt, plo_tril_best_t &r, plo_stats_t &st) {
@@ -172,7 +179,7 @@ int main(int argc, char **argv) {
                     const Tricount g{r.add, r.sca, r.mul};
                     if (better(g, best)) { best = g; bseed = r.seed; bvar = (int)r.variant; }
                 } else {
-                    if (gpu) std::clog << "# an empty row, a row of more than 64 entries, or -e with coefficients other than +-1: host search" << std::endl;
+                    if (gpu) std::clog << "# an empty row, a row of more than 64 entries or a coefficient wider than 64 bits: host search" << std::endl;
                     // best of the loop under (ADD, SCA, seed, variant), then strictly better than the unpermuted program
                     const Key lb = host_loop(seed0, loops);
                     const Tricount g{std::get<0>(lb), std::get<1>(lb), A.rowdim()};

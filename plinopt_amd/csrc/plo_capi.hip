@@ -300,6 +300,7 @@ int build_big_plan(plo_plan *pl)
     pl->pairs0 = pairs0; pl->distinct0 = keys.size();
     pl->algo_bytes = 8ull * nnz + 16ull * keys.size();       // distinct-triple form of B_cand for HBM-resident candidates
     B.prune = getenv("PLO_BIG_NOPRUNE") ? 0u : 1u;
+    B.fwin = 2048u; if (const char *e = getenv("PLO_BIG_FWIN")) B.fwin = (uint32_t)std::min<long>(2048, std::max<long>(64, strtol(e, nullptr, 10) / 64 * 64));   // test knob: windows of the flat sweep (a multiple of 64 entries)
     if (B.prune) {   // triples of frequency 1 are never chosen and never grow: they are not kept (plo_cse_big.hip, "pruning")
         size_t w = 0;
         for (size_t k = 0; k < keys.size(); ++k) if (cnts[k] >= 2u) { keys[w] = keys[k]; cnts[w] = cnts[k]; ++w; }
@@ -731,6 +732,19 @@ int plo_cse_plan_hbm_counters(const plo_plan_t *pl, uint32_t out[8])
     HIPCHK(hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost));
     for (int k = 0; k < 7; ++k) out[k] = hs[32 + k];
     out[7] = pl->big_refits;
+    return PLO_OK;
+}
+
+int plo_cse_plan_hbm_counters_ex(const plo_plan_t *pl, uint32_t *out, uint32_t n)
+{
+    if (!pl || !out || n > 10u) return fail(PLO_E_ARG, "bad argument");
+    uint32_t o[10] = {0};
+    const int rc = plo_cse_plan_hbm_counters(pl, o);
+    if (rc != PLO_OK) return rc;
+    uint32_t hs[64];
+    HIPCHK(hipMemcpy(hs, pl->d_stats, sizeof hs, hipMemcpyDeviceToHost));
+    o[8] = hs[53]; o[9] = hs[54];
+    for (uint32_t k = 0; k < n; ++k) out[k] = o[k];
     return PLO_OK;
 }
 
@@ -1772,12 +1786,11 @@ int plo_tril_plan_create_q(const plo_qcsr_t *A, const plo_qcsr_t *B, const plo_q
             }
         }
         cap = std::max(cap, 2u * nnz + 3u * M->m);
-        if (expanded && M == T) cap = std::max(cap, 4u * nnz + 2u * M->m);        // TransposedDoubleAlgorithm: 4(len-1)+2 atoms per row
+        if (expanded && M == T) cap = std::max(cap, 4u * nnz + 6u * M->m);        // TransposedDoubleAlgorithm: 4(len-1)+2 atoms per row, and 4 scaling atoms when the pivot is not +-1
         if (expanded && M == T && M->n >= 16382u) return fail(PLO_E_CAPACITY, "one more variable of c than the atom holds");
         bytes += round_up((M->m + 1) * 2, 16) + round_up(nnz * 2, 16) + round_up(nnz, 16) + round_up(nnz * 4, 16);
         algo += 2ull * (M->m + 1) + 3ull * nnz;                 // the CSR image of the three matrices, once per candidate
     }
-    if (expanded && !unit) return fail(PLO_E_UNSUPPORTED, "trilplacer -e with coefficients other than +-1: host path only");
     cap = round_up(cap + 2, 64);
     plo_tril_plan *pl = new plo_tril_plan();
     pl->rational = !unit;

@@ -51,8 +51,11 @@
 //              serves them (agent scope = memory side of the fabric on a part whose
 //              XCD L2s are not coherent with each other: 2.3x slower).
 // The work per candidate is ~2.5e8 pair retirements + 1.2e8 pair insertions (1.5e7 table
-// updates after aggregation); 6.7e7 L2 requests and 3.1 GB of HBM traffic per candidate:
-// the kernel runs at the memory system's random-access request rate.
+// updates after aggregation).  Round 4 state: 5.8e7 L2 requests and 1.85 GB of HBM traffic per
+// candidate (30x the algorithmic bytes), and NOT bound by the memory system: a candidate alone
+// on the chip takes 0.44 s, 512 together 0.63 s each -- the bound is the dependent chain of one
+// workgroup per candidate, two per CU (round 2's "random-access request rate"
+// diagnosis was retracted in round 3).
 // ===========================================================================
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -84,6 +87,7 @@ struct BigPlan {
              o_tl, o_clen, o_keep;            // per-candidate row lists of the input columns (compacted as they are walked), live length per column, scratch
     // deferred cold updates (DEFER, see "deferred" below): hot table + partitioned store + update log instead of one big table
     uint32_t defer, pbits, capp, plcap, logcap, logtrig, hwin, hotbits_min, hotbits_max, lgrp;
+    uint32_t fwin;                        // entries per window of the flat sweep (2048 = 32 trips: the marks of a window are 32 words per wave; a test knob makes it smaller)
     const uint64_t *st0; const uint32_t *pcount0;     // store image: 2^pbits partitions of capp entries (key48<<16 | count16), entries per partition
     uint64_t o_store, o_pcount, o_ptail, o_log, o_plog, o_hot;
 };
@@ -475,7 +479,7 @@ __device__ __forceinline__ int row_find(const uint32_t *ent, uint32_t base, uint
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r, aggn, nspill, keepn; uint64_t kprime; uint64_t selkey;
-    uint32_t nbisect, spilltot, listover;   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
+    uint32_t nbisect, spilltot, listover, nwin, nsearched;   // nwin: windows of the flat sweep beyond the first of a batch of rows (thread 0's wave); nsearched: rows walked by the row search   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
     uint32_t logn, hotn, hotbits, nforced, hotops, logtot_lo, logtot_hi;   // DEFER: log fill, claimed hot slots, hot table size; diagnostics: merges forced by log/hot pressure, updates served by the hot table, log entries written
     uint32_t derr; unsigned long long tmg[4], tmb[4]; uint32_t ngrp; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
     uint32_t cblk[512];            // level-M triple counts per block of 64 first columns (NCmax <= 32768)
@@ -887,7 +891,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
 #ifdef PLO_BIG_PROFILE
         for (int q = 0; q < 4; ++q) { sh.tb1[q] = sh.tb2[q] = 0; sh.nb[q] = 0; } sh.fb1 = sh.fb2 = sh.fl1 = sh.fl2 = 0; for (int q = 0; q < 16; ++q) sh.pw[q] = 0; for (int c_ = 0; c_ < 4; ++c_) for (int q = 0; q < 8; ++q) sh.tpc[c_][q] = 0;
 #endif
-        sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0; sh.nbisect = 0; sh.spilltot = 0; sh.listover = 0;
+        sh.errflag = 0; sh.fullscans = 0; sh.rebuilds = 0; sh.steps = 0; sh.hlbad = 0; ncrptr[0] = 0; sh.nbisect = 0; sh.spilltot = 0; sh.listover = 0; sh.nwin = 0; sh.nsearched = 0;
         sh.logn = 0; sh.hotn = 0; sh.hotbits = P.hotbits_min; sh.derr = 0; for (int q = 0; q < 4; ++q) { sh.tmg[q] = 0; sh.tmb[q] = 0; } sh.ngrp = 0; sh.nforced = 0; sh.hotops = 0; sh.logtot_lo = 0; sh.logtot_hi = 0;
     }
     PLO_BIG_FENCE(); BSYNC();
@@ -1090,6 +1094,7 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
             const uint32_t na = gload32(&clen[a]), nb = gload32(&clen[b]);          // live lengths: what earlier walks left of the lists
             const bool walk_a = na <= nb;
             const uint32_t *lst = walk_a ? la : lb; const uint32_t ln = walk_a ? na : nb;
+            if (tid == 0) sh.nsearched += ln;
             // Two rows per thread and trip, both columns of both rows searched in lock step: the four binary searches have
             // their loads in flight together (8 dependent memory round trips for two rows instead of 36).  A search keeps
             // the last entry it saw at its upper bound: when it ends that is the entry at the found position.
@@ -1336,14 +1341,16 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
                 const uint32_t E = wave_incl_scan(Lr), S = E - Lr, T = RL(E, 63);
                 const uint32_t safe = RL(R0.y, 0);
                 uint32_t qlo = 0;
-                for (uint32_t w0 = 0; w0 < T; w0 += 2048u) {
+                const uint32_t FW = P.fwin;
+                for (uint32_t w0 = 0; w0 < T; w0 += FW) {
+                    if (w0 && tid == 0) ++sh.nwin;
                     if (lane < 32u) __hip_atomic_store(&fm[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier();
-                    if (have && E >= w0 && E - w0 < 2048u) wg_or((unsigned long long *)&fm[(E - w0) >> 6], 1ull << (E & 63u));
+                    if (have && E >= w0 && E - w0 < FW) wg_or((unsigned long long *)&fm[(E - w0) >> 6], 1ull << (E & 63u));
                     __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier();
                     const uint64_t mreg = __hip_atomic_load(&fm[lane & 31u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const uint32_t mrl = (uint32_t)mreg, mrh = (uint32_t)(mreg >> 32);
-                    const uint32_t ntw = ((T - w0 < 2048u ? T - w0 : 2048u) + 63u) >> 6;
+                    const uint32_t ntw = ((T - w0 < FW ? T - w0 : FW) + 63u) >> 6;
                     // Trip t_: the row of each lane (advances qlo), the row's record fetched from the lane that holds it -- four
                     // ds_bpermute in flight together, one wait -- and the request for the entry.  A mark at bit i says "a row ended
                     // before position i": rows ended at or below a lane = bit 0 + v_mbcnt of the mask shifted right by one.
@@ -1830,6 +1837,9 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
 }
 
 
+#ifndef PLO_TRI_R
+#define PLO_TRI_R 4u               /* Triangle: registers per lane holding the rows of a column (64 rows each) */
+#endif
 #define PLO_PGFLAG 0x8000u
 #define PLO_PGCNT 0x7FFFu
 #define PLO_BFRESH 0xFFFFFFFFu
@@ -1989,53 +1999,86 @@ __device__ __forceinline__ uint64_t big_program_gen(const BigPlan &P, uint8_t *w
         }
         PLO_BIG_FENCE(); BSYNC();
         if (wave == 0) {
+            // A column's rows sit one per lane in PLO_TRI_R registers (round 4: 256 rows; one register = 64 rows until round 3): position
+            // q = 64 r + lane, ascending q = ascending row -- the order in which the reference scans the column (:433-447).
+            constexpr uint32_t R = PLO_TRI_R;
             uint32_t mulacc = 0, addacc = 0;
             for (uint32_t x = 0; x < nc2; ++x) {
                 const uint32_t j = cols2[x], k = tptr2[x + 1] - tptr2[x];
-                if (k > 64u) { if (lane == 0) wg_max(&sh.errflag, (uint32_t)BERR_PGEN); break; }
-                const uint32_t row = lane < k ? tlist[tptr2[x] + lane] : 0xFFFFFFFFu;
+                if (k > 64u * R) { if (lane == 0) wg_max(&sh.errflag, (uint32_t)BERR_PGEN); break; }
+                uint32_t row[R];
+#pragma unroll
+                for (uint32_t r = 0; r < R; ++r) row[r] = 64u * r + lane < k ? tlist[tptr2[x] + 64u * r + lane] : 0xFFFFFFFFu;
                 bool found = false;
                 for (;;) {
-                    uint32_t vj = 0, ivj = 0; bool mine = false;
-                    if (row != 0xFFFFFFFFu) {
-                        const uint32_t base = P.rs[row], L = len[row];
-                        for (uint32_t z = 0; z < L; ++z) if (col[base + z] == j) { vj = val[base + z]; ivj = inv[base + z]; mine = !babsone(vj, p); break; }
-                    }
-                    const uint64_t NU = __ballot(mine);
-                    if (__popcll(NU) < 2) break;
-                    int it = -1, nx = -1;
-                    uint64_t scan = found ? (1ull << __builtin_ctzll(NU)) : NU;
-                    while (scan) {
-                        const uint32_t i0 = (uint32_t)__builtin_ctzll(scan); scan &= scan - 1ull;
-                        const uint32_t iv1 = (uint32_t)__shfl((int)ivj, (int)i0);
-                        uint64_t cand = NU & ~(1ull << i0);
-                        if (found) cand = 1ull << __builtin_ctzll(cand);
-                        bool hit = false;
-                        if ((cand >> lane) & 1ull) {
-                            const uint32_t quot = bmul(vj, iv1, p, mu, mers), nq = p - quot;
-                            const uint32_t base = P.rs[row], L = len[row];
-                            for (uint32_t z = 0; z < L; ++z) {
-                                const uint32_t tv = val[base + z];
-                                if (col[base + z] != j && !babsone(tv, p) && (tv == quot || tv == nq)) { hit = true; break; }
-                            }
+                    uint32_t vj[R], ivj[R]; uint64_t NU[R]; uint32_t total = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < R; ++r) {
+                        vj[r] = 0; ivj[r] = 0; bool mine = false;
+                        if (row[r] != 0xFFFFFFFFu) {
+                            const uint32_t base = P.rs[row[r]], L = len[row[r]];
+                            for (uint32_t z = 0; z < L; ++z) if (col[base + z] == j) { vj[r] = val[base + z]; ivj[r] = inv[base + z]; mine = !babsone(vj[r], p); break; }
                         }
-                        const uint64_t hm = __ballot(hit);
-                        if (hm) { it = (int)i0; nx = (int)__builtin_ctzll(hm); break; }
+                        NU[r] = __ballot(mine); total += (uint32_t)__popcll(NU[r]);
+                    }
+                    if (total < 2u) break;
+                    // first and second position holding a non +-1 entry (after the first hit only that couple is looked at again, :453-498)
+                    int q1 = -1, q2 = -1;
+#pragma unroll
+                    for (uint32_t r = 0; r < R; ++r) { uint64_t mm = NU[r]; while (mm && q2 < 0) { const int q = (int)(64u * r) + (int)__builtin_ctzll(mm); mm &= mm - 1ull; if (q1 < 0) q1 = q; else q2 = q; } }
+                    int it = -1, nx = -1;
+                    for (uint32_t ri = 0; ri < R && it < 0; ++ri) {
+                        uint64_t scan = NU[ri];
+                        while (scan) {
+                            const uint32_t li = (uint32_t)__builtin_ctzll(scan); scan &= scan - 1ull;
+                            const int qi = (int)(64u * ri + li);
+                            if (found && qi != q1) { scan = 0; break; }
+                            uint32_t iv1 = 0;
+#pragma unroll
+                            for (uint32_t r = 0; r < R; ++r) if (r == ri) iv1 = (uint32_t)__shfl((int)ivj[r], (int)li);
+                            int first = -1;
+#pragma unroll
+                            for (uint32_t r = 0; r < R; ++r) {
+                                const int q = (int)(64u * r + lane);
+                                bool cand = ((NU[r] >> lane) & 1ull) && q != qi;
+                                if (found) cand = cand && q == (qi == q1 ? q2 : q1);
+                                bool hit = false;
+                                if (cand) {
+                                    const uint32_t quot = bmul(vj[r], iv1, p, mu, mers), nq = p - quot;
+                                    const uint32_t base = P.rs[row[r]], L = len[row[r]];
+                                    for (uint32_t z = 0; z < L; ++z) {
+                                        const uint32_t tv = val[base + z];
+                                        if (col[base + z] != j && !babsone(tv, p) && (tv == quot || tv == nq)) { hit = true; break; }
+                                    }
+                                }
+                                const uint64_t hm = __ballot(hit);
+                                if (hm && first < 0) first = (int)(64u * r) + (int)__builtin_ctzll(hm);
+                            }
+                            if (first >= 0) { it = qi; nx = first; break; }
+                            if (found) { scan = 0; break; }
+                        }
+                        if (found) break;                                   // (only the first position is a pivot then)
                     }
                     if (it < 0) break;
                     found = true;                                           // :453-498
-                    const uint32_t v1 = (uint32_t)__shfl((int)vj, it), iv1 = (uint32_t)__shfl((int)ivj, it);
+                    uint32_t v1 = 0, iv1 = 0, vn = 0, ivn = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < R; ++r) {
+                        if ((uint32_t)(it >> 6) == r) { v1 = (uint32_t)__shfl((int)vj[r], it & 63); iv1 = (uint32_t)__shfl((int)ivj[r], it & 63); }
+                        if ((uint32_t)(nx >> 6) == r) { vn = (uint32_t)__shfl((int)vj[r], nx & 63); ivn = (uint32_t)__shfl((int)ivj[r], nx & 63); }
+                    }
                     ++mulacc;
                     if (lane == 0) if (!gtab_flag(tab, ((uint64_t)j << rb) | v1, PLO_PGFLAG, hb)) wg_max(&sh.errflag, (uint32_t)BERR_TABLE);
-                    if ((int)lane == it) {
-                        const uint32_t base = P.rs[row], L = len[row];
-                        for (uint32_t z = 0; z < L; ++z) if (col[base + z] == j) { col[base + z] = PLO_BFRESH; val[base + z] = 1u; inv[base + z] = 1u; break; }
-                    }
+                    uint32_t rit = 0, rnx = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < R; ++r) { if ((uint32_t)(it >> 6) == r) rit = (uint32_t)__shfl((int)row[r], it & 63); if ((uint32_t)(nx >> 6) == r) rnx = (uint32_t)__shfl((int)row[r], nx & 63); }
                     uint32_t addone = 0;
-                    if ((int)lane == nx) {
-                        const uint32_t quot = bmul(vj, iv1, p, mu, mers), iquot = bmul(ivj, v1, p, mu, mers);
+                    if (lane == 0) {
+                        {   const uint32_t base = P.rs[rit], L = len[rit];
+                            for (uint32_t z = 0; z < L; ++z) if (col[base + z] == j) { col[base + z] = PLO_BFRESH; val[base + z] = 1u; inv[base + z] = 1u; break; } }
+                        const uint32_t quot = bmul(vn, iv1, p, mu, mers), iquot = bmul(ivn, v1, p, mu, mers);
                         const uint32_t eq = babs(quot, p), ieq = (quot == eq) ? iquot : p - iquot;
-                        const uint32_t base = P.rs[row], L = len[row];
+                        const uint32_t base = P.rs[rnx], L = len[rnx];
                         uint32_t w = 0, f = 1;
                         for (uint32_t z = 0; z < L; ++z) {
                             const uint32_t cz = col[base + z], tv = val[base + z], ti = inv[base + z];
@@ -2044,10 +2087,10 @@ __device__ __forceinline__ uint64_t big_program_gen(const BigPlan &P, uint8_t *w
                             col[base + w] = cz; val[base + w] = tv; inv[base + w] = ti; ++w;
                         }
                         col[base + w] = PLO_BFRESH; val[base + w] = eq; inv[base + w] = ieq; ++w;
-                        len[row] = w;
+                        len[rnx] = w;
                         addone = f - 1u;
                     }
-                    addacc += (uint32_t)__shfl((int)addone, nx);
+                    addacc += (uint32_t)__shfl((int)addone, 0);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -2122,7 +2165,7 @@ template <int MODE, bool DEFER> __global__ __launch_bounds__(PLO_BIG_THREADS, 4)
             const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
-            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u); atomicAdd(&J.stats[39], sh.nforced); atomicMax(&J.stats[43], sh.derr); for (int q = 0; q < 4; ++q) { J.stats[44 + q] = (uint32_t)(sh.tmg[q] / 100ull); J.stats[48 + q] = (uint32_t)(sh.tmb[q] / 100ull); } J.stats[52] = sh.ngrp; atomicAdd(&J.stats[40], sh.hotops); { const uint32_t lo_ = atomicAdd(&J.stats[41], sh.logtot_lo); if (lo_ + sh.logtot_lo < lo_) atomicAdd(&J.stats[42], 1u); atomicAdd(&J.stats[42], sh.logtot_hi); }
+            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u); atomicAdd(&J.stats[39], sh.nforced); atomicMax(&J.stats[43], sh.derr); for (int q = 0; q < 4; ++q) { J.stats[44 + q] = (uint32_t)(sh.tmg[q] / 100ull); J.stats[48 + q] = (uint32_t)(sh.tmb[q] / 100ull); } J.stats[52] = sh.ngrp; atomicAdd(&J.stats[53], sh.nwin); atomicAdd(&J.stats[54], sh.nsearched); atomicAdd(&J.stats[40], sh.hotops); { const uint32_t lo_ = atomicAdd(&J.stats[41], sh.logtot_lo); if (lo_ + sh.logtot_lo < lo_) atomicAdd(&J.stats[42], 1u); atomicAdd(&J.stats[42], sh.logtot_hi); }
                 J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull);
 #ifdef PLO_BIG_PROFILE
                 for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }

@@ -18,9 +18,9 @@
 //   pushvariables (:322-393)  per output variable, "next atom of the variable" and
 //                         "first atom that stops the push" are ballot scans; a rotation
 //                         is a parallel shift of the LDS arrays.
-// Coefficients: device path for matrices with entries +-1 and no empty row (every
-// multiplicative atom is then *-1 and additive values are small integers); anything
-// else is reported as unsupported and stays on the host.
+// Coefficients: +-1 (small signed values in the atoms) or rationals as residues modulo a
+// 31-bit prime (tril_kernel<true>), `-e` included; an empty row or a row of more than 64
+// entries is reported as unsupported and stays on the host.
 // ==========================================================================
 #pragma once
 #include <hip/hip_runtime.h>
@@ -417,65 +417,84 @@ template <bool RAT> __device__ void t_linear(TrilProg &P, const TrilMat &M, cons
     ops[0] = a; ops[1] = s; ops[2] = mu;
 }
 
-// `trilplacer -e`: TransposedDoubleAlgorithm (:507-598) on DoubleExpand(T) (:676-716) for +-1 matrices.  Row l of T stands
-// for the pair of rows (2l, 2l+1) of the expanded matrix -- the block <<a|c>,<0|a>> on the variables i = first column and
-// i+1 -- and gives 2(len-1) atoms, the two barriers of one double-size AXPY, and 2(len-1) atoms again (one trip per pair
-// of expanded rows: see oracle/plo_tril_oracle.c).  a = +-1, so y = 1/a = a, z = -c and no scaling atom exists.  No random
-// draw: the first entry is the pivot.
+// `trilplacer -e`: TransposedDoubleAlgorithm (:507-598) on DoubleExpand(T) (:676-716).  Row l of T stands for the pair of rows
+// (2l, 2l+1) of the expanded matrix -- the block <<a|c>,<0|a>> on the variables i = first column and i+1 -- and gives, in the
+// reference's order (:532-571): the scaling by y = 1/a (`*y` on i+1, the atom of z = -y c y when the row holds column i+1, `*y` on
+// i; no scaling atom when a = +-1), two atoms per further entry (one for the entry at i+1), the two barriers of one double-size
+// AXPY, the same atoms with the opposite sign, and the un-scaling (`*a`, the atom of c, `*a`).  One trip per pair of expanded
+// rows: see oracle/plo_tril_oracle.c.  No random draw: the first entry is the pivot.  RAT = false: entries +-1 (y = a, z = -c);
+// RAT = true (round 4): residues of rationals modulo `prime`, as in t_linear.
 template <bool RAT> __device__ void t_double(TrilProg &P, const TrilMat &M, const uint16_t *perm, const uint8_t *sgn, uint32_t sbit, uint32_t lane,
-                         uint32_t ops[3], uint32_t cap, uint32_t *errw, uint32_t *bm) {
+                         uint32_t ops[3], uint32_t cap, uint32_t *errw, uint32_t *bm, uint32_t prime) {
     P.n = 0;
+    const int ONE = 1, MONE = RAT ? (int)(prime - 1u) : -1;
     for (uint32_t l = 0; l < M.m; ++l) {
         const uint32_t r = perm[l], b = M.rp[r], len = (uint32_t)M.rp[r + 1u] - b;
         if (len == 0 || len > 64u) { if (lane == 0) atomicMax(errw, (uint32_t)TERR_ROW); return; }
-        if (P.n + 4u * len > cap) { if (lane == 0) atomicMax(errw, (uint32_t)TERR_CAP); return; }
+        if (P.n + 4u * len + 4u > cap) { if (lane == 0) atomicMax(errw, (uint32_t)TERR_CAP); return; }
         const bool neg = (sgn[l] >> sbit) & 1u;
         int c = -1, v = 0;
-        if (lane < len) { c = M.col[b + lane]; v = M.val[b + lane]; if (neg) v = -v; }
+        if (lane < len) {
+            c = M.col[b + lane];
+            if constexpr (RAT) { const uint32_t x = M.valp[b + lane]; v = (int)(neg ? (x ? prime - x : 0u) : x); }
+            else { v = M.val[b + lane]; if (neg) v = -v; }
+        }
         const int i = __builtin_amdgcn_readlane(c, 0), a = __builtin_amdgcn_readlane(v, 0), ci = i + 1;
         const int c1 = __builtin_amdgcn_readlane(c, 1), v1 = __builtin_amdgcn_readlane(v, 1);
         const bool has_c = len > 1u && c1 == ci;                                                      // :524-529
-        const uint32_t base = P.n, bar = base + 2u * (len - 1u), base2 = bar + 2u;
-        const uint32_t o1 = a == -1 ? T_ADD : T_SUB;           // MONEOP('-', y), y = a
-        const uint32_t o2 = a == -1 ? T_SUB : T_ADD;           // MONEOP('+', a) (and MONEOP('+', y))
+        const bool amone = a == MONE;
+        const uint32_t sc = (a != ONE && !amone) ? 1u : 0u;                                            // notAbsOne(y) <=> notAbsOne(a)
+        int y = a, z = -v1;                                                                            // +-1: y = a, z = -a c a = -c
+        if constexpr (RAT) {
+            y = (int)t_invmod((uint32_t)a, prime);
+            const uint32_t yc = t_mulmod(t_mulmod((uint32_t)y, (uint32_t)v1, prime), (uint32_t)y, prime);
+            z = (int)(yc ? prime - yc : 0u);                                                          // z = - a^-1 c a^-1 (:527-529)
+        }
+        const uint32_t base = P.n, e0 = base + 2u * sc + (has_c ? 1u : 0u), bar = base + 2u * sc + 2u * (len - 1u), base2 = bar + 2u;
+        const uint32_t end2 = base2 + 2u * (len - 1u) - (has_c ? 1u : 0u);
+        const uint32_t o1 = amone ? T_ADD : T_SUB;             // MONEOP('-', y): y is -1 iff a is
+        const uint32_t o2 = amone ? T_SUB : T_ADD;             // MONEOP('+', a) and MONEOP('+', y)
         if (lane >= 1u && lane < len) {
             if (has_c && lane == 1u) {
-                P.at[base + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o1);                               // :541-542 (the entry at i+1 only moves to i+2)
-                P.at[base2] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o2);                                   // :556-557
+                P.at[e0] = ta_make<RAT>((uint32_t)(c + 1), ci, (uint32_t)v, o1);                             // :541-542 (the entry at i+1 only moves to i+2)
+                P.at[base2] = ta_make<RAT>((uint32_t)(c + 1), ci, (uint32_t)v, o2);                          // :556-557
             } else {
-                const uint32_t off = 2u * lane - 2u, off2 = has_c ? 2u * lane - 3u : 2u * lane - 2u;
-                P.at[base + off] = ta_make<RAT>((uint32_t)c, i, v, o1);                                     // :537-540
-                P.at[base + off + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o1);                         // :541-542
-                P.at[base2 + off2] = ta_make<RAT>((uint32_t)c, i, v, o2);                                   // :552-555
-                P.at[base2 + off2 + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, v, o2);                       // :556-557
+                const uint32_t off = has_c ? 2u * lane - 3u : 2u * lane - 2u;
+                P.at[e0 + off] = ta_make<RAT>((uint32_t)c, i, (uint32_t)v, o1);                              // :537-540
+                P.at[e0 + off + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, (uint32_t)v, o1);                  // :541-542
+                P.at[base2 + off] = ta_make<RAT>((uint32_t)c, i, (uint32_t)v, o2);                           // :552-555
+                P.at[base2 + off + 1u] = ta_make<RAT>((uint32_t)(c + 1), ci, (uint32_t)v, o2);               // :556-557
             }
         }
         if (lane == 0) {
+            if (sc) { P.at[base] = ta_make<RAT>((uint32_t)ci, -1, (uint32_t)y, T_MUL); P.at[base + 1u + (has_c ? 1u : 0u)] = ta_make<RAT>((uint32_t)i, -1, (uint32_t)y, T_MUL); }       // :532, :535
             if (has_c) {
-                P.at[base] = ta_make<RAT>((uint32_t)ci, i, -v1, o2);                                        // :532-533: z = -c
-                P.at[base2 + 2u * (len - 1u) - 1u] = ta_make<RAT>((uint32_t)ci, i, v1, o2);                 // :563-564
+                P.at[base + sc] = ta_make<RAT>((uint32_t)ci, i, (uint32_t)z, o2);                            // :533-534
+                P.at[end2 + sc] = ta_make<RAT>((uint32_t)ci, i, (uint32_t)v1, o2);                           // :563-564
             }
-            P.at[bar] = ta_make<RAT>((uint32_t)i, -1, a, T_BAR);                                            // :546-548
-            P.at[bar + 1u] = ta_make<RAT>((uint32_t)ci, -1, a, T_BAR);
+            P.at[bar] = ta_make<RAT>((uint32_t)i, -1, (uint32_t)a, T_BAR);                                    // :546-548
+            P.at[bar + 1u] = ta_make<RAT>((uint32_t)ci, -1, (uint32_t)a, T_BAR);
+            if (sc) { P.at[end2] = ta_make<RAT>((uint32_t)ci, -1, (uint32_t)a, T_MUL); P.at[end2 + 1u + (has_c ? 1u : 0u)] = ta_make<RAT>((uint32_t)i, -1, (uint32_t)a, T_MUL); }         // :561, :565
         }
-        P.n = base + 4u * (len - 1u) + 2u;
+        P.n = base + 4u * sc + 4u * (len - 1u) + 2u;
         TW_SYNC();
     }
+    // (no `*1` atom exists: a scaling atom is only made when a is not +-1, :586-587)
     bool simp;
 #ifdef PLO_TRIL_PASSPUSH
-    do { t_pushvariables<RAT>(P, M.n + 1u, lane, bm); simp = t_simplify<RAT>(P, true, lane, 0u); } while (simp);
+    do { t_pushvariables<RAT>(P, M.n + 1u, lane, bm); simp = t_simplify<RAT>(P, true, lane, prime); } while (simp);
 #else
-    do { t_pushvariables_ref<RAT>(P, M.n + 1u, lane); simp = t_simplify<RAT>(P, true, lane, 0u); } while (simp);
+    do { t_pushvariables_ref<RAT>(P, M.n + 1u, lane); simp = t_simplify<RAT>(P, true, lane, prime); } while (simp);
 #endif
-    uint32_t ad = 0, sc = 0, mu = 0;                                                                   // :133-144
+    uint32_t ad = 0, sca = 0, mu = 0;                                                                  // :133-144
     for (uint32_t k = lane; k < P.n; k += 64u) {
         const uint64_t at = P.at[k]; const uint32_t o = ta_ope<RAT>(at); const int v = ta_val<RAT>(at);
-        if (t_as(o)) { ++ad; if (v != 1 && v != -1) ++sc; }
-        if (t_md(o)) ++sc;
+        if (t_as(o)) { ++ad; if (v != ONE && v != MONE) ++sca; }
+        if (t_md(o)) ++sca;
         if (o == T_BAR) ++mu;
     }
-    for (int off = 32; off > 0; off >>= 1) { ad += __shfl_xor(ad, off); sc += __shfl_xor(sc, off); mu += __shfl_xor(mu, off); }
-    ops[0] = ad; ops[1] = sc; ops[2] = mu >> 1;                                                        // :799: a double-size AXPY holds two barriers
+    for (int off = 32; off > 0; off >>= 1) { ad += __shfl_xor(ad, off); sca += __shfl_xor(sca, off); mu += __shfl_xor(mu, off); }
+    ops[0] = ad; ops[1] = sca; ops[2] = mu >> 1;                                                       // :799: a double-size AXPY holds two barriers
 }
 
 template <bool RAT> __global__ __launch_bounds__(256) void tril_kernel(TrilPlan P, TrilJob J)
@@ -517,7 +536,7 @@ template <bool RAT> __global__ __launch_bounds__(256) void tril_kernel(TrilPlan 
             for (uint32_t w = 0; w < 3u; ++w) {
                 uint32_t o[3] = {0, 0, 0};
                 bool done_ = false;
-                if constexpr (!RAT) { if (w == 2u && P.expanded) { t_double<false>(G, P.M[2], perm, sgn, 2u, lane, o, cap, J.err, bm); done_ = true; } }
+                if (w == 2u && P.expanded) { t_double<RAT>(G, P.M[2], perm, sgn, 2u, lane, o, cap, J.err, bm, P.p); done_ = true; }
                 if (!done_) t_linear<RAT>(G, P.M[w], perm, sgn, w, w == 2u, variant == 0u, rng, lane, o, cap, J.err, bm, P.p);
                 tot[3u * variant] += o[0]; tot[3u * variant + 1u] += o[1]; tot[3u * variant + 2u] += o[2];
             }

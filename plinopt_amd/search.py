@@ -40,9 +40,9 @@ class CSEPlan:
 
     def hbm_counters(self):
         """Diagnostics of the HBM-resident family over the last launch (plo_cse_plan_hbm_counters)."""
-        out = (ctypes.c_uint32 * 8)()
-        capi.check(capi.lib().plo_cse_plan_hbm_counters(self._h, out))
-        return dict(zip(("steps", "full_scans", "level_rebuilds", "bisections", "spilled_pairs", "list_overflows", "candidates", "eager_refits"), out[:8]))
+        out = (ctypes.c_uint32 * 10)()
+        capi.check(capi.lib().plo_cse_plan_hbm_counters_ex(self._h, out, 10))
+        return dict(zip(("steps", "full_scans", "level_rebuilds", "bisections", "spilled_pairs", "list_overflows", "candidates", "eager_refits", "extra_sweep_windows", "rows_searched"), out[:10]))
 
     def cost_many(self, seeds=None, seed0=0, n=0):
         """(adds[], muls[]) of candidates `seeds` (or seed0..seed0+n-1): Optimizer() per seed."""

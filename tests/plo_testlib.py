@@ -742,3 +742,33 @@ def l32_cut_b(p=131071, rows=None):
             v.append(x)
         rp.append(len(c))
     return len(sel), 1024, rp, c, v
+
+
+def longrow_matrix(p=131071, seed=2026, m=9, n=640, block=40):
+    """Synthetic matrix with rows BEYOND 512 entries that the literal oracle can still walk (tests/golden/make_longrow_costs.py): m rows
+    of ~530-600 entries over n columns that share most of their support -- column blocks of `block`, each present in 5 to 9 of the rows --
+    with entries u_i * w_j from four residues (so that a triple (a, b, w_b/w_a) is shared by every row holding both columns: frequencies
+    up to m, a first block present in all rows keeps the top level small), 3 % holes and 2 % entries with a ratio of their own."""
+    import random
+    rng = random.Random(seed)
+    inv2 = (p + 1) // 2
+    w = [rng.choice([1, 1, 1, p - 1, p - 1, 2, inv2]) for _ in range(n)]
+    u = [rng.choice([1, p - 1, 2]) for _ in range(m)]
+    rows = [[] for _ in range(m)]
+    for k in range(n // block):
+        sub = list(range(m)) if k == 0 else rng.sample(range(m), rng.choice([5, 7, 8, 9, 9, 9, 9, 9]))
+        for j in range(k * block, (k + 1) * block):
+            for i in sub:
+                if rng.random() < 0.03:
+                    continue
+                v = u[i] * w[j] % p
+                if rng.random() < 0.02:
+                    v = rng.choice([1, p - 1, 2, inv2])
+                rows[i].append((j, v))
+    rp, c, v = [0], [], []
+    for r in rows:
+        for j, x in r:
+            c.append(j)
+            v.append(x)
+        rp.append(len(c))
+    return m, n, rp, c, v

@@ -108,7 +108,7 @@ def test_sparsifier_cli_gpu_equals_host(hip, name):
     factorization is consistent (the reference's own criterion, bin/FDT.sh:64)."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
     path = os.path.join(DATA, name)
-    g = subprocess.run([SPS, "-q", str(P), "-c", "6", "-S", path], capture_output=True, text=True, timeout=600)
+    g = subprocess.run([SPS, "-q", str(P), "-c", "6", "-S", "--gpu-min-rows", "0", path], capture_output=True, text=True, timeout=600)
     h = subprocess.run([SPS, "-q", str(P), "-c", "6", "-S", "--gpu", "0", path], capture_output=True, text=True, timeout=600)
     assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
     assert "SUCCESS: consistent factorization" in g.stderr
@@ -126,7 +126,7 @@ def test_sparsifier_cli_on_gpu_prints_the_oracles_basis(hip, name, b, c):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
     path = os.path.join(DATA, name)
     CoB, Res, cand = oracle_sparsify(dense_mod(path, P), P, b, c, True)
-    g = subprocess.run([SPS, "-q", str(P), "-b", str(b), "-c", str(c), "-S", path], capture_output=True, text=True, timeout=600)
+    g = subprocess.run([SPS, "-q", str(P), "-b", str(b), "-c", str(c), "-S", "--gpu-min-rows", "0", path], capture_output=True, text=True, timeout=600)
     assert g.returncode == 0 and "SUCCESS: consistent factorization" in g.stderr and re.search(r"# GPU: \d+ launches, enumeration kernels", g.stderr), g.stderr
     assert parse_sms_text(g.stdout) == CoB
     tail = g.stderr.split("residuum profile:")[1]
@@ -142,7 +142,7 @@ def test_sparsifier_over_the_rationals_on_gpu_equals_host(hip, name, c):
     same change of basis and residue as the host enumeration over Q, no (block, row) sent back to the host, consistent factorization."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
     path = os.path.join(DATA, name)
-    g = subprocess.run([SPS, "-c", c, "-S", path], capture_output=True, text=True, timeout=900)
+    g = subprocess.run([SPS, "-c", c, "-S", "--gpu-min-rows", "0", path], capture_output=True, text=True, timeout=900)
     h = subprocess.run([SPS, "-c", c, "-S", "--gpu", "0", path], capture_output=True, text=True, timeout=900)
     assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
     assert "SUCCESS: consistent factorization" in g.stderr
@@ -151,6 +151,24 @@ def test_sparsifier_over_the_rationals_on_gpu_equals_host(hip, name, c):
     assert int(m.group(2)) <= int(m.group(1))               # plo_cob_search_batch: ONE launch per enumeration (an enumeration after dependent rows needs none)
     assert g.stdout == h.stdout
     assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)
+
+
+def test_small_enumerations_stay_on_the_host_by_default(hip):
+    """BASELINE configs[2] as written (`sparsifier -c 4`: 256 candidate rows per enumeration) pays nothing on the GPU -- a launch and two
+    copies per (block, row) for microseconds of work, and the enumerations of a run are sequential by definition
+    (plinopt_sparsify.inl:172-175, 282-314).  By default an enumeration of fewer than 20,000 rows is walked on the host (the tool says
+    how many); `-c 12` (20,736 rows) is on the GPU; the result is the same either way."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+    path = os.path.join(DATA, "4x4x4_49_156_L.sms")
+    d = subprocess.run([SPS, "-c", "4", "-S", path], capture_output=True, text=True, timeout=600)
+    f = subprocess.run([SPS, "-c", "4", "-S", "--gpu-min-rows", "0", path], capture_output=True, text=True, timeout=600)
+    assert d.returncode == 0 and f.returncode == 0, d.stderr + f.stderr
+    m = re.search(r"(\d+) enumerations in (\d+) launches .*; (\d+) enumerations of fewer than 20000 rows on the host", d.stderr)
+    assert m and int(m.group(1)) == 0 and int(m.group(2)) == 0 and int(m.group(3)) > 0, d.stderr
+    assert d.stdout == f.stdout
+    g = subprocess.run([SPS, "-q", str(P), "-c", "12", "-S", os.path.join(DATA, "2x2x2_7_Winograd_L.sms")], capture_output=True, text=True, timeout=600)
+    # (SparseFactor starts with 3 coefficients and adds 4 per round, plinopt_sparsify.h:78-80: the rounds below 12 coefficients stay on the host)
+    assert g.returncode == 0 and re.search(r"# GPU: [1-9]\d* launches", g.stderr) and re.search(r"; \d+ enumerations of fewer than 20000 rows on the host", g.stderr), g.stderr
 
 
 @pytest.mark.parametrize("generic", [False, True])

@@ -112,11 +112,35 @@ def test_integer_entries_through_the_integer_interface(hip):
     assert G.cost_many(seeds=seeds) == O.cost_many(seeds=seeds)
 
 
-def test_expanded_rational_inputs_are_refused(hip):
-    from plinopt_amd import TrilPlan, capi
-    with pytest.raises(capi.PloError) as e:
-        TrilPlan(2, [(2, [0, 1, 2], [0, 1], [1, 2]), (2, [0, 1, 2], [0, 1], [1, 1]), (2, [0, 1, 2], [0, 1], [1, 1])], expanded=True)
-    assert e.value.code == capi.PLO_E_UNSUPPORTED
+@pytest.mark.parametrize("name", RATIONAL)
+def test_expanded_rational_fixtures_cost_many_bit_exact(hip, name):
+    """Round 4: `trilplacer -e` with rational coefficients on the device (refused until round 3): TransposedDoubleAlgorithm
+    (plinopt_inplace.inl:507-598) with its scaling atoms `*y`, `*a` and the atoms of z = -y c y and c (:532-535, :561-565) on
+    DoubleExpand(T) (:676-716), coefficients as residues modulo the 31-bit prime.  All six counts of every seed equal the oracle's,
+    which works over Q, on each of the 25 rational triples (with the 22 unit ones below: all 47 with expanded=True)."""
+    from plinopt_amd import TrilPlan
+    O = OracleTril.from_sms(*(os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")))
+    G = TrilPlan(O.m, [(n, rp, col, [int(x) for x in num], [int(x) for x in den]) for n, (rp, col, num, den) in zip(O.dims, O.csr)], expanded=True)
+    n = 24 if O.m > 30 else 48
+    seeds = [TRIL_BASE_SEED, 0, 1, 2**40 + 7] + list(range(4000, 4000 + n))
+    assert G.cost_many(seeds=seeds) == O.cost_many(seeds=seeds, expanded=True)
+
+
+def test_expanded_rational_search_and_cli(hip):
+    import re
+    import subprocess
+    from plinopt_amd import TrilPlan
+    from plo_testlib import ROOT
+    for name, n in (("4x4x4_48_rational", 200), ("2x2x2_7_DPS-accurate", 800)):
+        files = [os.path.join(DATA, name + s) for s in ("_L.sms", "_R.sms", "_P.sms")]
+        O = OracleTril.from_sms(*files)
+        G = TrilPlan(O.m, [(nn, rp, col, [int(x) for x in num], [int(x) for x in den]) for nn, (rp, col, num, den) in zip(O.dims, O.csr)], expanded=True)
+        assert G.search(100, n) == O.search(100, n, expanded=True)
+        g = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-e", "-O", str(n), "--seed", "100"] + files, capture_output=True, text=True, timeout=600)
+        h = subprocess.run([os.path.join(ROOT, "bin", "trilplacer"), "-e", "-O", str(n), "--seed", "100", "--gpu", "0"] + files, capture_output=True, text=True, timeout=600)
+        assert g.returncode == 0 and h.returncode == 0, g.stderr + h.stderr
+        assert "restarts on GPU" in g.stderr and "restarts on host" in h.stderr and g.stdout == h.stdout
+        assert re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", g.stderr) == re.findall(r"(\d+)\t(?:ADD|SCA|AXPY)", h.stderr)
 
 
 def test_ten_thousand_seeds_on_config4(hip):
