@@ -493,6 +493,7 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
             if (pl->B.defer && hs[52]) fprintf(stderr, "#   merge, sum + write back of the last candidate: %u groups; us: sum (loads + table) %u, scan + write back %u, clear + bounds %u\n", hs[52], hs[48], hs[49], hs[51]);
             fprintf(stderr, "# big kernel (last candidate): steps %u, full scans %u, level rebuilds %u; phase us: level %u select %u rows %u sweep1 %u flush1 %u sweep2 %u flush2 %u tail %u\n",
                     hs[0], hs[1], hs[2], hs[4], hs[5], hs[6], hs[7], hs[8], hs[9], hs[10], hs[11]);
+            fprintf(stderr, "# big kernel (last candidate): image load + CSE phase %u us, ProgramGen %u us\n", hs[55], hs[56]);
 #ifdef PLO_BIG_PROFILE
             { unsigned long long g2[40] = {0}; if (hipMemcpyFromSymbol(g2, HIP_SYMBOL(plo::g_prof2), sizeof g2) == hipSuccess && g2[32]) {
                 static const char *cls[4] = {">=256", "64..255", "16..63", "<16"};

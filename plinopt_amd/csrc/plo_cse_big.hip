@@ -2155,17 +2155,20 @@ template <int MODE, bool DEFER> __global__ __launch_bounds__(PLO_BIG_THREADS, 4)
         __syncthreads();
         if (c >= J.ncand) break;
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
+        const unsigned long long tk0 = wall_clock64();
         uint64_t ok = big_candidate<MODE, DEFER>(P, ws, seed, sh, hist, agg, P.aggbits, TB, J.err);
         uint64_t res = 0;
         __syncthreads();
+        const unsigned long long tk1 = wall_clock64();
         if (ok) res = big_program_gen(P, ws, sh, scratch, J.err);
         __syncthreads();
+        const unsigned long long tk2 = wall_clock64();
         if (sh.errflag) ok = 0;
         if (threadIdx.x == 0) {
             const uint32_t a = (uint32_t)(res >> 32), mu_ = (uint32_t)res;
             if (J.adds) J.adds[c] = a;
             if (J.muls) J.muls[c] = mu_;
-            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u); atomicAdd(&J.stats[39], sh.nforced); atomicMax(&J.stats[43], sh.derr); for (int q = 0; q < 4; ++q) { J.stats[44 + q] = (uint32_t)(sh.tmg[q] / 100ull); J.stats[48 + q] = (uint32_t)(sh.tmb[q] / 100ull); } J.stats[52] = sh.ngrp; atomicAdd(&J.stats[53], sh.nwin); atomicAdd(&J.stats[54], sh.nsearched); atomicAdd(&J.stats[40], sh.hotops); { const uint32_t lo_ = atomicAdd(&J.stats[41], sh.logtot_lo); if (lo_ + sh.logtot_lo < lo_) atomicAdd(&J.stats[42], 1u); atomicAdd(&J.stats[42], sh.logtot_hi); }
+            if (J.stats) { atomicAdd(&J.stats[32], sh.steps); atomicAdd(&J.stats[33], sh.fullscans); atomicAdd(&J.stats[34], sh.rebuilds); atomicAdd(&J.stats[35], sh.nbisect); atomicAdd(&J.stats[36], sh.spilltot); atomicAdd(&J.stats[37], sh.listover); atomicAdd(&J.stats[38], 1u); atomicAdd(&J.stats[39], sh.nforced); atomicMax(&J.stats[43], sh.derr); for (int q = 0; q < 4; ++q) { J.stats[44 + q] = (uint32_t)(sh.tmg[q] / 100ull); J.stats[48 + q] = (uint32_t)(sh.tmb[q] / 100ull); } J.stats[52] = sh.ngrp; J.stats[55] = (uint32_t)((tk1 - tk0) / 100ull); J.stats[56] = (uint32_t)((tk2 - tk1) / 100ull); atomicAdd(&J.stats[53], sh.nwin); atomicAdd(&J.stats[54], sh.nsearched); atomicAdd(&J.stats[40], sh.hotops); { const uint32_t lo_ = atomicAdd(&J.stats[41], sh.logtot_lo); if (lo_ + sh.logtot_lo < lo_) atomicAdd(&J.stats[42], 1u); atomicAdd(&J.stats[42], sh.logtot_hi); }
                 J.stats[0] = sh.steps; J.stats[1] = sh.fullscans; J.stats[2] = sh.rebuilds; for (int q = 0; q < 8; ++q) J.stats[4 + q] = (uint32_t)(sh.tph[q] / 100ull);
 #ifdef PLO_BIG_PROFILE
                 for (int q = 0; q < 4; ++q) { J.stats[16 + q] = (uint32_t)(sh.tb1[q] / 100ull); J.stats[20 + q] = (uint32_t)(sh.tb2[q] / 100ull); J.stats[24 + q] = sh.nb[q]; }

@@ -30,6 +30,9 @@ def run(ncand, env_extra):
     m = re.search(r"sum \+ write back of the last candidate: (\d+) groups; us: sum \(loads \+ table\) (\d+), scan \+ write back (\d+), clear \+ bounds (\d+)", r.stderr)
     if m:
         out["merge_sum"] = {"groups": int(m.group(1)), "sum_us": int(m.group(2)), "scan_write_back_us": int(m.group(3)), "clear_bounds_us": int(m.group(4))}
+    m = re.search(r"image load \+ CSE phase (\d+) us, ProgramGen (\d+) us", r.stderr)
+    if m:
+        out["last_candidate"]["load_and_cse_us"] = int(m.group(1)); out["last_candidate"]["program_gen_us"] = int(m.group(2))
     out["stderr_tail"] = [ln for ln in r.stderr.splitlines() if ln.startswith("#")][-6:]
     return out
 
