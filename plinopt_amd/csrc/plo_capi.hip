@@ -29,6 +29,10 @@
 #include <string>
 #include <vector>
 
+#ifndef PLO_BIG_LOGTRIG_MAX
+#define PLO_BIG_LOGTRIG_MAX (4ull << 20)      /* log records between two merges of the deferred updates, at most */
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -343,7 +347,7 @@ int build_big_plan(plo_plan *pl)
             const uint64_t lpp = 6080u - capp;                                            // records of a partition's log that still fit the merge beside its live triples (12 records per thread, an LDS table of 2^13 slots)
             uint64_t budget = lpp * Pn * 5ull / 6ull;                                      // (hash imbalance of the partitions' shares)
             if (budget > stepmax + hotmax + 4096ull) {
-                uint64_t trig = std::min<uint64_t>(budget - stepmax - hotmax - 4096ull, 4ull << 20);
+                uint64_t trig = std::min<uint64_t>(budget - stepmax - hotmax - 4096ull, (uint64_t)PLO_BIG_LOGTRIG_MAX);
                 if (const char *e = getenv("PLO_BIG_LOGTRIG")) trig = std::min<uint64_t>(trig, std::max<uint64_t>(1, strtoull(e, nullptr, 10)));   // test knob: merges forced by the log
                 const uint64_t logcap = trig + stepmax + hotmax + 4096ull;
                 B.defer = 1u; B.pbits = pbits; B.capp = capp; B.logtrig = (uint32_t)trig; B.logcap = (uint32_t)logcap;
@@ -1368,7 +1372,9 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         K.PM = tmp.P; K.m = m; K.n = n; K.rank = R; K.ndeps = ndeps; K.per_block = per_block;
         K.mers = 0; for (uint32_t kk = 2; kk < 31; ++kk) if (p == (1u << kk) - 1u) K.mers = kk;
         uint32_t off = 0;
-        K.off_depc = off;  off += ndeps * R * 4u;
+        const uint32_t depc_bytes = round_up(ndeps * R * 4u, 16);
+        const bool depc_inside = !getenv("PLO_KMETHOD_DEPC_SCRATCH");             // (A/B knob: the round-3 placement in the scratch)
+        if (!depc_inside) { K.off_depc = (int32_t)off; off += depc_bytes; }
         K.off_vrow = off;  off += 64u * 4u;
         K.off_ord = off;   off += 128u * 2u;
         K.off_piv = off;   off += 128u * 2u;
@@ -1385,6 +1391,7 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         if (cap_scale == 1) {
             // sizing launch: Dep's pair count over a sample of the decompositions
             K.region = round_up(std::max(K.PM.region_bytes, vc_end), 16);
+            if (depc_inside) { const uint32_t at = round_up(std::max(K.PM.region_bytes, vc_end), 16); K.region = at + depc_bytes; K.off_depc = -(int32_t)depc_bytes; }
             uint32_t W = 0, lds = 0;
             for (uint32_t w : {4u, 2u, 1u}) { const uint32_t l = K.PM.rs_bytes + w * (K.region + K.scratch_bytes); if (l <= g_lds_max) { W = w; lds = l; break; } }
             if (!W) { cleanup(); return fail(PLO_E_CAPACITY, "kernel-method state does not fit LDS"); }
@@ -1415,6 +1422,14 @@ int plo_kernel_search(const plo_csr_t *M, uint32_t p, uint64_t seed0, uint64_t n
         if (rc != PLO_OK) { cleanup(); return rc; }
         K.rsD = nullptr;                                                          // Dep's row starts are computed per restart on the device
         K.region = round_up(std::max(std::max(K.PM.region_bytes, K.PD.region_bytes), vc_end), 16);
+        if (depc_inside) {
+            // the combinations live from the end of the decomposition to the end of Dep's image build: behind Free's region (Optimizer on Free
+            // runs meanwhile) and behind the elimination arrays (they are copied out of C), over Dep's tie list / multiplier list (idle until
+            // Dep's Optimizer call)
+            const uint32_t at = round_up(std::max(std::max(K.PM.region_bytes, vc_end), K.PD.off_ties), 16);
+            K.region = std::max(K.region, at + depc_bytes);
+            K.off_depc = (int32_t)at - (int32_t)K.region;
+        }
         uint32_t W = 0, lds = 0, bestw = 0;
         for (uint32_t w : {4u, 2u, 1u}) {
             const uint32_t l = K.PM.rs_bytes + K.PD.rs_bytes + w * (K.region + K.scratch_bytes);

@@ -39,7 +39,10 @@ struct KPlan {
     uint32_t mers;                 // k when p = 2^k - 1 (shift-and-add reduction in the elimination), else 0
     uint32_t region;               // bytes of the image region of a wave (max of the two plans)
     uint32_t off_vc;               // elimination work arrays V, C inside the image region, behind M's template
-    uint32_t off_depc, off_vrow, off_ord, off_piv, off_basis, off_deps, off_rsd, scratch_bytes;   // scratch behind the region
+    int32_t off_depc;              // the dependent rows' combinations, relative to the END of the image region: negative = inside it (round 4: behind the
+                                   // elimination arrays, where Dep's tie list and multiplier list lie -- both idle until Dep's Optimizer call, by which
+                                   // time the combinations have become Dep's rows: 2.1 KB less per wave on 4x4x4_49_156_L, 11 waves per CU instead of 9)
+    uint32_t off_vrow, off_ord, off_piv, off_basis, off_deps, off_rsd, scratch_bytes;   // scratch behind the region
     const uint64_t *rsD;           // unused since round 3 (Dep's row starts are per restart: KScratch::rsd)
 };
 #ifdef PLO_KM_PROFILE
@@ -66,7 +69,7 @@ __device__ __forceinline__ uint32_t kinv(uint32_t x, uint32_t p, uint64_t mu) {
 
 struct KScratch { uint32_t *depc, *vrow; uint16_t *ord, *piv, *basis, *deps, *rsd; };   // rsd: row starts of THIS restart's Dep (rows packed: the image is sized from sampled entry counts, not from rows x rank)
 __device__ __forceinline__ KScratch kscratch(const KPlan &K, uint8_t *scr) {
-    return KScratch{(uint32_t *)(scr + K.off_depc), (uint32_t *)(scr + K.off_vrow),
+    return KScratch{(uint32_t *)(scr + (ptrdiff_t)K.off_depc), (uint32_t *)(scr + K.off_vrow),
                     (uint16_t *)(scr + K.off_ord), (uint16_t *)(scr + K.off_piv), (uint16_t *)(scr + K.off_basis), (uint16_t *)(scr + K.off_deps), (uint16_t *)(scr + K.off_rsd)};
 }
 

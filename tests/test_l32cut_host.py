@@ -48,3 +48,16 @@ def test_host_engine_equals_literal_oracle_on_the_cuts(rows, which, tmp_path):
     write_sms(sms, m, n, rp, c, v)
     for k in range(len(G["adds"])):
         assert _fast_cost(sms, G["seed0"] + k, check=(k == 0)) == (G["adds"][k], G["muls"][k]), (which, k)
+
+
+def test_host_engine_equals_literal_oracle_on_the_long_rows(tmp_path):
+    """tests/golden/longrow_costs.json (literal oracle on rows of 461-627 entries, tests/golden/make_longrow_costs.py): the scalable host
+    engine -- the source of config 5's full-size goldens -- gives the same costs, and its program computes the matrix."""
+    from plo_testlib import longrow_matrix
+    G = json.load(open(os.path.join(GOLDEN, "longrow_costs.json")))
+    m, n, rp, c, v = longrow_matrix(P)
+    assert len(c) == G["nnz"] and [rp[i + 1] - rp[i] for i in range(m)] == G["row_lengths"]
+    sms = str(tmp_path / "longrow.sms")
+    write_sms(sms, m, n, rp, c, v)
+    for k in range(len(G["adds"])):
+        assert _fast_cost(sms, G["seed0"] + k, check=(k == 0)) == (G["adds"][k], G["muls"][k]), k
