@@ -30,7 +30,10 @@
 #include <vector>
 
 #ifndef PLO_BIG_LOGTRIG_MAX
-#define PLO_BIG_LOGTRIG_MAX (4ull << 20)      /* log records between two merges of the deferred updates, at most */
+// log records between two merges of the deferred updates, at most (the partitions' capacity -- what a merge can sum in its LDS table --
+// is the other bound: 5.6e6 on config 5).  Round 4: 8 M instead of 4 M: 7 merges per candidate instead of 8 (one forced by the log
+// instead of two), 789 -> 811 candidates/s on one box (profiles/r04_ab_config5.txt); 11 MB more workspace per candidate.
+#define PLO_BIG_LOGTRIG_MAX (8ull << 20)
 #endif
 
 namespace {
