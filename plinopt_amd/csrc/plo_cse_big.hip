@@ -778,6 +778,10 @@ __device__ __forceinline__ void defer_merge(const BigPlan &P, uint8_t *ws, BigSh
         if (Mx >= 2u) { th = Mx; for (uint32_t f = Mx; f >= 2u; --f) { if (f != Mx && acc + hist[f] > P.hwin) break; acc += hist[f]; th = f; } }
         if (acc > P.hlcap / 2u) wg_max(&sh.errflag, (uint32_t)BERR_HL);
         uint32_t hb = P.hotbits_min; while ((1ull << hb) < 4ull * acc + 1024ull && hb < P.hotbits_max) ++hb;
+#ifdef PLO_BIG_MERGELOG
+        printf("# merge %u at step %u: M %u theta %u window %llu triples (hot table 2^%u); histogram of the levels below: [%u]=%u [%u]=%u [%u]=%u; log %u records\n", sh.fullscans, sh.steps, Mx, th, (unsigned long long)acc, hb,
+               th > 2u ? th - 1u : 0u, th > 2u ? hist[th - 1u] : 0u, th > 3u ? th - 2u : 0u, th > 3u ? hist[th - 2u] : 0u, 2u, hist[2], sh.logn);
+#endif
         sh.M = Mx >= 2u ? Mx : 0u; sh.theta = th; sh.hotbits = hb; sh.hotn = 0u; sh.hlcount = 0u; sh.logn = 0u; sh.hlbad = 0u; ++sh.fullscans;
     }
     BSYNC();
