@@ -166,6 +166,14 @@ int plo_oracle_sp_local(uint32_t n, uint32_t m, uint32_t *TM, uint32_t *TCoB, ui
 /* blockSparsifier (:667-748) with sparseAlternate / SparseFactor / FactorDiagonals / sparseLU: M (m x n) -> CoB (n x n), Res (m x n), M == Res . CoB */
 int plo_oracle_sparsify(uint32_t m, uint32_t n, const uint32_t *M, uint32_t p, uint32_t blocksize, uint32_t maxnumcoeff, int initial_elimination,
                         uint32_t *CoB, uint32_t *Res, uint64_t *candidates);
+/* the same two over Q, the field the reference runs bin/sparsifier in without -q (src/sparsifier.cpp:66-83): the SAME restatement
+ * (plo_sparsify_body.h) instantiated with checked 64-bit rationals; matrices as (numerators, denominators > 0), results in lowest terms */
+int plo_oracle_sp_coeffs_q(uint32_t n, uint32_t m, const int64_t *TMnum, const int64_t *TMden, uint32_t maxnumcoeff, int64_t *outnum, int64_t *outden, uint32_t *ncoeffs);
+int plo_oracle_sparsify_q(uint32_t m, uint32_t n, const int64_t *Mnum, const int64_t *Mden, uint32_t blocksize, uint32_t maxnumcoeff, int initial_elimination,
+                          int64_t *CoBnum, int64_t *CoBden, int64_t *Resnum, int64_t *Resden, uint64_t *candidates);
+/* counters of the last plo_oracle_sparsify[_q] call: candidates that carried a coordinate outside their block (:305), rows filled by the fallback (:317-326) */
+uint64_t plo_oracle_sparsify_carried(void);
+uint64_t plo_oracle_sparsify_fallbacks(void);
 
 #ifdef __cplusplus
 }

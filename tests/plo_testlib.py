@@ -284,6 +284,8 @@ def oracle():
         L.plo_oracle_sp_coeffs.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p]
         L.plo_oracle_sp_local.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32]
         L.plo_oracle_sparsify.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, u32p, u32p, u64p]
+        L.plo_oracle_sp_coeffs_q.argtypes = [ctypes.c_uint32, ctypes.c_uint32, i64p, i64p, ctypes.c_uint32, i64p, i64p, u32p]
+        L.plo_oracle_sparsify_q.argtypes = [ctypes.c_uint32, ctypes.c_uint32, i64p, i64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, i64p, i64p, i64p, i64p, u64p]
         L.plo_oracle_naive_ops.argtypes = [ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p, u32p]
         L.plo_oracle_naive_ops.restype = None
         L.plo_oracle_free.argtypes = [ctypes.c_void_p]
@@ -495,6 +497,57 @@ def oracle_sparsify(M, p, blocksize=4, maxnumcoeff=11, initial_elimination=True)
     rc = oracle().plo_oracle_sparsify(m, n, _arr([x for r in M for x in r]), p, blocksize, maxnumcoeff, 1 if initial_elimination else 0, cob, res, ctypes.byref(cand))
     assert rc == 0
     return [list(cob[i * n:(i + 1) * n]) for i in range(n)], [list(res[i * n:(i + 1) * n]) for i in range(m)], cand.value
+
+
+def oracle_sp_coeffs_q(TM, maxnumcoeff):
+    """Coefficient set of localSparsifier over Q (plinopt_sparsify.inl:256-268 with QField<Rational>) for the dense matrix TM of Fractions."""
+    from fractions import Fraction
+    n, m = len(TM), len(TM[0])
+    flat = [Fraction(x) for r in TM for x in r]
+    on, od = (ctypes.c_int64 * (maxnumcoeff + 8))(), (ctypes.c_int64 * (maxnumcoeff + 8))()
+    cnt = ctypes.c_uint32()
+    assert oracle().plo_oracle_sp_coeffs_q(n, m, _arr([x.numerator for x in flat], ctypes.c_int64), _arr([x.denominator for x in flat], ctypes.c_int64),
+                                           maxnumcoeff, on, od, ctypes.byref(cnt)) == 0
+    return [Fraction(on[k], od[k]) for k in range(cnt.value)]
+
+
+def oracle_sparsify_q(M, blocksize=4, maxnumcoeff=11, initial_elimination=True):
+    """blockSparsifier (plinopt_sparsify.inl:667-748) of the dense m x n matrix M of Fractions over Q: (CoB, Res, candidates)."""
+    from fractions import Fraction
+    m, n = len(M), len(M[0])
+    flat = [Fraction(x) for r in M for x in r]
+    cn, cd = (ctypes.c_int64 * (n * n))(), (ctypes.c_int64 * (n * n))()
+    rn, rd = (ctypes.c_int64 * (m * n))(), (ctypes.c_int64 * (m * n))()
+    cand = ctypes.c_uint64()
+    rc = oracle().plo_oracle_sparsify_q(m, n, _arr([x.numerator for x in flat], ctypes.c_int64), _arr([x.denominator for x in flat], ctypes.c_int64),
+                                        blocksize, maxnumcoeff, 1 if initial_elimination else 0, cn, cd, rn, rd, ctypes.byref(cand))
+    assert rc == 0
+    return ([[Fraction(cn[i * n + j], cd[i * n + j]) for j in range(n)] for i in range(n)],
+            [[Fraction(rn[i * n + j], rd[i * n + j]) for j in range(n)] for i in range(m)], cand.value)
+
+
+def dense_q(path):
+    """dense matrix of Fractions of an SMS file (list of rows)"""
+    from fractions import Fraction
+    m, n, ent = read_sms(path)
+    D = [[Fraction(0)] * n for _ in range(m)]
+    for (i, j), v in ent.items():
+        D[i][j] = v
+    return D
+
+
+def parse_sms_text_q(text):
+    """dense matrix of Fractions of an SMS text as the tools print it over Q (entries `a` or `a/b`)"""
+    from fractions import Fraction
+    lines = [ln for ln in text.splitlines() if ln.strip() and not ln.lstrip().startswith("#")]
+    m, n = int(lines[0].split()[0]), int(lines[0].split()[1])
+    D = [[Fraction(0)] * n for _ in range(m)]
+    for ln in lines[1:]:
+        i, j, v = ln.split()[:3]
+        if int(i) == 0:
+            break
+        D[int(i) - 1][int(j) - 1] = Fraction(v)
+    return D
 
 
 def dense_mod(path, p):

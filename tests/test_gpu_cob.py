@@ -136,7 +136,7 @@ def test_sparsifier_cli_on_gpu_prints_the_oracles_basis(hip, name, b, c):
 
 @pytest.mark.parametrize("name,c", [("4x4x4_49_156_L.sms", "4"), ("2x2x2_7_Winograd_L.sms", "6"), ("2x2x2_7_DPS-accurate_L.sms", "6"), ("4x4x4_48_rational_L.sms", "5"),
                                     ("3x3x3_23_58_P.sms", "6")])
-def test_sparsifier_over_the_rationals_on_gpu_equals_host(hip, name, c):
+def test_sparsifier_over_the_rationals_on_gpu_equals_host_and_oracle(hip, name, c):
     """BASELINE configs[2] as written (`sparsifier -c 4 data/4x4x4_49_156_L.sms`, no -q): over Q, the field the reference runs it in
     (src/sparsifier.cpp:66-83).  The enumeration runs on the GPU modulo two 31-bit primes, every winner is re-evaluated over Q;
     same change of basis and residue as the host enumeration over Q, no (block, row) sent back to the host, consistent factorization."""
@@ -151,6 +151,14 @@ def test_sparsifier_over_the_rationals_on_gpu_equals_host(hip, name, c):
     assert int(m.group(2)) <= int(m.group(1))               # plo_cob_search_batch: ONE launch per enumeration (an enumeration after dependent rows needs none)
     assert g.stdout == h.stdout
     assert re.search(r"with (\d+) non-zeroes", g.stderr).group(1) == re.search(r"with (\d+) non-zeroes", h.stderr).group(1)
+    # ... and both are what the ORACLE's Q instance gives (oracle/plo_sparsify_oracle.c: the restatement of plinopt_sparsify.inl instantiated
+    # with checked rationals): change of basis, residue and the number of candidate rows
+    from plo_testlib import dense_q, oracle_sparsify_q, parse_sms_text_q
+    CoB, Res, cand = oracle_sparsify_q(dense_q(path), 4, int(c), True)
+    assert parse_sms_text_q(g.stdout) == CoB
+    tail = g.stderr.split("residuum profile:")[1]
+    assert parse_sms_text_q(tail[tail.index("\n") + 1:]) == Res
+    assert ("# CoB enumeration: %d candidate rows" % cand) in g.stderr
 
 
 def test_small_enumerations_stay_on_the_host_by_default(hip):
