@@ -161,6 +161,26 @@ def test_sparsifier_over_the_rationals_on_gpu_equals_host_and_oracle(hip, name, 
     assert ("# CoB enumeration: %d candidate rows" % cand) in g.stderr
 
 
+@pytest.mark.parametrize("b", [8, 16])
+def test_fallback_rows_on_gpu_equal_the_oracle(hip, b):
+    """`-c 1` (coefficient list {0}: every row after the seed is filled by the canonical fallback, plinopt_sparsify.inl:317-326, and the
+    oracle's candidates carry the fallback's coordinate, :305 -- tests/test_sparsify_oracle.py): the GPU enumeration prints the oracle's basis."""
+    import ctypes
+    from plo_testlib import dense_mod, oracle, oracle_sparsify, parse_sms_text
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "plinopt_amd", "csrc", "host")])
+    L = oracle()
+    L.plo_oracle_sparsify_carried.restype = ctypes.c_uint64
+    path = os.path.join(DATA, "4x4x4_49_156_L.sms")
+    CoB, Res, cand = oracle_sparsify(dense_mod(path, P), P, b, 1, True)
+    assert L.plo_oracle_sparsify_carried() > 0
+    g = subprocess.run([SPS, "-q", str(P), "-b", str(b), "-c", "1", "-S", "--gpu-min-rows", "0", path], capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0 and "SUCCESS: consistent factorization" in g.stderr and re.search(r"# GPU: [1-9]\d* launches", g.stderr), g.stderr
+    assert parse_sms_text(g.stdout) == CoB
+    tail = g.stderr.split("residuum profile:")[1]
+    assert parse_sms_text(tail[tail.index("\n") + 1:]) == Res
+    assert ("# CoB enumeration: %d candidate rows" % cand) in g.stderr
+
+
 def test_small_enumerations_stay_on_the_host_by_default(hip):
     """BASELINE configs[2] as written (`sparsifier -c 4`: 256 candidate rows per enumeration) pays nothing on the GPU -- a launch and two
     copies per (block, row) for microseconds of work, and the enumerations of a run are sequential by definition
