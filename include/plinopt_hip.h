@@ -80,7 +80,11 @@ int plo_device_count(void);
  * of include/plinopt_optimize.inl:1206-1207: the matrix is converted once). */
 int plo_cse_plan_create(const plo_csr_t *A, uint32_t p, plo_plan_t **plan);
 /* flags: PLO_PLAN_HBM forces the HBM-resident kernel family (one workgroup per candidate,
- * plo_cse_big.hip) that plo_cse_plan_create selects by itself when a candidate does not fit LDS. */
+ * plo_cse_big.hip) that plo_cse_plan_create selects by itself when a candidate does not fit LDS.
+ * Limits of that family (PLO_E_CAPACITY): 32766 rows, 32768 columns (created ones included), rows of 8192 entries, 65536 distinct
+ * coefficients, any odd prime below 2^31 -- but a modulus too wide for a residue in the 48-bit pair key beside the columns (above
+ * 2^(48 - 2 ceil(log2 columns)); a 31-bit prime: more than 256 columns) needs a matrix of at most 32 distinct coefficients (the key
+ * then holds the ratio's identifier). */
 #define PLO_PLAN_HBM 1u
 int plo_cse_plan_create_ex(const plo_csr_t *A, uint32_t p, uint32_t flags, plo_plan_t **plan);
 /* 1 if the plan runs on the HBM-resident kernel family, 0 for the LDS-resident wave kernel */

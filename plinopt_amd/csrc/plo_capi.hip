@@ -242,6 +242,7 @@ template <class T> int upload(plo_plan *pl, const std::vector<T> &v, const T **d
 
 const void *big_kernel_fn(const plo::BigPlan &B)
 {
+    if (B.idk) return B.defer ? (const void *)plo::cse_big_kernel<2, true, true> : (const void *)plo::cse_big_kernel<2, false, true>;
     if (B.defer) return B.mode == 2u ? (const void *)plo::cse_big_kernel<2, true> : B.mode == 1u ? (const void *)plo::cse_big_kernel<1, true> : (const void *)plo::cse_big_kernel<0, true>;
     return B.mode == 2u ? (const void *)plo::cse_big_kernel<2, false> : B.mode == 1u ? (const void *)plo::cse_big_kernel<1, false> : (const void *)plo::cse_big_kernel<0, false>;
 }
@@ -257,21 +258,39 @@ int build_big_plan(plo_plan *pl)
     uint32_t maxlen = 1, naive = 0; bool unit = true;
     for (uint32_t i = 0; i < m; ++i) { uint32_t l = rowptr[i + 1] - rowptr[i]; maxlen = std::max(maxlen, l); if (l > 1) naive += l - 1; }
     for (uint32_t k = 0; k < nnz; ++k) unit = unit && (val[k] == 1u || val[k] == p - 1);
+    // The values of a candidate are the distinct values of the input (a CSE step moves values, it creates none): rows are
+    // packed as column | +-1 flag << 15 | value index << 16, with one {value, inverse} table.
+    std::vector<uint32_t> dv(val.begin(), val.end());
+    std::sort(dv.begin(), dv.end()); dv.erase(std::unique(dv.begin(), dv.end()), dv.end());
+    if (dv.size() > 65536) return fail(PLO_E_CAPACITY, "more than 65536 distinct coefficients: the packed row entry holds a 16-bit value index");
+    // at most 32 values: the <= 1024 ratios v_i/v_j get identifiers (kernel mode 2: 6-byte aggregation entries, no product in the sweep)
+    const bool ratio_ids = dv.size() <= 32 && !getenv("PLO_BIG_VT_GLOBAL") && !getenv("PLO_BIG_NORID");
+    std::vector<uint32_t> rat, rv;
+    if (ratio_ids) {
+        const uint32_t nv = (uint32_t)dv.size();
+        rat.resize(nv * nv);
+        for (uint32_t i = 0; i < nv; ++i) { const uint32_t ii = inv_mod(dv[i], p); for (uint32_t j = 0; j < nv; ++j) rat[j * nv + i] = (uint32_t)((uint64_t)dv[j] * ii % p); }   // rat[i * nv + j] = v_i / v_j
+        rv = rat; std::sort(rv.begin(), rv.end()); rv.erase(std::unique(rv.begin(), rv.end()), rv.end());
+    }
+    // A pair key is (column, column, ratio) in 48 bits.  Ratio field: the residue (rb bits) -- or, when that leaves too few bits for the
+    // columns (a 31-bit prime: 8 bits, 256 columns) and the matrix has ratio identifiers, the IDENTIFIER (rank in the sorted list of
+    // ratios: keys keep their order), kb <= 10 bits: any modulus below 2^31 with 32768 columns (plo::cse_big_idkey_kernel).
     const uint32_t rb = ceil_log2(p);
-    if (rb > 30 || (48u - rb) / 2u < 2u) return fail(PLO_E_CAPACITY, "modulus too large for the 48-bit pair key");
-    const uint32_t bbmax = (48u - rb) / 2u;
     uint64_t NC = (uint64_t)n + naive / 2 + 2;
+    uint32_t kb = rb; bool idk = false;
+    {
+        const uint32_t bbres = rb <= 44u ? (48u - rb) / 2u : 0u;            // column bits beside a residue
+        const bool fits = rb <= 30u && bbres >= 2u && n + 2ull <= (1ull << bbres) && std::min<uint64_t>(NC, 32768) <= (1ull << bbres);
+        if ((!fits || getenv("PLO_BIG_IDKEYS")) && ratio_ids && rb <= 31u) { idk = true; kb = std::max(1u, ceil_log2((uint32_t)rv.size())); }   // (PLO_BIG_IDKEYS: test knob, identifiers although residues would fit)
+        else if (rb > 30 || bbres < 2u) return fail(PLO_E_CAPACITY, "modulus too large for the 48-bit pair key (and more than 32 distinct coefficients: no ratio identifiers)");
+    }
+    const uint32_t bbmax = std::min(15u, (48u - kb) / 2u);
     if (n + 2ull > (1ull << bbmax) || n + 2ull > 32768ull) return fail(PLO_E_CAPACITY, "too many columns for the HBM-resident kernel (48-bit pair key / 32768 columns)");
     NC = std::min<uint64_t>(std::min<uint64_t>(NC, 1ull << bbmax), 32768);   // 32768 = 512 LDS block sums x 64; exceeding it at run time is reported by the device (BERR_COLS)
     const uint32_t bb = ceil_log2((uint32_t)NC);
     if (m >= 0x7FFFu) return fail(PLO_E_CAPACITY, "more than 32766 rows: frequency does not fit the table slot");
     if (maxlen > 8192) return fail(PLO_E_CAPACITY, "row longer than 8192 entries");
 
-    // The values of a candidate are the distinct values of the input (a CSE step moves values, it creates none): rows are
-    // packed as column | +-1 flag << 15 | value index << 16, with one {value, inverse} table.
-    std::vector<uint32_t> dv(val.begin(), val.end());
-    std::sort(dv.begin(), dv.end()); dv.erase(std::unique(dv.begin(), dv.end()), dv.end());
-    if (dv.size() > 65536) return fail(PLO_E_CAPACITY, "more than 65536 distinct coefficients: the packed row entry holds a 16-bit value index");
     std::vector<uint2> vt(dv.size());
     for (size_t k = 0; k < dv.size(); ++k) vt[k] = make_uint2(dv[k], inv_mod(dv[k], p));
     std::vector<uint32_t> inv(nnz), ent(nnz), tptr(n + 1, 0), trows(nnz), ucount(n, 0);
@@ -294,7 +313,11 @@ int build_big_plan(plo_plan *pl)
                 const uint32_t i = trows[q]; uint32_t x = rowptr[i];
                 while (col[x] != a) ++x;
                 for (uint32_t y = x + 1; y < rowptr[i + 1]; ++y)
-                    tmp.push_back(((uint64_t)a << (bb + rb)) | ((uint64_t)col[y] << rb) | (uint32_t)((uint64_t)val[y] * inv[x] % p));
+                {
+                    uint32_t rr = (uint32_t)((uint64_t)val[y] * inv[x] % p);
+                    if (idk) rr = (uint32_t)(std::lower_bound(rv.begin(), rv.end(), rr) - rv.begin());
+                    tmp.push_back(((uint64_t)a << (bb + kb)) | ((uint64_t)col[y] << kb) | rr);
+                }
             }
             pairs0 += tmp.size();
             std::sort(tmp.begin(), tmp.end());
@@ -322,7 +345,7 @@ int build_big_plan(plo_plan *pl)
     if (cap > (1ull << 30)) return fail(PLO_E_CAPACITY, "pair table above 2^30 slots");
     std::vector<uint32_t> hist(maxf + 2, 0);
     for (size_t k = 0; k < keys.size(); ++k) ++hist[cnts[k]];
-    B.m = m; B.n = n; B.nnz = nnz; B.p = p; B.NCmax = (uint32_t)NC; B.hbits = hbits; B.rb = rb; B.bb = bb; B.unit = unit ? 1u : 0u;
+    B.m = m; B.n = n; B.nnz = nnz; B.p = p; B.NCmax = (uint32_t)NC; B.hbits = hbits; B.rb = rb; B.bb = bb; B.kb = kb; B.idk = idk ? 1u : 0u; B.unit = unit ? 1u : 0u;
     B.maxf0 = maxf + 1; B.M0 = maxf; B.multcap = multcap; B.scr_stride = maxlen;
     B.dmcap = (uint32_t)std::min<uint64_t>(1u << 20, cap); B.hlcap = (uint32_t)std::min<uint64_t>(1u << 18, cap);   // window list: <= hlcap/2 keys per window, ping-pong halves
     B.mu = (~0ull) / p;
@@ -382,12 +405,8 @@ int build_big_plan(plo_plan *pl)
     }
     B.nv = (uint32_t)dv.size(); B.vt_lds = (dv.size() <= 512 && !getenv("PLO_BIG_VT_GLOBAL")) ? 1u : 0u;   // (test knob: the global-memory value table)
     B.mode = B.vt_lds ? 1u : 0u; B.nr = 0;
-    if (dv.size() <= 32 && !getenv("PLO_BIG_VT_GLOBAL") && !getenv("PLO_BIG_NORID")) {
-        // at most 32 values: the <= 1024 ratios v_i/v_j get identifiers (kernel mode 2: 6-byte aggregation entries, no product in the sweep)
+    if (ratio_ids) {
         const uint32_t nv = (uint32_t)dv.size();
-        std::vector<uint32_t> rat(nv * nv);
-        for (uint32_t i = 0; i < nv; ++i) for (uint32_t j = 0; j < nv; ++j) rat[i * nv + j] = (uint32_t)((uint64_t)vt[i].x * vt[j].y % p);
-        std::vector<uint32_t> rv(rat); std::sort(rv.begin(), rv.end()); rv.erase(std::unique(rv.begin(), rv.end()), rv.end());
         std::vector<uint16_t> rt(PLO_RSTRIDE * PLO_RSTRIDE, 0), iv(rv.size());     // identifiers at [i * 32 + j]
         for (uint32_t i = 0; i < nv; ++i) for (uint32_t j = 0; j < nv; ++j) rt[i * PLO_RSTRIDE + j] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), rat[i * nv + j]) - rv.begin());
         for (size_t k = 0; k < rv.size(); ++k) iv[k] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), inv_mod(rv[k], p)) - rv.begin());   // the inverse of v_i/v_j is v_j/v_i: in the set
@@ -475,11 +494,13 @@ int launch_big(plo_plan *pl, plo::BigJob J, plo_stats_t *st)
     {
         const plo::BigPlan &B = pl->B;
         if (B.defer) {
-            if (B.mode == 2u) hipLaunchKernelGGL((plo::cse_big_kernel<2, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            if (B.idk) hipLaunchKernelGGL((plo::cse_big_kernel<2, true, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            else if (B.mode == 2u) hipLaunchKernelGGL((plo::cse_big_kernel<2, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
             else if (B.mode == 1u) hipLaunchKernelGGL((plo::cse_big_kernel<1, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
             else hipLaunchKernelGGL((plo::cse_big_kernel<0, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
         } else {
-            if (B.mode == 2u) hipLaunchKernelGGL((plo::cse_big_kernel<2, false>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            if (B.idk) hipLaunchKernelGGL((plo::cse_big_kernel<2, false, true>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
+            else if (B.mode == 2u) hipLaunchKernelGGL((plo::cse_big_kernel<2, false>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
             else if (B.mode == 1u) hipLaunchKernelGGL((plo::cse_big_kernel<1, false>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
             else hipLaunchKernelGGL((plo::cse_big_kernel<0, false>), dim3((uint32_t)grid), dim3(PLO_BIG_THREADS), pl->big_lds, g_stream, pl->B, J);
         }

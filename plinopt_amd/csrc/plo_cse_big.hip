@@ -90,6 +90,7 @@ struct BigPlan {
     uint32_t fwin;                        // entries per window of the flat sweep (2048 = 32 trips: the marks of a window are 32 words per wave; a test knob makes it smaller)
     const uint64_t *st0; const uint32_t *pcount0;     // store image: 2^pbits partitions of capp entries (key48<<16 | count16), entries per partition
     uint64_t o_store, o_pcount, o_ptail, o_log, o_plog, o_hot;
+    uint32_t kb, idk;                     // idk: the ratio field of a pair key holds the ratio's identifier (kb bits), not the residue (cse_big_kernel<2, ., true>)
 };
 
 struct BigJob {
@@ -823,7 +824,7 @@ __device__ __forceinline__ void defer_merge(const BigPlan &P, uint8_t *ws, BigSh
 // ---------------------------------------------------------------------------
 // One candidate by one workgroup.  Returns (adds<<32 | muls) in thread 0.
 // ---------------------------------------------------------------------------
-template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const BigTabs &TB, uint32_t *errw)
+template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t big_candidate(const BigPlan &P, uint8_t *ws, uint64_t seed, BigShared &sh, uint32_t *hist, uint64_t *agg, uint32_t aggbits, const BigTabs &TB, uint32_t *errw)
 {
     const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nth >> 6;
     uint64_t *tab   = (uint64_t *)(ws + (DEFER ? P.o_hot : P.o_tab));      // the table the level code and the tie pick look triples up in (DEFER: the hot table)
@@ -847,10 +848,17 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
     uint16_t *agglist = (MODE == 2 && !DEFER) ? TB.list : (uint16_t *)sh.sel; const uint32_t listcap = (MODE == 2 && !DEFER) ? (1u << aggbits) : PLO_AGG_LIST;   // (DEFER: the Bloom filter has the place of mode 2's full list)
     uint64_t *spill = (uint64_t *)(ws + P.o_spill); const uint32_t spillcap = P.nnz + 64u;   // new-column pairs of entries that found no room in LDS (a step touches every entry at most once)
     uint32_t *multc = (uint32_t *)(ws + P.o_multc), *multv = (uint32_t *)(ws + P.o_multv);
-    const uint32_t p = P.p, rb = P.rb, abits = P.rb + P.bb, n = P.n, m = P.m, mers = P.mers;
+    // A pair key is (first column, second column, ratio) in 48 bits.  The ratio field holds the residue (rb bits) -- or, IDK (mode 2 only:
+    // a modulus too wide for 48 bits, e.g. a 31-bit prime with 32768 columns), the ratio's IDENTIFIER (kb <= 10 bits).  Identifiers are
+    // ranks in the sorted list of ratios, so keys compare as they do with residues (the tie pick walks triples in key order, :244-253).
+    const uint32_t p = P.p, rb = P.rb, kb = IDK ? P.kb : P.rb, abits = kb + P.bb, n = P.n, m = P.m, mers = P.mers;
     uint32_t hbits = DEFER ? P.hotbits_min : P.hbits;                                // DEFER: the hot table is sized anew at every merge
     const uint64_t mu = P.mu, cap = 1ull << P.hbits;
-#define BKEY(a_, b_, r_) (((uint64_t)(a_) << abits) | ((uint64_t)(b_) << rb) | (uint64_t)(r_))
+    auto key_ratio = [&](uint32_t x) -> uint32_t {                                   // the ratio field of a key for the residue x
+        if constexpr (MODE == 2 && IDK) { uint32_t lo = 0, hi = P.nr; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rval[mid] < x) lo = mid + 1u; else hi = mid; } return lo; }
+        else return x;
+    };
+#define BKEY(a_, b_, r_) (((uint64_t)(a_) << abits) | ((uint64_t)(b_) << kb) | (uint64_t)key_ratio(r_))
 
     // ---- load the candidate image
     {   // 16-byte copies, 4 in flight per thread (all buffers are 256-byte aligned, sizes padded by the host)
@@ -1083,7 +1091,8 @@ template <int MODE, bool DEFER> __device__ __forceinline__ uint64_t big_candidat
         }
         const uint64_t key = sh.selkey;
         PLO_STAMP(1);
-        const uint32_t r = (uint32_t)(key & ((1ull << rb) - 1ull)), b = (uint32_t)(key >> rb) & ((1u << P.bb) - 1u), a = (uint32_t)(key >> abits);
+        const uint32_t rfield = (uint32_t)(key & ((1ull << kb) - 1ull)), b = (uint32_t)(key >> kb) & ((1u << P.bb) - 1u), a = (uint32_t)(key >> abits);
+        uint32_t r = rfield; if constexpr (MODE == 2 && IDK) r = rval[rfield];
         const uint32_t lm = ncols;
         if (lm + 1u >= P.NCmax) { if (tid == 0) wg_max(&sh.errflag, (uint32_t)BERR_COLS); BSYNC(); break; }
         // ---- RemOneCSE :60-194
@@ -2124,7 +2133,8 @@ __device__ __forceinline__ uint64_t big_program_gen(const BigPlan &P, uint8_t *w
     return ((uint64_t)(sh.nbadd + sh.acc0) << 32) | (sh.nbmul + sh.acc1);
 }
 
-template <int MODE, bool DEFER> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_big_kernel(BigPlan P, BigJob J)
+// IDK: mode 2 with ratio IDENTIFIERS in the pair keys (big_candidate): moduli too wide for a residue in the 48-bit key
+template <int MODE, bool DEFER, bool IDK = false> __global__ __launch_bounds__(PLO_BIG_THREADS, 4) void cse_big_kernel(BigPlan P, BigJob J)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bigdyn[];                 // hist[maxf0+1], the value / ratio tables, then per-wave scratch (nwaves * stride)
     __shared__ BigShared sh;
@@ -2160,7 +2170,7 @@ template <int MODE, bool DEFER> __global__ __launch_bounds__(PLO_BIG_THREADS, 4)
         if (c >= J.ncand) break;
         const uint64_t seed = J.seeds ? J.seeds[c] : J.seed0 + c;
         const unsigned long long tk0 = wall_clock64();
-        uint64_t ok = big_candidate<MODE, DEFER>(P, ws, seed, sh, hist, agg, P.aggbits, TB, J.err);
+        uint64_t ok = big_candidate<MODE, DEFER, IDK>(P, ws, seed, sh, hist, agg, P.aggbits, TB, J.err);
         uint64_t res = 0;
         __syncthreads();
         const unsigned long long tk1 = wall_clock64();

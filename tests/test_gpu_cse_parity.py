@@ -71,22 +71,47 @@ def test_largest_31_bit_prime_on_wide_matrices(hip, name):
     assert plan.search(9, 400) == M.search(9, 400, nthreads=8)
 
 
-def test_capacity_error_is_loud(hip):
-    """A pair key beyond 51 bits (more than 1024 columns with a 31-bit modulus) is refused by the LDS kernel, and the HBM family
-    refuses 31-bit ratios in its 48-bit key: the plan fails loudly, nothing is rerouted silently."""
+def _wide(p, vals, seed=1):
     import random
-    from plinopt_amd import CSEPlan, capi
-    p = 2147483629
-    rng = random.Random(1)
+    rng = random.Random(seed)
     rows = [sorted(rng.sample(range(1100), 6)) for _ in range(40)]
     rp, c, v = [0], [], []
     for r in rows:
         for j in r:
-            c.append(j); v.append(rng.choice([1, p - 1, 2]))
+            c.append(j); v.append(rng.choice(vals))
         rp.append(len(c))
+    return 40, 1100, rp, c, v
+
+
+def test_capacity_error_is_loud(hip):
+    """A pair key beyond 51 bits (more than 1024 columns with a 31-bit modulus) is refused by the LDS kernel; the HBM family takes it with
+    ratio identifiers in its 48-bit key when the matrix has at most 32 distinct coefficients (next test) and refuses it otherwise:
+    the plan fails loudly, nothing is rerouted silently."""
+    import random
+    from plinopt_amd import CSEPlan, capi
+    p = 2147483629
+    rng = random.Random(2)
+    vals = [1, p - 1] + [rng.randint(2, p - 2) for _ in range(40)]
+    m, n, rp, c, v = _wide(p, vals)
+    assert len(set(v)) > 32
     with pytest.raises(capi.PloError) as e:
-        CSEPlan(40, 1100, rp, c, v, p)
-    assert e.value.code == capi.PLO_E_CAPACITY
+        CSEPlan(m, n, rp, c, v, p)
+    assert e.value.code == capi.PLO_E_CAPACITY and "ratio identifiers" in str(e.value)
+
+
+@pytest.mark.parametrize("p", [2147483629, 2147483647, 1073741827])
+def test_31_bit_prime_with_1100_columns_on_the_hbm_family(hip, p):
+    """Round 4: a modulus too wide for a residue in the HBM family's 48-bit pair key (31 bits leave 8 per column) gets the ratio's
+    IDENTIFIER there (plo::cse_big_kernel<2, ., true>; at most 32 distinct coefficients, i.e. every +-1 matrix and the few-valued
+    kind) -- PLO_E_CAPACITY in round 3 (reference field: Modular<Integer>, src/optimizer.cpp:125-139).  Against the literal oracle."""
+    from plinopt_amd import CSEPlan
+    m, n, rp, c, v = _wide(p, [1, p - 1, 2, p - 3, 5])
+    M = OracleMatrix(m, n, rp, c, v, p)
+    plan = CSEPlan(m, n, rp, c, v, p)
+    assert plan.is_hbm
+    assert plan.cost_many(seed0=3, n=12) == tuple(M.cost_many(seed0=3, nseeds=12, nthreads=8))
+    assert plan.search(3, 12) == M.search(3, 12, nthreads=8)
+    plan.close()
 
 
 @pytest.mark.parametrize("name,nseeds", [("2x2x2_7_Winograd_L.sms", 100000), ("cyclic.sms", 30000), ("4x4x4_49_156_L.sms", 12000),

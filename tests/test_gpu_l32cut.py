@@ -67,6 +67,20 @@ def test_cut_with_single_ratio_entries(hip, cut, monkeypatch):
     assert a == G["adds"][:8] and mu == G["muls"][:8]
 
 
+def test_cut_with_ratio_identifiers_in_the_pair_keys(hip, cut, monkeypatch):
+    """plo::cse_big_kernel<2, ., true> (what a modulus too wide for a residue in the 48-bit pair key gets, e.g. a 31-bit prime with more
+    than 256 columns): the ratio field of a key holds the ratio's rank among the sorted ratios, so keys keep their order and the tie
+    pick (plinopt_optimize.inl:244-253) walks the same sequence.  Forced here on the modulus of the fixture: same costs, deferred
+    and eager."""
+    G, csr, _ = cut
+    monkeypatch.setenv("PLO_BIG_IDKEYS", "1")
+    a, mu, cnt = _run(csr, G, n=8)
+    assert a == G["adds"][:8] and mu == G["muls"][:8]
+    monkeypatch.setenv("PLO_BIG_EAGER", "1")
+    a, mu, cnt = _run(csr, G, n=4)
+    assert a == G["adds"][:4] and mu == G["muls"][:4]
+
+
 def test_cut_b_rows_of_four_chunks(hip, cut):
     """Second cut (tests/golden/l32cutB_costs.json, literal oracle): 24 short rows and two rows of 256 entries -- a row
     is swept in four 64-lane chunks and rewritten in place across chunk boundaries."""

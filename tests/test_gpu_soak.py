@@ -4,7 +4,8 @@ against the product's host engines.
 
   wave kernel          200 random matrices of up to 200 x 64 over five moduli, 8 seeds each              (soak_wave.py)
   HBM family            40 matrices the literal oracle can walk, forced through plo_cse_big.hip, 3 seeds;
-                        two of the dense few-valued kind whose live triples outgrow the planned structures (soak_hbm.py)
+                        two of the dense few-valued kind whose live triples outgrow the planned structures (soak_hbm.py);
+                        36 more over moduli of 25 to 31 bits (ratio identifiers in the pair keys)
   kernel method        200 matrices x 12 restarts: decomposition, both images, both programs             (soak_misc.py)
   in-place trilinear   500 triples (+-1 and rational, plain and `-e`) x 12 seeds x both variants          (soak_misc.py)
   change of basis      300 groups of 1-4 enumerations, single and batched launches                         (soak_misc.py --cob)
@@ -104,6 +105,36 @@ def test_hbm_family_on_matrices_the_literal_oracle_walks(hip):
         plan.close()
         assert got == e, (s, m, n)
     print("HBM soak slice: %d matrices, %d plan rebuilds" % (len(cases), refits))
+
+
+def test_hbm_family_with_wide_moduli(hip):
+    """Moduli of 25 to 31 bits on the HBM family: residues in the pair keys while they leave room for the columns, ratio identifiers
+    beyond (31 bits: always) -- 36 matrices of at most 32 distinct coefficients, 3 seeds each, against the literal oracle."""
+    from plinopt_amd import CSEPlan
+    cases = []
+    for s in range(36):
+        rng = random.Random(7500 + s)
+        p = rng.choice([2147483629, 2147483647, 1073741827, 16777259])
+        m, n = rng.randint(20, 80), rng.randint(16, 300)
+        per_row = rng.randint(3, 12)
+        nv = rng.choice([0, 1, 3, 12, 30])
+        vals = [1, p - 1] + [rng.randint(2, p - 2) for _ in range(nv)]
+        rows = [{j: rng.choice(vals) for j in rng.sample(range(n), min(n, per_row))} for _ in range(m)]
+        cases.append((s, p, m, n, rows))
+
+    def oracle(case):
+        s, p, m, n, rows = case
+        rp, c, v = synth.to_csr(rows, p)
+        return tuple(OracleMatrix(m, n, rp, c, v, p).cost_many(seed0=s * 7, nseeds=3, nthreads=1))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        exp = list(ex.map(oracle, cases))
+    for (s, p, m, n, rows), e in zip(cases, exp):
+        rp, c, v = synth.to_csr(rows, p)
+        plan = CSEPlan(m, n, rp, c, v, p, hbm=True)
+        assert plan.is_hbm
+        got = plan.cost_many(seed0=s * 7, n=3)
+        plan.close()
+        assert got == e, (s, p, m, n)
 
 
 def test_kernel_method_on_random_matrices(hip):
