@@ -186,11 +186,11 @@ def gather_per_rank(dev, world, kernel_ms, search_s, reduce_s):
 
 def issue_roofline(name, kernel, per_launch_ms):
     """For the kernels whose state lives in LDS the HBM roofline says nothing: report instruction issue instead, from the
-    committed rocprofv3 counters of the same workload (profiles/r03_issue.json, else r02_issue.json: SQ_INSTS_* / SQ_BUSY_CYCLES).
+    committed rocprofv3 counters of the same workload (profiles/r04_issue.json, else r03 / r02: SQ_INSTS_* / SQ_BUSY_CYCLES).
     The counters belong to one version of the kernel: `stale` says whether the source has changed since; `achieved` is scaled by
     profiled kernel time / this run's kernel time (the instruction count of a launch does not change with the clock)."""
     d = None
-    for fn in ("r03_issue.json", "r02_issue.json"):
+    for fn in ("r04_issue.json", "r03_issue.json", "r02_issue.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn))).get(name)
         except Exception:

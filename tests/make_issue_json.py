@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03_issue.json entry from a rocprofv3 --pmc summary (tests/rocpd_summary.py *_pmc.csv):
+"""profiles/r04_issue.json entry (the file starts as a copy of r03_issue.json: entries of unchanged kernels stay) from a rocprofv3 --pmc summary (tests/rocpd_summary.py *_pmc.csv):
    python tests/make_issue_json.py <workload> <kernel substring> <profiles/xxx_pmc.csv> "<source note>"
 Rates are per clock and compute unit (256 CUs); cycles = SQ_BUSY_CYCLES / 32 (MI355X_MICROARCH.md, profiling section).
 Every entry carries the hash of the kernel sources it was measured on: bench.py marks the figure stale when they have changed."""
@@ -31,8 +31,9 @@ def main(name, kern, csv, note):
          "lds_per_clk_cu": avg["SQ_INSTS_LDS"] / cyc / 256, "vmem_per_clk_cu": (avg.get("SQ_INSTS_VMEM_RD", 0) + avg.get("SQ_INSTS_VMEM_WR", 0)) / cyc / 256,
          "source": note, "kernel_source_sha16": sources_sha16(name)}
     e["bound_unit"] = "scalar" if e["salu_per_clk_cu"] / 1.0 >= e["valu_per_clk_cu"] / 2.0 else "vector"
-    p = os.path.join(ROOT, "profiles", "r03_issue.json")
-    d = json.load(open(p)) if os.path.exists(p) else {"_comment": "Issue-rate view of the kernels that are not HBM-bound (rocprofv3 --pmc SQ_INSTS_* / SQ_BUSY_CYCLES, per launch; cycles = SQ_BUSY_CYCLES / 32 shader engines; rates per clock and compute unit, 256 CUs). Peaks used by bench.py: 1 scalar and 2 vector wave-instructions per clock and CU. kernel_source_sha16: sha256 of the kernel source(s) at measurement time."}
+    p = os.path.join(ROOT, "profiles", "r04_issue.json")
+    prev = os.path.join(ROOT, "profiles", "r03_issue.json")
+    d = json.load(open(p)) if os.path.exists(p) else json.load(open(prev)) if os.path.exists(prev) else {"_comment": "Issue-rate view of the kernels that are not HBM-bound (rocprofv3 --pmc SQ_INSTS_* / SQ_BUSY_CYCLES, per launch; cycles = SQ_BUSY_CYCLES / 32 shader engines; rates per clock and compute unit, 256 CUs). Peaks used by bench.py: 1 scalar and 2 vector wave-instructions per clock and CU. kernel_source_sha16: sha256 of the kernel source(s) at measurement time."}
     d[name] = e
     json.dump(d, open(p, "w"), indent=1)
     print(name, json.dumps(e))

@@ -49,6 +49,28 @@ for f in sorted(glob.glob(os.path.join(DATA, "*.sms"))):
         continue
     check(os.path.basename(f), M, 1000, 12)
 print("# data matrices:", ran, "checked,", bad, "mismatches", flush=True)
+if os.environ.get("PLO_SOAK_WIDE"):
+    # moduli of 25 to 31 bits, at most 32 distinct coefficients, up to 2000 columns: residues in the 48-bit pair keys while they leave room
+    # for the columns, ratio identifiers beyond (plo::cse_big_kernel<2, ., true>); against the literal oracle
+    s = 0; wide = refused = 0
+    while time.time() - t0 < budget:
+        rng = random.Random(7700 + s); s += 1
+        p = rng.choice([2147483629, 2147483647, 1073741827, 16777259, 536870923])
+        m, n = rng.randint(10, 120), rng.randint(8, 2000)
+        per_row = rng.randint(2, 14)
+        vals = [1, p - 1] + [rng.randint(2, p - 2) for _ in range(rng.choice([0, 1, 3, 12, 30]))]
+        rows = [{j: rng.choice(vals) for j in rng.sample(range(n), min(n, per_row))} for _ in range(m)]
+        rp, c, v = synth.to_csr(rows, p)
+        try:
+            check("wide %d %dx%d" % (p, m, n), OracleMatrix(m, n, rp, c, v, p), s * 5, 4)
+            wide += 1
+        except capi.PloError as e:
+            if e.code not in (capi.PLO_E_CAPACITY, capi.PLO_E_UNSUPPORTED):
+                raise
+            refused += 1
+            print("refused:", str(e)[:140], flush=True)
+    print("# wide moduli: %d matrices, %d refused; total %d checked, %d mismatches in %.0f s" % (wide, refused, ran, bad, time.time() - t0), flush=True)
+    sys.exit(1 if bad else 0)
 import re              # noqa: E402
 import subprocess      # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

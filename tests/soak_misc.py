@@ -48,6 +48,7 @@ while time.time() - t0 < budget:                                # ---- in-place 
     rng = random.Random(12000 + s); s += 1
     m = rng.randint(2, 40); na, nb, nc = rng.randint(2, 12), rng.randint(2, 12), rng.randint(2, 12)
     unit = rng.random() < 0.6
+    expanded = rng.random() < 0.35                              # `trilplacer -e` (round 4: rational inputs too)
     def mat(rows, cols):
         e = {}
         for i in range(rows):
@@ -61,9 +62,9 @@ while time.time() - t0 < budget:                                # ---- in-place 
     O = OracleTril(A, B, C)
     try:
         if unit:
-            G = TrilPlan(O.m, [(n_, rp, col, [int(x) for x in num]) for n_, (rp, col, num, den) in zip(O.dims, O.csr)])
+            G = TrilPlan(O.m, [(n_, rp, col, [int(x) for x in num]) for n_, (rp, col, num, den) in zip(O.dims, O.csr)], expanded=expanded)
         else:
-            G = TrilPlan(O.m, [(n_, rp, col, [int(x) for x in num], [int(x) for x in den]) for n_, (rp, col, num, den) in zip(O.dims, O.csr)])
+            G = TrilPlan(O.m, [(n_, rp, col, [int(x) for x in num], [int(x) for x in den]) for n_, (rp, col, num, den) in zip(O.dims, O.csr)], expanded=expanded)
         got = G.cost_many(seed0=s, n=12)
     except capi.PloError as e:
         if e.code in (capi.PLO_E_CAPACITY, capi.PLO_E_UNSUPPORTED):
@@ -71,9 +72,9 @@ while time.time() - t0 < budget:                                # ---- in-place 
             continue
         raise
     ran2 += 1
-    if got != O.cost_many(seed0=s, nseeds=12):
+    if got != O.cost_many(seed0=s, nseeds=12, expanded=expanded):
         bad += 1
-        print("MISMATCH trilinear case", s - 1, m, na, nb, nc, unit, flush=True)
+        print("MISMATCH trilinear case", s - 1, m, na, nb, nc, unit, expanded, flush=True)
 print("# trilinear: %d triples, %d refused; total mismatches %d in %.0f s" % (ran2, refused2, bad, time.time() - t0), flush=True)
 if "--cob" in sys.argv:                                         # ---- change-of-basis enumeration (and its batch entry)
     from plo_testlib import oracle_cob_search
