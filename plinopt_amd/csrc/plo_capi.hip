@@ -410,8 +410,12 @@ int build_big_plan(plo_plan *pl)
         std::vector<uint16_t> rt(PLO_RSTRIDE * PLO_RSTRIDE, 0), iv(rv.size());     // identifiers at [i * 32 + j]
         for (uint32_t i = 0; i < nv; ++i) for (uint32_t j = 0; j < nv; ++j) rt[i * PLO_RSTRIDE + j] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), rat[i * nv + j]) - rv.begin());
         for (size_t k = 0; k < rv.size(); ++k) iv[k] = (uint16_t)(std::lower_bound(rv.begin(), rv.end(), inv_mod(rv[k], p)) - rv.begin());   // the inverse of v_i/v_j is v_j/v_i: in the set
-        if ((rc = upload(pl, rv, &B.rval)) || (rc = upload(pl, rt, &B.rtid)) || (rc = upload(pl, iv, &B.invid))) return rc;
+        std::vector<uint8_t> ng(PLO_RSTRIDE, 0xFF);                                 // value index of -v
+        for (uint32_t i = 0; i < nv; ++i) { const auto it = std::lower_bound(dv.begin(), dv.end(), p - dv[i]); if (it != dv.end() && *it == p - dv[i]) ng[i] = (uint8_t)(it - dv.begin()); }
+        if ((rc = upload(pl, rv, &B.rval)) || (rc = upload(pl, rt, &B.rtid)) || (rc = upload(pl, iv, &B.invid)) || (rc = upload(pl, ng, &B.negidx))) return rc;
         B.nr = (uint32_t)rv.size(); B.mode = 2u;
+        B.id_one = (uint32_t)(std::lower_bound(rv.begin(), rv.end(), 1u) - rv.begin());
+        { const auto it = std::lower_bound(rv.begin(), rv.end(), p - 1u); B.id_mone = (it != rv.end() && *it == p - 1u) ? (uint32_t)(it - rv.begin()) : 0xFFFFu; }
     }
     B.invtab = nullptr;
     if (p <= (1u << 20)) {                                   // 1/x for every residue (the flush needs v_a/v_c from v_c/v_a): i^-1 = -(p/i) (p mod i)^-1
@@ -447,10 +451,24 @@ int build_big_plan(plo_plan *pl)
       if (bb + 2u * rb + cb <= 64u && !getenv("PLO_BIG_NODUAL")) { B.agg_dual = 1u; B.agg_cb = 64u - bb - 2u * rb; if (B.agg_cb > 16u) B.agg_cb = 16u; }
       else { B.agg_dual = 0u; B.agg_cb = 16u; } }
     // dynamic LDS, in words: histogram, tables of the mode, then max(ProgramGen scratch, aggregation table: 2^aggbits entries of 8 bytes, 6 in mode 2)
+    // Mode 2 with deferred updates (the flat sweep): beside the hashed aggregation table the scratch region holds a DIRECT count table
+    // indexed by column for the entries whose ratio is +-1 (84 % of config 5's), and the waves' queues of the other entries
+    // (plo_cse_big.hip, "direct counts"); the hashed table then has 2^12 slots at most.
+#ifdef PLO_BIG_DIRECT
+    const bool direct = B.mode == 2u && B.defer && !getenv("PLO_BIG_NODIRECT");
+#else
+    const bool direct = false;                               // (an experiment of round 4, kept behind -DPLO_BIG_DIRECT: DESIGN.md 2.2)
+#endif
+    if (direct && B.aggbits > 12u && !getenv("PLO_BIG_AGGBITS")) B.aggbits = 12u;
     const uint32_t agg_words = B.mode == 2u ? (1u << B.aggbits) + (1u << B.aggbits) / 2u : 2u << B.aggbits;
     uint32_t scr_words = std::max<uint32_t>((PLO_BIG_THREADS / 64) * maxlen, agg_words);
-    uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + PLO_RSTRIDE * PLO_RSTRIDE / 2u + (B.nr + 3u) / 4u * 2u + (B.defer ? 0u : (1u << B.aggbits) / 2u) : 0u;   // mode 2: ratio values, ratio ids, inverse ids, slot list of the aggregation table (eager flush only)
+    uint32_t tab_words = B.mode == 1u ? 2u * ((B.nv + 1u) & ~1u) : B.mode == 2u ? ((B.nr + 1u) & ~1u) + PLO_RSTRIDE * PLO_RSTRIDE / 2u + (B.nr + 3u) / 4u * 2u + PLO_RSTRIDE / 4u + (B.defer ? 0u : (1u << B.aggbits) / 2u) : 0u;   // mode 2: ratio values, ratio ids, inverse ids, negated value indices, slot list of the aggregation table (eager flush only)
     if (B.defer) { tab_words += PLO_DBLOOM_WORDS; scr_words = std::max<uint32_t>(scr_words, PLO_DMREG_WORDS - PLO_DBLOOM_WORDS); }   // Bloom filter, and 64 KB in all for the merge
+    B.dcols = 0u;
+    if (direct && scr_words >= agg_words + PLO_BIG_QUEUE_WORDS + 1024u) {
+        B.dcols = std::min<uint32_t>(scr_words - agg_words - PLO_BIG_QUEUE_WORDS, 32768u);
+        if (const char *e = getenv("PLO_BIG_DCOLS")) B.dcols = (uint32_t)std::min<long>(B.dcols, std::max<long>(1, strtol(e, nullptr, 10)));   // test knob: columns beyond go through the queue
+    }
     pl->big_lds = (((B.maxf0 + 2u) & ~1u) + tab_words + scr_words) * 4u;
     if (pl->big_lds + sizeof(plo::BigShared) + 64 > g_lds_max) return fail(PLO_E_CAPACITY, "frequency histogram does not fit LDS");
     HIPCHK(hipFuncSetAttribute(big_kernel_fn(B), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->big_lds));

@@ -91,6 +91,10 @@ struct BigPlan {
     const uint64_t *st0; const uint32_t *pcount0;     // store image: 2^pbits partitions of capp entries (key48<<16 | count16), entries per partition
     uint64_t o_store, o_pcount, o_ptail, o_log, o_plog, o_hot;
     uint32_t kb, idk;                     // idk: the ratio field of a pair key holds the ratio's identifier (kb bits), not the residue (cse_big_kernel<2, ., true>)
+    // -DPLO_BIG_DIRECT (an experiment of round 4) -- mode 2 with deferred updates: columns of the DIRECT count table of the flat
+    // sweep (0: none), identifiers of the ratios 1 and -1 (0xFFFF: -1 is no ratio of the matrix), value index of -v for every value index (0xFF: none)
+    uint32_t dcols, id_one, id_mone;
+    const uint8_t *negidx;
 };
 
 struct BigJob {
@@ -366,9 +370,23 @@ __device__ __forceinline__ bool agg_add(uint64_t *agg, uint32_t aggbits, uint32_
 // Mode 2 (at most 32 distinct values, hence at most 1024 distinct ratios v_i/v_j): an aggregation entry is
 // (column << 10 | ratio identifier) in a u32 key array and a u16 count array -- 6 bytes per entry instead of 8, 32-bit
 // LDS operations, and no modular product in the sweep (the identifier comes from a 2-byte table lookup).
+#ifdef PLO_BIG_DIRECT
+#define PLO_DIRECT_ONLY(x_) x_
+#else
+#define PLO_DIRECT_ONLY(x_)
+#endif
+#define PLO_BIG_QUEUE 128u                  // entries of a wave's queue of the flat sweep ("direct counts")
+#define PLO_BIG_QUEUE_WORDS (PLO_BIG_QUEUE * (PLO_BIG_THREADS / 64u))
+#ifndef PLO_BIG_DIRECT_MIN
+#define PLO_BIG_DIRECT_MIN 128u            // steps of fewer rows use the hashed table only (their flush does not scan the direct table)
+#endif
 #define PLO_RIDB 10u
 #define PLO_RSTRIDE 32u                    // row stride of the ratio-identifier table (at most 32 values): an index is a shift and an or
-struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint16_t *list; uint32_t *bloom; };   // bloom: DEFER, followed by the scratch region   // list: mode 2, one u16 per aggregation slot
+#ifdef PLO_BIG_DIRECT
+struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint16_t *list; uint32_t *bloom; const uint8_t *negidx; };
+#else
+struct BigTabs { const uint2 *vts; const uint16_t *rtid; const uint32_t *rval; const uint16_t *invid; uint16_t *list; uint32_t *bloom; };
+#endif   // bloom: DEFER, followed by the scratch region   // list: mode 2, one u16 per aggregation slot
 __device__ __forceinline__ bool agg_add_rid(uint32_t *aggk, uint32_t *aggc32, uint32_t aggbits, uint32_t key, uint32_t *aggn, uint16_t *agglist, uint32_t listcap) {
     const uint32_t mask = (1u << aggbits) - 1u;
     uint32_t s = (key * 0x9E3779B1u) >> (32u - aggbits);
@@ -480,6 +498,9 @@ __device__ __forceinline__ int row_find(const uint32_t *ent, uint32_t base, uint
 struct BigShared {
     uint32_t M, theta, ncols, nbadd, nbmul, nmult, naff, dmcount, hlcount, rng, errflag, sel_n, sel_over, invr, fullscans, rebuilds, steps, hlbad, acc0, acc1;
     uint32_t a, b, r, aggn, nspill, keepn; uint64_t kprime; uint64_t selkey;
+#ifdef PLO_BIG_DIRECT
+    uint32_t dn;                   // words of the direct count table the step's sweep has touched (listed for the flush)
+#endif
     uint32_t nbisect, spilltot, listover, nwin, nsearched;   // nwin: windows of the flat sweep beyond the first of a batch of rows (thread 0's wave); nsearched: rows walked by the row search   // diagnostics: tie picks by bisection, entries through the spill list, sweeps whose slot list overflowed
     uint32_t logn, hotn, hotbits, nforced, hotops, logtot_lo, logtot_hi;   // DEFER: log fill, claimed hot slots, hot table size; diagnostics: merges forced by log/hot pressure, updates served by the hot table, log entries written
     uint32_t derr; unsigned long long tmg[4], tmb[4]; uint32_t ngrp; uint32_t outcnt[64];           // DEFER merge: live entries written back per partition of the current group
@@ -839,6 +860,11 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
     auto VT = [&](uint32_t vi) -> uint2 { if constexpr (MODE == 1) return vts[vi]; else return vtg[vi]; };
     const uint16_t *rtid = TB.rtid, *invid = TB.invid; const uint32_t *rval = TB.rval;   // mode 2
     uint32_t *aggk = (uint32_t *)agg, *aggc32 = aggk + (1u << aggbits); uint16_t *aggc16 = (uint16_t *)aggc32;      // mode 2: key array, count array
+    // Direct counts (round 4, mode 2 with deferred updates): behind the hashed table, one word per column c < P.dcols -- low half: entries
+    // of ratio 1 met by the running sweep, high half: ratio -1 -- and a queue of PLO_BIG_QUEUE words per wave (see the flat sweep)
+#ifdef PLO_BIG_DIRECT
+    uint32_t *dcnt = aggc32 + (1u << aggbits) / 2u, *wqueue = dcnt + P.dcols;
+#endif
     uint32_t *aff   = (uint32_t *)(ws + P.o_aff), *ncrptr = (uint32_t *)(ws + P.o_ncrptr), *ncr = (uint32_t *)(ws + P.o_ncr);
     // slots claimed in the aggregation table by the running sweep (the flush walks this list, not the table): mode 2 has room
     // for every slot; the other modes keep a short list in the tie-selection buffer, idle during the sweeps, and walk the
@@ -894,6 +920,9 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
     const uint32_t acb = P.agg_cb; const uint64_t AEMPTY = ~0ull << acb;
     if constexpr (MODE == 2) { for (uint32_t s = tid; s < (1u << aggbits); s += nth) { aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0; } }
     else for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = AEMPTY;
+#ifdef PLO_BIG_DIRECT
+    if constexpr (MODE == 2 && DEFER) for (uint32_t s = tid; s < P.dcols; s += nth) dcnt[s] = 0u;
+#endif
     if (tid == 0) {
         uint64_t x = seed + 0x9E3779B97F4A7C15ull;
         x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
@@ -934,6 +963,9 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                 if (!dfirst) {                                                // the merge worked in the scratch region: the aggregation table is empty again
                     if constexpr (MODE == 2) { for (uint32_t s = tid; s < (1u << aggbits); s += nth) { aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0; } }
                     else for (uint32_t s = tid; s < (1u << aggbits); s += nth) agg[s] = AEMPTY;
+#ifdef PLO_BIG_DIRECT
+                    if constexpr (MODE == 2 && DEFER) for (uint32_t s = tid; s < P.dcols; s += nth) dcnt[s] = 0u;
+#endif
                     BSYNC();
                 }
                 dfirst = false; need_rebuild = true; hbits = sh.hotbits;
@@ -1098,7 +1130,7 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
         // ---- RemOneCSE :60-194
         const bool swap = gload32(&ucount[a]) < gload32(&ucount[b]);      // :70-88
         const uint32_t l0 = swap ? b : a, l1 = swap ? a : b;
-        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; sh.keepn = 0; }      // (nothing here uses `swap`: the two counts stay in flight while the row lists are walked)
+        if (tid == 0) { sh.naff = 0; sh.aggn = 0; sh.nspill = 0; sh.keepn = 0; PLO_DIRECT_ONLY(sh.dn = 0;) }      // (nothing here uses `swap`: the two counts stay in flight while the row lists are walked)
         if constexpr (FAST) { for (uint32_t w = tid; w < ((1u << aggbits) + 31u) / 32u; w += nth) aggbm[w] = 0u; }      // (the tie pick used the buffer)
         BSYNC();
 #define RL(v_, k_) ((uint32_t)__builtin_amdgcn_readlane((int)(v_), (int)(k_)))
@@ -1129,7 +1161,13 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                 if constexpr (MODE == 2) {
                     // 16-byte record (value indices have 5 bits): positions, row start, length (<= 8192: 14 bits) | value index and +-1 flag of
                     // the a and b entries, row -- 32 bytes in round 2: 48 MB less written and read per candidate on config 5
-                    *(uint4 *)(aff + 4u * idx) = make_uint4(pa | (pb << 16), base, L | (PLO_EUNIT(ea) << 14) | (PLO_EVI(ea) << 15) | (PLO_EUNIT(eb) << 20) | (PLO_EVI(eb) << 21), i);
+                    // (bits 26-31: the value index of -v_a and "there is one" -- the direct counts of the flat sweep)
+#ifdef PLO_BIG_DIRECT
+                    const uint32_t nva = TB.negidx[PLO_EVI(ea)];
+#else
+                    const uint32_t nva = 0xFFu;
+#endif
+                    *(uint4 *)(aff + 4u * idx) = make_uint4(pa | (pb << 16), base, L | (PLO_EUNIT(ea) << 14) | (PLO_EVI(ea) << 15) | (PLO_EUNIT(eb) << 20) | (PLO_EVI(eb) << 21) | ((nva & 31u) << 26) | (nva != 0xFFu ? 0x80000000u : 0u), i);
                 } else {
                 uint32_t *rec = aff + 8u * idx;                             // record: row, positions (16 bits each), row start and length; the two packed entries
                 *(uint4 *)rec = make_uint4(i, pa | (pb << 16), base, L);
@@ -1345,6 +1383,30 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
             // earlier), so no load sees a store.
             uint64_t *fm = sh.sel + 256u + 32u * wave;                  // (the bitmap of claimed slots takes at most the first 2 KB)
             const uint32_t dump = P.nnz + 64u + lane;                   // (the entry array has 128 spare words)
+            // Direct counts (round 4).  On config 5 84 % of the entries carry +-7710: four of five swept entries have ratio 1 or -1 to
+            // their row's v_a, and every trip paid the ratio lookup, the pair read and (96 % of the trips: some lane claims) the
+            // compare-and-swap for all 64 lanes.  Now an entry of ratio +-1 in a column below P.dcols is ONE fire-and-forget add to the
+            // column's word of a direct table (no lookup: v == v_a, or v == -v_a with the index of -v_a carried by the row record);
+            // the other entries are appended to the wave's queue (column, value indices: 30 bits) and go through the hashed table 64 at
+            // a time, full lanes.  The flush reads both tables.  Steps of fewer than PLO_BIG_DIRECT_MIN rows keep to the hashed table
+            // (their flush does not scan the direct one).
+#ifdef PLO_BIG_DIRECT
+            const bool use_direct = P.dcols != 0u && naff >= PLO_BIG_DIRECT_MIN;
+            uint32_t *wq = wqueue + wave * PLO_BIG_QUEUE; uint32_t qn = 0;
+            auto drain = [&](uint32_t cntq) {                           // the first min(cntq, 64) queued entries: hashed table (or its fall-back)
+                __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier();
+                const bool on = lane < cntq;
+                const uint32_t raw = on ? __hip_atomic_load(&wq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                if (on) retire_entry((raw & 0x7FFFu) | (((raw >> 15) & 31u) << 16), (raw >> 20) & 31u, (raw >> 25) & 31u, make_uint2(0, 0), make_uint2(0, 0));
+                if (cntq > 64u) {
+                    const bool mv = lane + 64u < cntq;
+                    const uint32_t x_ = mv ? __hip_atomic_load(&wq[lane + 64u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier();
+                    if (mv) __hip_atomic_store(&wq[lane], x_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier();
+            };
+#endif
             const uint32_t selsh = l0 == a ? 14u : 20u;                 // the new column's entry carries the +-1 flag and the value index of the l0 entry
             for (uint32_t k0 = 0; k0 < nrw; k0 += 64u) {
                 const bool have = k0 + lane < nrw;
@@ -1467,6 +1529,22 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
 #ifdef PLO_BIG_PROFILE
                         __builtin_amdgcn_wave_barrier(); const unsigned long long t1_ = clock64(); probe_iters = 0;
 #endif
+#if defined(PLO_BIG_DIRECT) && !defined(PLO_BIG_PROFILE)
+                        if (use_direct) {
+                            const uint32_t cE = PLO_ECOL(ec), viE = PLO_EVI(ec) & 31u, viaE = (rzc >> 15) & 31u;
+                            const bool one = viE == viaE, mone = (rzc >> 31) != 0u && viE == ((rzc >> 26) & 31u);
+                            const bool dir = act && cE < P.dcols && (one || mone);
+                            if (dir) wg_add(&dcnt[cE], one ? 1u : 0x10000u);
+                            const bool qd = act && !dir;
+                            const uint64_t qm = __builtin_amdgcn_ballot_w64(qd);
+                            if (qm) {
+                                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                                if (qd) __hip_atomic_store(&wq[qn + rk], cE | (viE << 15) | (viaE << 20) | (((rzc >> 21) & 31u) << 25), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                qn += (uint32_t)__builtin_popcountll(qm);          // (below 64 before: never beyond the queue's 128 words)
+                                if (qn >= 64u) { drain(qn); qn -= 64u; }
+                            }
+                        } else
+#endif
                         if (act) retire_entry(ec, (rzc >> 15) & 31u, (rzc >> 21) & 31u, make_uint2(0, 0), make_uint2(0, 0));
 #ifdef PLO_BIG_PROFILE
                         {   __builtin_amdgcn_wave_barrier(); const unsigned long long t2_ = clock64(); pw0 += t1_ - t0_; pw1 += t2_ - t1_; pw2 += t0_ - tl_; tl_ = t2_; ++ptr;
@@ -1478,6 +1556,9 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
 #endif
                 }
             }
+#ifdef PLO_BIG_DIRECT
+            if (qn) drain(qn);                                          // what the wave's queue still holds
+#endif
             } else
 #endif
             for (uint32_t k0 = 0; k0 < nrw; k0 += 64u) {
@@ -1577,23 +1658,74 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                 else { gstore64(&tab[sl], v - (uint64_t)M); retired(key, M, M); }
             }
             const uint32_t nent = sh.aggn, nslot = FAST ? (1u << aggbits) / 16u : nent <= listcap ? nent : (1u << aggbits);     // few entries: walk the slot list, not the table (FAST: the bitmap, 16 slots per thread and round)
+            // FAST: behind the bitmap words of the hashed table, the words of the direct table (columns below the new one) when the step's sweep used it
+            // (its non-zero words are first listed -- a light pass, 16-bit column numbers in the waves' queue space, idle by now -- so that the
+            // rounds below are as many as the touched columns need, not as many as the table has; a list that overflows: the whole table)
+#ifdef PLO_BIG_DIRECT
+            uint32_t ndir = 0; bool dlisted = false;
+            uint16_t *dlist = (uint16_t *)wqueue;
+            if constexpr (FAST) {
+                if (P.dcols != 0u && naff >= PLO_BIG_DIRECT_MIN) {
+                    const uint32_t nd0 = lm < P.dcols ? lm : P.dcols;
+                    for (uint32_t w0 = 0; w0 < nd0; w0 += nth) {
+                        const uint32_t w = w0 + tid;
+                        const bool nz = w < nd0 && dcnt[w] != 0u;
+                        const uint64_t bm_ = __builtin_amdgcn_ballot_w64(nz);
+                        if (bm_) {
+                            uint32_t base_ = 0;
+                            if (lane == 0) base_ = wg_add(&sh.dn, (uint32_t)__builtin_popcountll(bm_));
+                            base_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_);
+                            const uint32_t ix = base_ + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm_, 0u));
+                            if (nz && ix < 2u * PLO_BIG_QUEUE_WORDS) dlist[ix] = (uint16_t)w;
+                        }
+                    }
+                    BSYNC();
+                    const uint32_t dn = sh.dn;
+                    dlisted = dn <= 2u * PLO_BIG_QUEUE_WORDS;
+                    ndir = dlisted ? dn : nd0;
+                }
+            }
+#endif
             uint32_t nhot = 0;
-            for (uint32_t s0 = 0; s0 < nslot; s0 += nth) {
+#ifndef PLO_BIG_DIRECT
+            const uint32_t ndir = 0;
+#endif
+            for (uint32_t s0 = 0; s0 < nslot + ndir; s0 += nth) {
               const uint32_t e_ = s0 + tid;
-              uint32_t bits_ = 0;
-              if constexpr (FAST) { if (e_ < nslot) bits_ = (aggbm[e_ >> 1] >> ((e_ & 1u) << 4)) & 0xFFFFu; }
+              uint32_t bits_ = 0; PLO_DIRECT_ONLY(uint32_t dw_ = 0; uint32_t dcol_ = 0; const bool isdir = e_ >= nslot;)
+              if constexpr (FAST) {
+                  if (e_ < nslot) bits_ = (aggbm[e_ >> 1] >> ((e_ & 1u) << 4)) & 0xFFFFu;
+#ifdef PLO_BIG_DIRECT
+                  else if (e_ - nslot < ndir) { dcol_ = dlisted ? (uint32_t)dlist[e_ - nslot] : e_ - nslot; dw_ = dcnt[dcol_]; if (dw_) dcnt[dcol_] = 0u; bits_ = ((dw_ & 0xFFFFu) ? 1u : 0u) | ((dw_ >> 16) ? 2u : 0u); }
+#endif
+              }
               for (bool more_ = true; more_;) {
                 bool valid; uint32_t s;
+#ifdef PLO_BIG_DIRECT
+                if constexpr (FAST) { valid = bits_ != 0u; s = valid ? (isdir ? (uint32_t)__builtin_ctz(bits_) : e_ * 16u + (uint32_t)__builtin_ctz(bits_)) : 0u; bits_ &= bits_ - 1u; }
+#else
                 if constexpr (FAST) { valid = bits_ != 0u; s = valid ? e_ * 16u + (uint32_t)__builtin_ctz(bits_) : 0u; bits_ &= bits_ - 1u; }
+#endif
                 else { valid = e_ < nslot; s = valid ? (nent <= listcap ? (uint32_t)agglist[e_] : e_) : 0u; }
                 uint32_t c = 0, x = 0, y = 0, d = 0;
                 if constexpr (MODE == 2) {
+#ifdef PLO_BIG_DIRECT
+                    if (FAST && isdir) {
+                        if (valid) {
+                            const uint32_t xid = s ? P.id_mone : P.id_one;
+                            d = s ? dw_ >> 16 : dw_ & 0xFFFFu; c = dcol_;
+                            x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                        }
+                    } else
+#endif
+                    {
                     const uint32_t kq = valid ? aggk[s] : 0xFFFFFFFFu;
                     valid = kq != 0xFFFFFFFFu;
                     if (valid) {
                         d = aggc16[s]; aggk[s] = 0xFFFFFFFFu; aggc16[s] = 0; c = kq >> PLO_RIDB;
                         const uint32_t xid = kq & ((1u << PLO_RIDB) - 1u);
                         x = rval[xid]; y = rval[c > a ? (uint32_t)invid[xid] : xid];
+                    }
                     }
                 } else {
                     const uint64_t v = valid ? agg[s] : AEMPTY;
@@ -2141,7 +2273,11 @@ template <int MODE, bool DEFER, bool IDK = false> __global__ __launch_bounds__(P
     __shared__ unsigned long long cur;
     uint32_t *hist = bigdyn;
     uint32_t *nextw = bigdyn + ((P.maxf0 + 2u) & ~1u);
+#ifdef PLO_BIG_DIRECT
+    BigTabs TB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#else
     BigTabs TB{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#endif
     if constexpr (MODE == 1) {                                     // {value, inverse} per value index
         uint2 *vts = (uint2 *)nextw; nextw += 2u * ((P.nv + 1u) & ~1u);
         for (uint32_t k = threadIdx.x; k < P.nv; k += blockDim.x) vts[k] = P.vt[k];
@@ -2154,6 +2290,11 @@ template <int MODE, bool DEFER, bool IDK = false> __global__ __launch_bounds__(P
         for (uint32_t k = threadIdx.x; k < P.nr; k += blockDim.x) { rv[k] = P.rval[k]; iv[k] = P.invid[k]; }
         for (uint32_t k = threadIdx.x; k < PLO_RSTRIDE * PLO_RSTRIDE; k += blockDim.x) rt[k] = P.rtid[k];
         TB.rval = rv; TB.rtid = rt; TB.invid = iv;
+#ifdef PLO_BIG_DIRECT
+        uint8_t *ng = (uint8_t *)nextw; nextw += PLO_RSTRIDE / 4u;
+        if (threadIdx.x < PLO_RSTRIDE) ng[threadIdx.x] = P.negidx[threadIdx.x];
+        TB.negidx = ng;
+#endif
         if constexpr (!DEFER) { TB.list = (uint16_t *)nextw; nextw += (1u << P.aggbits) / 2u; }
     }
     if constexpr (DEFER) { TB.bloom = nextw; nextw += PLO_DBLOOM_WORDS; }           // Bloom filter of the hot triples; with the scratch region behind it: the merge's 64 KB
