@@ -1510,23 +1510,11 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                     settle();
 #else
                     uint32_t adc, zc, ppc, rzc, ec; prep(0u, adc, zc, ppc, rzc, ec);
-#ifndef PLO_BIG_PREFETCH1
-                    // Entries are requested TWO trips ahead (round 4).  With 512 workgroups in flight a trip of ~2,400 cycles is about what a
-                    // load takes to come back from HBM under that load: with one trip of lead every trip waited for its entry -- which is why
-                    // neither a shorter aggregation chain nor fewer instructions moved the loaded sweep.  A store of a trip
-                    // goes at most two positions below the storing entry's own address, which the same or an earlier trip has loaded: no
-                    // load of a later trip, however early, sees it.
-                    uint32_t ad1, z1, pp1, rz1, e1; prep(1u, ad1, z1, pp1, rz1, e1);
-#endif
                     // (the wait counters of the loop header merge both incoming edges: with the first entry still in flight here every
                     // trip would wait for all but one memory operation, i.e. for the stores of the trip before)
                     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
                     for (uint32_t t = 0; t < ntw; ++t) {
-#ifndef PLO_BIG_PREFETCH1
-                        uint32_t adn, zn, ppn, rzn, en; prep(t + 2u, adn, zn, ppn, rzn, en);
-#else
                         uint32_t adn, zn, ppn, rzn, en; prep(t + 1u, adn, zn, ppn, rzn, en);
-#endif
 #ifdef PLO_BIG_PROFILE
                         const unsigned long long t0_ = clock64();
 #endif
@@ -1563,12 +1551,7 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                             uint32_t mx = probe_iters; for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)mx, o); mx = u > mx ? u : mx; }
                             pit += mx; pact += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act)); tl_ = clock64(); }
 #endif
-#ifndef PLO_BIG_PREFETCH1
-                        adc = ad1; zc = z1; ppc = pp1; rzc = rz1; ec = e1;
-                        ad1 = adn; z1 = zn; pp1 = ppn; rz1 = rzn; e1 = en;
-#else
                         adc = adn; zc = zn; ppc = ppn; rzc = rzn; ec = en;
-#endif
                     }
 #endif
                 }
