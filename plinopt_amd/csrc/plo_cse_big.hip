@@ -1508,6 +1508,31 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                         adc = adn; zc = zn; ppc = ppn; rzc = rzn; ec = en;
                     }
                     settle();
+#elif !defined(PLO_BIG_PREFETCH1) && !defined(PLO_BIG_PROFILE) && !defined(PLO_BIG_DIRECT)
+                    // Round 4 (default): entries are requested TWO trips ahead and the loop is unrolled three times, so that the three sets
+                    // of trip registers (address, position in the row, the row's record words, the entry) rotate by NAME.  The one-ahead loop
+                    // below ends in `ec = en`: a copy of the entry requested at the top of the same trip, i.e. a wait for that load at the
+                    // bottom of every trip -- a load had one trip body (~1,500 cycles) to come back, and with 512 workgroups in flight it
+                    // takes longer (a first two-ahead version that kept the copies gained nothing: the copy of the newest set waited just
+                    // the same).  A store of a trip goes at most two positions below the storing entry's own address, which the same or an
+                    // earlier trip has loaded: no load of a later trip, however early, sees it.  816 -> 840-846 candidates/s A/B on one box,
+                    // a candidate alone 436 -> 421 ms (profiles/r04_ab_config5.txt); three trips ahead (four sets): 832, the registers spill.
+                    auto body3 = [&](uint32_t t, uint32_t adc, uint32_t zc, uint32_t ppc, uint32_t rzc, uint32_t ec) {
+                        const uint32_t pa = ppc & 0xFFFFu, pb = ppc >> 16;
+                        const bool in = w0 + (t << 6) + lane < T, act = in && zc != pa && zc != pb;
+                        // (the two UNCONDITIONAL stores: see the one-ahead loop below)
+                        ent[act && zc > pa ? adc - 1u - (zc > pb ? 1u : 0u) : dump] = ec;
+                        ent[in && zc + 1u == (rzc & 0x3FFFu) ? adc - 1u : dump] = (((rzc >> selsh) & 63u) << 15) | lm;
+                        if (act) retire_entry(ec, (rzc >> 15) & 31u, (rzc >> 21) & 31u, make_uint2(0, 0), make_uint2(0, 0));
+                    };
+                    uint32_t a0_, z0_, p0_, r0_, e0_, a1_, z1_, p1_, r1_, e1_, a2_, z2_, p2_, r2_, e2_;
+                    prep(0u, a0_, z0_, p0_, r0_, e0_); prep(1u, a1_, z1_, p1_, r1_, e1_);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): see the one-ahead loop below
+                    for (uint32_t t = 0;;) {
+                        prep(t + 2u, a2_, z2_, p2_, r2_, e2_); body3(t, a0_, z0_, p0_, r0_, e0_); if (++t >= ntw) break;
+                        prep(t + 2u, a0_, z0_, p0_, r0_, e0_); body3(t, a1_, z1_, p1_, r1_, e1_); if (++t >= ntw) break;
+                        prep(t + 2u, a1_, z1_, p1_, r1_, e1_); body3(t, a2_, z2_, p2_, r2_, e2_); if (++t >= ntw) break;
+                    }
 #else
                     uint32_t adc, zc, ppc, rzc, ec; prep(0u, adc, zc, ppc, rzc, ec);
                     // (the wait counters of the loop header merge both incoming edges: with the first entry still in flight here every
