@@ -1508,7 +1508,7 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                         adc = adn; zc = zn; ppc = ppn; rzc = rzn; ec = en;
                     }
                     settle();
-#elif !defined(PLO_BIG_PREFETCH1) && !defined(PLO_BIG_PROFILE) && !defined(PLO_BIG_DIRECT)
+#elif !defined(PLO_BIG_PREFETCH1) && !defined(PLO_BIG_PROFILE)
                     // Round 4 (default): entries are requested TWO trips ahead and the loop is unrolled three times, so that the three sets
                     // of trip registers (address, position in the row, the row's record words, the entry) rotate by NAME.  The one-ahead loop
                     // below ends in `ec = en`: a copy of the entry requested at the top of the same trip, i.e. a wait for that load at the
@@ -1523,6 +1523,22 @@ template <int MODE, bool DEFER, bool IDK> __device__ __forceinline__ uint64_t bi
                         // (the two UNCONDITIONAL stores: see the one-ahead loop below)
                         ent[act && zc > pa ? adc - 1u - (zc > pb ? 1u : 0u) : dump] = ec;
                         ent[in && zc + 1u == (rzc & 0x3FFFu) ? adc - 1u : dump] = (((rzc >> selsh) & 63u) << 15) | lm;
+#ifdef PLO_BIG_DIRECT
+                        if (use_direct) {
+                            const uint32_t cE = PLO_ECOL(ec), viE = PLO_EVI(ec) & 31u, viaE = (rzc >> 15) & 31u;
+                            const bool one = viE == viaE, mone = (rzc >> 31) != 0u && viE == ((rzc >> 26) & 31u);
+                            const bool dir = act && cE < P.dcols && (one || mone);
+                            if (dir) wg_add(&dcnt[cE], one ? 1u : 0x10000u);
+                            const bool qd = act && !dir;
+                            const uint64_t qm = __builtin_amdgcn_ballot_w64(qd);
+                            if (qm) {
+                                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                                if (qd) __hip_atomic_store(&wq[qn + rk], cE | (viE << 15) | (viaE << 20) | (((rzc >> 21) & 31u) << 25), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                qn += (uint32_t)__builtin_popcountll(qm);
+                                if (qn >= 64u) { drain(qn); qn -= 64u; }
+                            }
+                        } else
+#endif
                         if (act) retire_entry(ec, (rzc >> 15) & 31u, (rzc >> 21) & 31u, make_uint2(0, 0), make_uint2(0, 0));
                     };
                     uint32_t a0_, z0_, p0_, r0_, e0_, a1_, z1_, p1_, r1_, e1_, a2_, z2_, p2_, r2_, e2_;

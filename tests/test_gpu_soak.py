@@ -12,6 +12,7 @@ against the product's host engines.
   schedule enumeration 500 matrices x 96 schedules of the exhaustive tree (-E)                              (soak_misc.py --enum)
 
 A refusal the header documents (PLO_E_CAPACITY / PLO_E_UNSUPPORTED) is counted and bounded, anything else fails."""
+import os
 import random
 from concurrent.futures import ThreadPoolExecutor
 from fractions import Fraction
@@ -98,6 +99,8 @@ def test_hbm_family_on_matrices_the_literal_oracle_walks(hip):
     refits = 0
     for (s, m, n, rows), e in zip(cases, exp):
         rp, c, v = synth.to_csr(rows, P)
+        if os.environ.get("PLO_TEST_TRACE"):
+            print("case", s, m, n, len(c), len(set(v)), flush=True)
         plan = CSEPlan(m, n, rp, c, v, P, hbm=True)
         assert plan.is_hbm
         got = plan.cost_many(seed0=s * 10, n=3)
