@@ -562,14 +562,15 @@ __device__ __forceinline__ uint32_t dpart(uint64_t key, uint32_t pbits) { return
 __device__ __forceinline__ uint32_t dlslot(uint64_t key, uint32_t pbits, uint32_t lb) { return (uint32_t)((dmix(key) << pbits) >> (64u - lb)); }
 __device__ __forceinline__ bool dbloom_test(const uint32_t *bl, uint64_t key) {
     const uint64_t g = key * 0xD6E8FEB86659FD93ull;
-    const uint32_t i1 = (uint32_t)(g >> 47), i2 = (uint32_t)(g >> 30) & 0x1FFFFu;
-    const uint32_t w1 = __hip_atomic_load(&bl[i1 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), w2 = __hip_atomic_load(&bl[i2 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return (((w1 >> (i1 & 31u)) & (w2 >> (i2 & 31u))) & 1u) != 0u;
+    const uint32_t i1 = (uint32_t)(g >> 47), i2 = (uint32_t)(g >> 30) & 0x1FFFFu, i3 = (uint32_t)(g >> 13) & 0x1FFFFu;
+    const uint32_t w1 = __hip_atomic_load(&bl[i1 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), w2 = __hip_atomic_load(&bl[i2 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                   w3 = __hip_atomic_load(&bl[i3 >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (((w1 >> (i1 & 31u)) & (w2 >> (i2 & 31u)) & (w3 >> (i3 & 31u))) & 1u) != 0u;
 }
 __device__ __forceinline__ void dbloom_set(uint32_t *bl, uint64_t key) {
     const uint64_t g = key * 0xD6E8FEB86659FD93ull;
-    const uint32_t i1 = (uint32_t)(g >> 47), i2 = (uint32_t)(g >> 30) & 0x1FFFFu;
-    wg_or(&bl[i1 >> 5], 1u << (i1 & 31u)); wg_or(&bl[i2 >> 5], 1u << (i2 & 31u));
+    const uint32_t i1 = (uint32_t)(g >> 47), i2 = (uint32_t)(g >> 30) & 0x1FFFFu, i3 = (uint32_t)(g >> 13) & 0x1FFFFu;
+    wg_or(&bl[i1 >> 5], 1u << (i1 & 31u)); wg_or(&bl[i2 >> 5], 1u << (i2 & 31u)); wg_or(&bl[i3 >> 5], 1u << (i3 & 31u));
 }
 // slot of `key` in the hot table (v = its word), 0xFFFFFFFF when absent.  No slot is ever emptied between merges.
 __device__ __forceinline__ uint32_t hot_slot(const uint64_t *hot, uint64_t key, uint32_t hb, uint64_t &v) {
